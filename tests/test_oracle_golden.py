@@ -1,0 +1,157 @@
+"""Pins the CPU oracle (oracle/) to vectors produced by the reference itself (tests/golden/)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import load_golden, csr_from, close_scaled, formula_tensor
+from oracle import oracle as O
+from oracle import torch_path as TP
+
+
+def _same_csr(a, b, exact_values=True):
+    a, b = sp.csr_matrix(a), sp.csr_matrix(b)
+    a.sort_indices(); b.sort_indices()
+    assert a.shape == b.shape and a.nnz == b.nnz
+    assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+    assert np.array_equal(a.data.astype(np.float64), b.data.astype(np.float64))
+
+
+# --------------------------------------------------------------------------- k-core numbers
+def test_toy_kcore_known_answers():
+    g = load_golden("toy_kcore.npz")
+    for name in g["names"]:
+        n = int(g[name + "_n"])
+        e = g[name + "_edges"]
+        adj = O.adjacency_from_edge_rows(e[:, 0], e[:, 1], np.ones(len(e)), n)
+        assert np.array_equal(O.core_numbers(adj), g[name + "_core"]), name
+    # the reference's own toy graph shape: 4-clique + pendant, separate edge
+    assert g["clique_path_core"].tolist() == [3, 3, 3, 3, 1, 1, 1]
+
+
+def test_uci_core_numbers_and_kcore_files_bit_exact():
+    snaps = load_golden("uci_snapshots.npz")
+    kc = load_golden("uci_kcore.npz")
+    n = len(snaps["node_names"])
+    maxcores = []
+    for t in range(len(snaps["files"])):
+        adj = O.adjacency_from_edge_rows(snaps["t%d_src" % t], snaps["t%d_dst" % t], snaps["t%d_w" % t], n)
+        core = O.core_numbers(adj)
+        assert np.array_equal(core, kc["core_t%d" % t])
+        mats = O.kcore_matrices(adj, core)
+        files = [str(f) for f in kc["t%d_files" % t]]
+        assert files == O.core_file_names(len(mats))
+        maxcores.append(len(mats))
+        for f, m in zip(files, mats):
+            _same_csr(m, csr_from(kc, "t%d_%s" % (t, f[:-4]), n))
+    assert maxcores == [8, 16, 6, 5, 4, 3, 2]          # SURVEY.md §8a row a10 [probe]
+
+
+def _uci_mats():
+    kc = load_golden("uci_kcore.npz")
+    n = len(kc["core_t0"])
+    return [[csr_from(kc, "t%d_%s" % (t, str(f)[:-4]), n) for f in kc["t%d_files" % t]] for t in range(7)], n
+
+
+@pytest.mark.parametrize("tag,start,dur,mc,expectK", [
+    ("mcm1_", 0, 7, -1, [8, 8, 6, 5, 4, 3, 2]),       # quirk A: sticky max_core from snapshot 0
+    ("mc5_", 0, 7, 5, [5, 5, 5, 5, 4, 3, 2]),
+    ("w4_", 4, 3, -1, [4, 3, 2]),
+])
+def test_uci_loader_semantics(tag, start, dur, mc, expectK):
+    mats, n = _uci_mats()
+    ca = load_golden("uci_core_adj.npz")
+    got = O.core_adj_list(mats, start, dur, 7, max_core=mc)
+    assert [len(g) for g in got] == expectK == ca[tag + "K"].tolist()
+    for t, inner in enumerate(got):
+        for j, m in enumerate(inner):
+            _same_csr(m, csr_from(ca, tag + "t%d_j%d" % (t, j), n))
+    if tag == "mcm1_":
+        assert [m.nnz for m in got[0]] == [2677, 1506, 1872, 2208, 2500, 2830, 3236, 3542]
+    if tag == "mc5_":
+        assert [m.nnz for m in got[0]] == [4107, 2500, 2830, 3236, 3542]
+
+
+# ------------------------------------------------------------- weighted graphs, duplicates etc.
+def test_weighted_small_pipeline_and_aggregation():
+    g = load_golden("weighted_small.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        n = int(g[p + "n"])
+        per_snap = []
+        for s in range(2):
+            adj = O.adjacency_from_edge_rows(g[p + "s%d_src" % s], g[p + "s%d_dst" % s], g[p + "s%d_w" % s], n)
+            _same_csr(adj, csr_from(g, p + "s%d_dateadj" % s, n))           # utils.get_sp_adj_mat
+            core = O.core_numbers(adj)
+            assert np.array_equal(core, g[p + "s%d_core" % s])
+            mats = O.kcore_matrices(adj, core)
+            files = [str(f) for f in g[p + "core_t%d_files" % s]]
+            assert files == O.core_file_names(len(mats))
+            for f, m in zip(files, mats):
+                _same_csr(m, csr_from(g, p + "core_t%d_%s" % (s, f[:-4]), n))
+            per_snap.append(mats)
+        adj_list = O.core_adj_list(per_snap, 0, 2, 2, max_core=int(g[p + "max_core"]))
+        assert [len(a) for a in adj_list] == g[p + "adj_K"].tolist()
+        for t, inner in enumerate(adj_list):
+            for j, m in enumerate(inner):
+                _same_csr(m, csr_from(g, p + "adj_t%d_j%d" % (t, j), n))
+        # aggregation stage (layers.py:41-48,58) and its gradient
+        x = g[p + "cd_x"]
+        H = O.core_aggregate(adj_list[1], x)
+        close_scaled(H, g[p + "cd_agg"])
+        # full layer through the torch restatement, forward and dX
+        sd = {k[len(p + "cd_sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(p + "cd_sd_")}
+        xt = torch.from_numpy(x).requires_grad_(True)
+        tadj = [TP.coo_like_reference(m) for m in adj_list[1]]
+        out = TP.core_diffusion(sd, "", xt, tadj, str(g[p + "cd_rnn"]))
+        np.testing.assert_allclose(out.detach().numpy(), g[p + "cd_out"], rtol=1e-4, atol=1e-5)
+        (out * torch.from_numpy(g[p + "cd_gout"])).sum().backward()
+        np.testing.assert_allclose(xt.grad.numpy(), g[p + "cd_dx"], rtol=1e-4, atol=2e-5)
+
+
+def test_aggregate_backward_matches_autograd():
+    g = load_golden("weighted_small.npz")
+    p = "c1_"
+    n = int(g[p + "n"])
+    adj = [csr_from(g, p + "adj_t1_j%d" % j, n, np.float32) for j in range(int(g[p + "adj_K"][1]))]
+    x = torch.from_numpy(g[p + "cd_x"]).requires_grad_(True)
+    hs = TP.aggregate_loop([TP.coo_like_reference(m) for m in adj], x)
+    H = torch.stack(hs, 0).transpose(0, 1)
+    dH = torch.from_numpy(formula_tensor(tuple(H.shape), 0.7, 0.2))
+    (H * dH).sum().backward()
+    close_scaled(O.core_aggregate_bwd(adj, g[p + "cd_x"], dH.numpy()), x.grad.numpy(), rtol=2e-5, atol_scale=4e-6)
+
+
+# ----------------------------------------------------------------------------- whole models
+def _sd(g, tag):
+    return {k[len(tag + "sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "sd_")}
+
+
+def _uci_window(start, dur):
+    mats, n = _uci_mats()
+    adj = O.core_adj_list(mats, start, dur, 7, max_core=-1)
+    return [[TP.coo_like_reference(m) for m in inner] for inner in adj], n
+
+
+def test_models_match_reference_outputs():
+    g = load_golden("models_uci.npz")
+    start, dur = int(g["start"]), int(g["duration"])
+    adj, n = _uci_window(start, dur)
+    eye = [TP.coo_like_reference(sp.eye(n, format="csr")) for _ in range(dur)]
+    xd = [torch.from_numpy(a) for a in formula_tensor((dur, n, 24), 0.11, 0.3)]
+    tol = dict(rtol=1e-4, atol=2e-5)
+
+    out = TP.ctgcn(_sd(g, "ctgcn_c_"), eye, adj, "GRU", "C", "L")
+    np.testing.assert_allclose(out.numpy(), g["ctgcn_c_out"], **tol)
+    out, tr = TP.ctgcn(_sd(g, "ctgcn_s_"), xd, adj, "GRU", "S", "N")
+    np.testing.assert_allclose(out.numpy(), g["ctgcn_s_out"], **tol)
+    np.testing.assert_allclose(torch.stack(tr).numpy(), g["ctgcn_s_trans"], **tol)
+    out = TP.ctgcn(_sd(g, "ctgcn_c_lstm_"), xd, adj, "LSTM", "C", "L")
+    np.testing.assert_allclose(out.numpy(), g["ctgcn_c_lstm_out"], **tol)
+    out = TP.cgcn(_sd(g, "cgcn_c_"), xd, adj, "GRU", "C", "L")
+    np.testing.assert_allclose(torch.stack(out).numpy(), g["cgcn_c_out"], **tol)
+    out, tr = TP.cgcn(_sd(g, "cgcn_s_"), xd, adj, "GRU", "S", "N")
+    np.testing.assert_allclose(torch.stack(out).numpy(), g["cgcn_s_out"], **tol)
+    np.testing.assert_allclose(torch.stack(tr).numpy(), g["cgcn_s_trans"], **tol)
+    out = TP.cgcn(_sd(g, "cgcn_c_single_"), xd[0], adj[0], "GRU", "C", "N")
+    np.testing.assert_allclose(out.numpy(), g["cgcn_c_single_out"], **tol)

@@ -1,0 +1,69 @@
+"""ctypes binding of libctgcn_hip.so (C ABI: include/ctgcn_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+Build it with `python -m ctgcn_amd.build` (hipcc --offload-arch=gfx950) or __graft_entry__.build().
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libctgcn_hip.so")
+
+F_SELF_LOOP, F_RELU, F_NESTED = 1, 2, 4
+OP_KCORE = 1
+MAX_SLOTS = 255
+ABI_VERSION = 1
+
+_c = ctypes
+_vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_int, _c.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/ctgcn_hip.h declares
+SIGNATURES = {
+    "ctgcn_abi_version": (_int, []),
+    "ctgcn_last_error": (_c.c_char_p, []),
+    "ctgcn_device_info": (_int, [_c.c_char_p, _sz, _c.POINTER(_int)]),
+    "ctgcn_spmm_csr_f32": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp]),
+    "ctgcn_core_aggregate_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _u32, _vp]),
+    "ctgcn_core_aggregate_bwd_prep_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "ctgcn_core_aggregate_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u32, _vp]),
+    "ctgcn_kcore_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_i32), _vp]),
+    "ctgcn_edge_levels_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "ctgcn_workspace_bytes": (_sz, [_int, _i64, _i64, _i32, _i32]),
+}
+
+_lib = None
+
+
+class CtgcnHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once). Raises CtgcnHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CtgcnHipError(
+            "libctgcn_hip.so not found at %s — the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m ctgcn_amd.build`." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.ctgcn_abi_version() != ABI_VERSION:
+        raise CtgcnHipError("libctgcn_hip.so ABI %d != binding ABI %d; rebuild" % (lib.ctgcn_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ctgcn_last_error()
+        raise CtgcnHipError("%s failed (code %d): %s" % (what, rc, msg.decode("utf-8", "replace") if msg else ""))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()

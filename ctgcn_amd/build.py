@@ -1,0 +1,25 @@
+"""Build libctgcn_hip.so for gfx950 in-tree:  python -m ctgcn_amd.build [--force]"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "ctgcn_hip.hip")
+HDR = os.path.join(os.path.dirname(_HERE), "include", "ctgcn_hip.h")
+OUT = os.path.join(_HERE, "csrc", "libctgcn_hip.so")
+
+
+def build(force=False, verbose=False):
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(HDR))
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,277 @@
+"""CoreAdj — one snapshot's list of k-core adjacency matrices in the fused, slot-tagged CSR form
+the HIP aggregation kernel streams (include/ctgcn_hip.h: ctgcn_core_aggregate_f32).
+
+The reference keeps K separate N x N torch sparse COO tensors per snapshot (helper.py:51-82, 20 B per
+entry each).  Because k-core subgraphs are nested (A_kmax ⊆ ... ⊆ A_1) the same information is ONE CSR
+over the largest kept matrix plus a uint8 tag per entry: entry tagged s is present in matrices
+s, s+1, ..., K-1 ("slot" = position in the reference's adjacency list).  9 B per entry of the largest
+matrix instead of 20 B per entry of every matrix.  Lists that are not nested (arbitrary user supplied
+matrices) are kept too: then an entry is stored once per matrix containing it and the NESTED flag is off.
+
+Two builders:
+  * CoreAdj.from_matrices(...)      host side, from scipy matrices / torch sparse tensors (the .npz route)
+  * CoreAdj.from_graph(...)         device side, from the snapshot's CSR: k-core peel -> edge levels ->
+                                    slot table (host, O(max_core)) -> per-row stable partition, all HIP.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+_SENTINEL = 255
+
+
+class CoreAdj(object):
+    """Slot-tagged CSR of the K matrices the reference loader would return for one snapshot.
+
+    Quacks like the reference's inner list where it matters: len() == K, iteration yields torch sparse
+    COO tensors equal to the reference's (built lazily, for interop only — the models never use them).
+    """
+
+    def __init__(self, n, K, row_ptr, col, val, slot, self_loop, nested, symmetric, nnz_per_slot, levels=None):
+        self.n, self.K = int(n), int(K)
+        self.row_ptr, self.col, self.val, self.slot = row_ptr, col, val, slot
+        self.self_loop, self.nested, self.symmetric = bool(self_loop), bool(nested), bool(symmetric)
+        self.nnz_per_slot = [int(v) for v in nnz_per_slot]      # reference-semantics nnz(A_j), incl. the +I of slot 0
+        self.levels = None if levels is None else [int(v) for v in levels]   # k value of each slot (k-core route)
+        self._t = None                                           # transposed arrays, built on demand when not symmetric
+        assert 0 <= self.K <= _lib.MAX_SLOTS
+
+    # ------------------------------------------------------------------ list-like surface
+    def __len__(self):
+        return self.K
+
+    def __iter__(self):
+        return iter(self.to_torch_sparse_list())
+
+    @property
+    def nnz(self):
+        return int(self.col.numel())
+
+    @property
+    def device(self):
+        return self.col.device
+
+    @property
+    def flags(self):
+        return (_lib.F_SELF_LOOP if self.self_loop else 0) | (_lib.F_NESTED if self.nested else 0)
+
+    @property
+    def aggregated_edges(self):
+        """sum_k nnz(A_k): the numerator of the 'aggregated edges/s' metric for one CoreDiffusion call."""
+        return sum(self.nnz_per_slot)
+
+    def to(self, device):
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        out = CoreAdj(self.n, self.K, self.row_ptr.to(device), self.col.to(device), self.val.to(device),
+                      self.slot.to(device), self.self_loop, self.nested, self.symmetric, self.nnz_per_slot, self.levels)
+        if self._t is not None:
+            out._t = tuple(a.to(device) for a in self._t)
+        return out
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def cpu(self):
+        return self.to("cpu")
+
+    # ------------------------------------------------------------------ transposed view (backward pass)
+    def transposed(self):
+        """(row_ptr, col, val, slot) of the transposed matrices, same (row, slot, col) ordering."""
+        if self.symmetric:
+            return self.row_ptr, self.col, self.val, self.slot
+        if self._t is None:
+            dev = self.device
+            rows = torch.repeat_interleave(torch.arange(self.n, device=dev), (self.row_ptr[1:] - self.row_ptr[:-1]).long())
+            key = (self.col.long() * (self.K + 1) + self.slot.long()) * self.n + rows
+            order = torch.argsort(key, stable=True)
+            t_rows = self.col.long()[order]
+            counts = torch.bincount(t_rows, minlength=self.n)
+            t_ptr = torch.zeros(self.n + 1, dtype=torch.int64, device=dev)
+            t_ptr[1:] = torch.cumsum(counts, 0)
+            self._t = (t_ptr.to(torch.int32), rows[order].to(torch.int32).contiguous(), self.val[order].contiguous(),
+                       self.slot[order].contiguous())
+        return self._t
+
+    # ------------------------------------------------------------------ interop / tests
+    def to_scipy_list(self):
+        """The K matrices as scipy CSR float32, exactly what the reference loader's list holds (coalesced)."""
+        import scipy.sparse as sp
+        rp = self.row_ptr.cpu().numpy().astype(np.int64)
+        col = self.col.cpu().numpy()
+        val = self.val.cpu().numpy()
+        slot = self.slot.cpu().numpy().astype(np.int64)
+        rows = np.repeat(np.arange(self.n), np.diff(rp))
+        out = []
+        for j in range(self.K):
+            keep = (slot <= j) if self.nested else (slot == j)
+            m = sp.csr_matrix((val[keep], (rows[keep], col[keep])), shape=(self.n, self.n), dtype=np.float32)
+            if j == 0 and self.self_loop:
+                m = (m + sp.eye(self.n, dtype=np.float32, format="csr")).tocsr()
+            m.sum_duplicates()
+            m.sort_indices()
+            out.append(m)
+        return out
+
+    def to_torch_sparse_list(self):
+        out = []
+        for m in self.to_scipy_list():
+            coo = m.tocoo()
+            idx = torch.from_numpy(np.vstack((coo.row, coo.col)).astype(np.int64))
+            out.append(torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data), coo.shape).to(self.device))
+        return out
+
+    # ------------------------------------------------------------------ builder 1: host, from explicit matrices
+    @staticmethod
+    def from_matrices(mats, self_loop=None, device="cpu"):
+        """mats: the K matrices in list order (scipy sparse, or torch sparse COO/CSR tensors).
+
+        If `self_loop` is None, a first matrix of the form B + I (unit diagonal, B and every later matrix
+        zero-diagonal — what helper.py:71-72 produces) is detected and the diagonal is folded into the
+        SELF_LOOP flag.  Nestedness (identical entries forming a suffix of the list) is detected; lists
+        that are not nested are stored entry-per-matrix with NESTED off.
+        """
+        import scipy.sparse as sp
+        K = len(mats)
+        if K == 0:
+            raise ValueError("empty adjacency list")
+        if K > _lib.MAX_SLOTS:
+            raise ValueError("at most %d matrices per snapshot" % _lib.MAX_SLOTS)
+        sm = []
+        for m in mats:
+            if isinstance(m, torch.Tensor):
+                m = m.detach().cpu()
+                if m.layout != torch.sparse_coo:
+                    m = m.to_sparse_coo() if m.layout != torch.strided else m.to_sparse()
+                m = m.coalesce()
+                ii = m.indices().numpy()
+                m = sp.csr_matrix((m.values().numpy().astype(np.float32), (ii[0], ii[1])), shape=tuple(m.shape))
+            else:
+                m = sp.csr_matrix(m).astype(np.float32)
+                m.sum_duplicates()
+            sm.append(m)
+        n = sm[0].shape[0]
+        for m in sm:
+            if m.shape != (n, n):
+                raise ValueError("adjacency matrices must all be %d x %d" % (n, n))
+        nnz_per_slot = [int(m.nnz) for m in sm]
+
+        if self_loop is None:
+            d0 = sm[0].diagonal()
+            self_loop = bool(n > 0 and np.all(d0 == 1.0) and not any(m.diagonal().any() for m in sm[1:]))
+            strip = self_loop
+        else:
+            strip = False   # caller passes B and asks for B + I
+            if self_loop:
+                nnz_per_slot[0] += n
+        if strip:
+            first = sm[0].tolil()
+            first.setdiag(0)
+            first = first.tocsr()
+            first.eliminate_zeros()
+            sm[0] = first
+
+        rows = np.concatenate([m.tocoo().row for m in sm]).astype(np.int64)
+        cols = np.concatenate([m.tocoo().col for m in sm]).astype(np.int64)
+        vals = np.concatenate([m.tocoo().data for m in sm]).astype(np.float32)
+        tags = np.concatenate([np.full(m.nnz, j, dtype=np.int64) for j, m in enumerate(sm)])
+
+        # group identical (row, col); nested  <=>  every group is {s, s+1, ..., K-1} with one value
+        order = np.lexsort((tags, cols, rows))
+        rows, cols, vals, tags = rows[order], cols[order], vals[order], tags[order]
+        key = rows * n + cols
+        first_of_group = np.ones(len(key), dtype=bool)
+        first_of_group[1:] = key[1:] != key[:-1]
+        gid = np.cumsum(first_of_group) - 1
+        nested = True
+        if len(key):
+            gstart = np.flatnonzero(first_of_group)
+            gsize = np.diff(np.append(gstart, len(key)))
+            smin = tags[gstart]
+            if not np.array_equal(gsize, K - smin):      # a suffix has exactly K - s members (tags are distinct & sorted)
+                nested = False
+            elif not np.array_equal(vals, vals[gstart][gid]):
+                nested = False
+        if nested:
+            keep = first_of_group
+            rows, cols, vals, tags = rows[keep], cols[keep], vals[keep], tags[keep]
+        order = np.lexsort((cols, tags, rows))
+        rows, cols, vals, tags = rows[order], cols[order], vals[order], tags[order]
+        row_ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=n), out=row_ptr[1:])
+        if row_ptr[-1] >= 2 ** 31:
+            raise ValueError("more than 2^31-1 stored entries")
+
+        # symmetric (structure, value AND tag) -> the backward pass can reuse the same arrays
+        symmetric = False
+        if nested:
+            mv = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+            mt = sp.csr_matrix((tags + 1, (rows, cols)), shape=(n, n))
+            symmetric = bool((mv != mv.T).nnz == 0 and (mt != mt.T).nnz == 0)
+        adj = CoreAdj(n, K, torch.from_numpy(row_ptr.astype(np.int32)), torch.from_numpy(cols.astype(np.int32)),
+                      torch.from_numpy(vals), torch.from_numpy(tags.astype(np.uint8)), self_loop, nested, symmetric,
+                      nnz_per_slot)
+        return adj.to(device)
+
+    # ------------------------------------------------------------------ builder 2: device, from the snapshot graph
+    @staticmethod
+    def from_graph(row_ptr, col, val, max_core=-1, core=None):
+        """Device route.  row_ptr/col/val: CUDA tensors holding the snapshot's symmetric, zero-diagonal CSR
+        (int32/int32/float32).  Runs the HIP k-core peel (unless `core` is given), tags every entry with
+        level = min(core[u], core[v]) and applies the loader semantics of helper.py:51-82 through a
+        level -> slot table.  Returns (CoreAdj, core_numbers, file_count) where file_count is the number
+        of per-k files the reference would have written (= max core number), which the caller needs for
+        the sticky max_core rule (helper.py:61-62).
+        """
+        from . import ops
+        n = row_ptr.numel() - 1
+        if core is None:
+            core, max_k = ops.kcore(row_ptr, col)
+        else:
+            max_k = int(core.max().item()) if n else 0
+        file_count = max_k
+        if file_count == 0:
+            return None, core, 0
+        hist_len = file_count + 1
+        level, count, wsum = ops.edge_levels(row_ptr, col, val, core, hist_len)
+        table, K, levels, nnz_per_slot = slot_table(count.cpu().numpy(), wsum.cpu().numpy(), file_count, max_core, n)
+        col2, val2, slot2 = ops.slot_reorder(row_ptr, col, val, level, torch.from_numpy(table).to(col.device), K)
+        adj = CoreAdj(n, K, row_ptr, col2, val2, slot2, True, True, True, nnz_per_slot, levels)
+        return adj, core, file_count
+
+
+def slot_table(count, wsum, file_count, max_core, n):
+    """Loader semantics of helper.py:58-78 as a level -> slot table.
+
+    count[L] / wsum[L]: number / weight-sum of CSR entries whose level min(core[u],core[v]) is L
+    (L = 0..file_count).  Files 1..file_count exist (structure_generation.py:47-56); the loader keeps
+    k = 1..min(max_core, file_count) (helper.py:63) and visits them from the largest k down (helper.py:64).
+    Slot 0 = A_kept + I.  Going down, matrix A_k is dropped when (A_k - A_{k+1}).sum() == 0, i.e. when the
+    entries of level exactly k sum to zero (helper.py:74-76).  Returns (table uint8[file_count+1], K,
+    k-value per slot, reference nnz per slot).
+    """
+    count = np.asarray(count, dtype=np.int64)
+    wsum = np.asarray(wsum, dtype=np.float64)
+    kept = file_count if max_core < 0 else min(int(max_core), file_count)
+    if kept < 1:
+        raise ValueError("max_core must keep at least one k-core matrix")
+    table = np.full(file_count + 1, _SENTINEL, dtype=np.uint8)
+    table[kept:] = 0
+    levels = [kept]
+    nnz = [int(count[kept:].sum()) + n]
+    for k in range(kept - 1, 0, -1):
+        if wsum[k] == 0:
+            if count[k] != 0:
+                raise NotImplementedError(
+                    "entries of k-core level %d have weights that sum to zero; the reference drops that matrix "
+                    "but keeps its entries for later ones — use the .npz route (CoreAdj.from_matrices)" % k)
+            continue
+        if len(levels) >= _lib.MAX_SLOTS:
+            raise ValueError("more than %d distinct k-core matrices in one snapshot" % _lib.MAX_SLOTS)
+        table[k] = len(levels)
+        levels.append(k)
+        nnz.append(int(count[k:].sum()))
+    assert count[0] == 0, "an edge endpoint cannot have core number 0"
+    return table, len(levels), levels, nnz

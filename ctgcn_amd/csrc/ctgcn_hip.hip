@@ -1,0 +1,694 @@
+// ctgcn_hip.hip — hand-written gfx950 (MI355X, CDNA4) kernels for the CTGCN hot path and the
+// C ABI declared in include/ctgcn_hip.h.  Built with
+//     hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC
+// No torch types, no CUDA shims, no CPU fallback.
+//
+// Kernels (all HBM/latency bound — integer or fp32 gather work, nothing here is GEMM shaped):
+//   agg_fwd_kernel      CoreDiffusion aggregation loop (reference layers.py:41-48,58) fused over the
+//                       K nested k-core matrices; also serves plain CSR SpMM (layers.py:43,45).
+//   agg_bwd_kernel      its gradient w.r.t. X (slot-indexed gather of the suffix-summed dH).
+//   agg_bwd_prep_kernel relu-mask + (double) suffix sum along the core axis.
+//   kcore_*             level-synchronous k-core peel (structure_generation.py:35).
+//   edge_level_kernel   level(e)=min(core[u],core[v]) + per-level histogram (structure_generation.py:48-53).
+//   slot_reorder_kernel stable per-row partition by slot (helper.py:63-78 encoded as a table).
+//
+// Mapping used by the aggregation kernels (wave = 64 lanes):
+//   a row of X is d fp32 = d/4 float4 "chunks".  A row of the sparse matrix is owned by a group of
+//   LPR lanes (LPR = 8..64, power of two >= number of chunks, so d=128 -> 32 lanes, two rows per wave);
+//   lane i of the group owns chunk i of every gathered X row, so one gather is ONE coalesced
+//   16 B/lane load of the full 4*d-byte row.  The group's lanes first load LPR (col,val,slot) triples
+//   with one coalesced load each and then broadcast them with ds_bpermute, U gathers are issued
+//   back to back before the first is consumed.  Because the entries of a row are sorted by slot, the
+//   K outputs need only two accumulators per lane (P = running A_j·x, R = running res_j) whatever K is.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ctgcn_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) return fail(CTGCN_E_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int VEC> struct vec_of;
+template <> struct vec_of<4> { using type = f4; };
+template <> struct vec_of<1> { using type = float; };
+
+template <int VEC> __device__ __forceinline__ typename vec_of<VEC>::type vzero();
+template <> __device__ __forceinline__ f4 vzero<4>() { return f4{0.f, 0.f, 0.f, 0.f}; }
+template <> __device__ __forceinline__ float vzero<1>() { return 0.f; }
+
+__device__ __forceinline__ f4 vmax0(f4 v) { return f4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; }
+__device__ __forceinline__ float vmax0(float v) { return fmaxf(v, 0.f); }
+__device__ __forceinline__ f4 vfma(float a, f4 x, f4 acc)
+{
+    return f4{fmaf(a, x.x, acc.x), fmaf(a, x.y, acc.y), fmaf(a, x.z, acc.z), fmaf(a, x.w, acc.w)};
+}
+__device__ __forceinline__ float vfma(float a, float x, float acc) { return fmaf(a, x, acc); }
+
+struct AggArgs {
+    int64_t n;
+    int32_t d, K;
+    const int32_t *row_ptr;
+    const int32_t *col;
+    const float *val;
+    const uint8_t *slot;   // may be null: every entry is slot 0
+    const float *src;      // X [n, ldsrc]  (fwd)   or Z [n, K, d] (bwd)
+    int64_t ldsrc;
+    const float *self;     // bwd only: S0 [n, d] or null
+    float *out;            // fwd: H (row stride out_ld, slot stride d) ; bwd: dX (row stride out_ld)
+    int64_t out_ld;
+    uint32_t flags;
+    int32_t accumulate;
+    int32_t chunks;        // ceil(d / VEC)
+    int32_t passes;        // ceil(chunks / LPR)
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward: per row   R = [self] X[row];  for slot j: P (+)= sum_{e in slot j} val*X[col];  R += P;
+//                    out[row, j] = relu?(R)
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int LPR, int U>
+__global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a)
+{
+    using V = typename vec_of<VEC>::type;
+    const int lig = threadIdx.x & (LPR - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
+    if (row >= a.n) return;
+    const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0;
+    const bool relu = (a.flags & CTGCN_F_RELU) != 0;
+    const bool nested = (a.flags & CTGCN_F_NESTED) != 0;
+    const uint8_t *__restrict__ slot = a.slot;
+    const float *__restrict__ X = a.src;
+    float *__restrict__ outrow = a.out + row * a.out_ld;
+
+    for (int pass = 0; pass < a.passes; ++pass) {
+        const int ch = pass * LPR + lig;
+        const bool live = ch < a.chunks;
+        // dead lanes read chunk 0 (valid memory) and never store: keeps every load unconditional
+        const int64_t foff = live ? (int64_t)ch * VEC : 0;
+        V R = vzero<VEC>(), P = vzero<VEC>();
+        if (self) R = *(const V *)(X + row * a.ldsrc + foff);
+        int cur = 0;
+
+        auto close_slot = [&]() {
+            R += P;
+            if (!nested) P = vzero<VEC>();
+            V v = relu ? vmax0(R) : R;
+            if (live) {
+                V *o = (V *)(outrow + (int64_t)cur * a.d + foff);
+                if (a.accumulate) v += *o;
+                __builtin_nontemporal_store(v, o);
+            }
+            ++cur;
+        };
+
+        for (int base = start; base < end; base += LPR) {
+            const int my = base + lig;
+            int c = 0, s = 0;
+            float w = 0.f;
+            if (my < end) {
+                c = a.col[my];
+                w = a.val[my];
+                s = slot ? (int)slot[my] : 0;
+            }
+            const int cnt = min(LPR, end - base);
+            int j = 0;
+            for (; j + U <= cnt; j += U) {
+                V xv[U];
+                float wj[U];
+                int sj[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cj = __shfl(c, j + u, LPR);
+                    wj[u] = __shfl(w, j + u, LPR);
+                    sj[u] = __shfl(s, j + u, LPR);
+                    xv[u] = *(const V *)(X + (int64_t)cj * a.ldsrc + foff);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    while (cur < sj[u]) close_slot();
+                    P = vfma(wj[u], xv[u], P);
+                }
+            }
+            for (; j < cnt; ++j) {
+                const int cj = __shfl(c, j, LPR);
+                const float w1 = __shfl(w, j, LPR);
+                const int s1 = __shfl(s, j, LPR);
+                const V x1 = *(const V *)(X + (int64_t)cj * a.ldsrc + foff);
+                while (cur < s1) close_slot();
+                P = vfma(w1, x1, P);
+            }
+        }
+        while (cur < a.K) close_slot();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dX[row] = [self] S0[row] + sum_e val[e] * Z[col[e], slot[e], :]
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int LPR, int U>
+__global__ __launch_bounds__(256) void agg_bwd_kernel(const AggArgs a)
+{
+    using V = typename vec_of<VEC>::type;
+    const int lig = threadIdx.x & (LPR - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
+    if (row >= a.n) return;
+    const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    const uint8_t *__restrict__ slot = a.slot;
+    const float *__restrict__ Z = a.src;
+    const int64_t zrow = (int64_t)a.K * a.d;
+
+    for (int pass = 0; pass < a.passes; ++pass) {
+        const int ch = pass * LPR + lig;
+        const bool live = ch < a.chunks;
+        const int64_t foff = live ? (int64_t)ch * VEC : 0;
+        V P = vzero<VEC>();
+        if (a.self) P = *(const V *)(a.self + row * (int64_t)a.d + foff);
+        for (int base = start; base < end; base += LPR) {
+            const int my = base + lig;
+            int64_t off = 0;
+            float w = 0.f;
+            if (my < end) {
+                off = (int64_t)a.col[my] * zrow + (slot ? (int64_t)slot[my] * a.d : 0);
+                w = a.val[my];
+            }
+            const int cnt = min(LPR, end - base);
+            int j = 0;
+            for (; j + U <= cnt; j += U) {
+                V xv[U];
+                float wj[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t oj = __shfl(off, j + u, LPR);
+                    wj[u] = __shfl(w, j + u, LPR);
+                    xv[u] = *(const V *)(Z + oj + foff);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) P = vfma(wj[u], xv[u], P);
+            }
+            for (; j < cnt; ++j) {
+                const int64_t oj = __shfl(off, j, LPR);
+                const float w1 = __shfl(w, j, LPR);
+                P = vfma(w1, *(const V *)(Z + oj + foff), P);
+            }
+        }
+        if (live) {
+            V *o = (V *)(a.out + row * a.out_ld + foff);
+            if (a.accumulate) P += *o;
+            *o = P;
+        }
+    }
+}
+
+// G_j = dH_j*[H_j>0]; S_j = sum_{i>=j} G_i; Z_j = nested ? sum_{i>=j} S_i : S_j; S0 = S_0
+template <int VEC>
+__global__ __launch_bounds__(256) void agg_bwd_prep_kernel(int64_t n, int32_t d, int32_t K, int32_t chunks,
+                                                           const float *__restrict__ dH, const float *__restrict__ H,
+                                                           float *__restrict__ Z, float *__restrict__ S0, uint32_t flags)
+{
+    using V = typename vec_of<VEC>::type;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * chunks) return;
+    const int64_t row = idx / chunks;
+    const int64_t foff = (idx - row * chunks) * VEC;
+    const bool relu = (flags & CTGCN_F_RELU) != 0, nested = (flags & CTGCN_F_NESTED) != 0;
+    V s = vzero<VEC>(), t = vzero<VEC>();
+    for (int j = K - 1; j >= 0; --j) {
+        const int64_t o = (row * K + j) * d + foff;
+        V g = *(const V *)(dH + o);
+        if (relu) {
+            const V h = *(const V *)(H + o);
+            if constexpr (VEC == 4) {
+                g.x = h.x > 0.f ? g.x : 0.f; g.y = h.y > 0.f ? g.y : 0.f;
+                g.z = h.z > 0.f ? g.z : 0.f; g.w = h.w > 0.f ? g.w : 0.f;
+            } else {
+                g = h > 0.f ? g : 0.f;
+            }
+        }
+        s += g;
+        t += s;
+        *(V *)(Z + o) = nested ? t : s;
+    }
+    if (S0) *(V *)(S0 + row * d + foff) = s;
+}
+
+// ---------------------------------------------------------------------------------- launch helpers
+struct AggPlan { int vec, lpr, chunks, passes; };
+
+AggPlan plan_for(int d, bool vec4_ok)
+{
+    AggPlan p;
+    p.vec = vec4_ok ? 4 : 1;
+    p.chunks = (d + p.vec - 1) / p.vec;
+    int lpr = 8;
+    while (lpr < 64 && lpr < p.chunks) lpr <<= 1;
+    p.lpr = lpr;
+    p.passes = (p.chunks + lpr - 1) / lpr;
+    return p;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <bool FWD, int VEC, int LPR>
+void launch_agg_t(const AggArgs &a, hipStream_t st)
+{
+    constexpr int U = 4;
+    const int rows_per_block = 256 / LPR;
+    const int64_t blocks = (a.n + rows_per_block - 1) / rows_per_block;
+    if (FWD)
+        hipLaunchKernelGGL((agg_fwd_kernel<VEC, LPR, U>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((agg_bwd_kernel<VEC, LPR, U>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+
+template <bool FWD>
+int launch_agg(AggArgs a, bool vec4_ok, hipStream_t st)
+{
+    const AggPlan p = plan_for(a.d, vec4_ok);
+    a.chunks = p.chunks;
+    a.passes = p.passes;
+    if (a.n == 0) return CTGCN_OK;
+    const int64_t rows_per_block = 256 / p.lpr;
+    if ((a.n + rows_per_block - 1) / rows_per_block > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "grid too large");
+#define CASE(V, L) if (p.vec == V && p.lpr == L) { launch_agg_t<FWD, V, L>(a, st); }
+    CASE(4, 8) else CASE(4, 16) else CASE(4, 32) else CASE(4, 64)
+    else CASE(1, 8) else CASE(1, 16) else CASE(1, 32) else CASE(1, 64)
+#undef CASE
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+// ================================================================================================
+// k-core peel.  One kernel launch per level k (the launch boundary is the only grid-wide barrier):
+//   scan  — each block scans its own vertex range for unclaimed vertices with deg == k;
+//   chase — the block processes its queue; a neighbour whose degree drops to k is claimed by the
+//           thread whose atomicSub returned k+1 and appended to THIS block's queue (LDS, spilling
+//           to a per-block linked stack inside a shared pool of n entries: every vertex is pushed
+//           at most once in the whole run, so the pool cannot overflow).
+// deg[] only changes through device-scope atomics; a vertex's final deg is its core number.
+// ================================================================================================
+struct KcoreCtl {
+    int visited;
+    int pool_tail;
+    int max_core;
+    int pad[13];
+};
+
+constexpr int KC_QCAP = 8192;
+constexpr int KC_GROUP = 16;   // lanes cooperating on one vertex's neighbour list
+
+__global__ __launch_bounds__(256) void kcore_init_kernel(int n, const int32_t *__restrict__ row_ptr,
+                                                         const int32_t *__restrict__ col, int32_t *__restrict__ deg)
+{
+    const int lig = threadIdx.x & 7;
+    const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    if (v >= n) return;
+    int cnt = 0;
+    for (int e = row_ptr[v] + lig, end = row_ptr[v + 1]; e < end; e += 8) cnt += (col[e] != (int)v);
+    cnt += __shfl_xor(cnt, 1, 8);
+    cnt += __shfl_xor(cnt, 2, 8);
+    cnt += __shfl_xor(cnt, 4, 8);
+    if (lig == 0) deg[v] = cnt;
+}
+
+__device__ __forceinline__ bool kc_claim(unsigned *claimed, int v)
+{
+    const unsigned bit = 1u << (v & 31);
+    return (atomicOr(&claimed[v >> 5], bit) & bit) == 0;
+}
+
+__global__ __launch_bounds__(256) void kcore_level_kernel(int n, int k, int chunk, const int32_t *__restrict__ row_ptr,
+                                                          const int32_t *__restrict__ col, int32_t *deg,
+                                                          unsigned *claimed, int32_t *pool_v, int32_t *pool_prev,
+                                                          KcoreCtl *ctl)
+{
+    __shared__ int q[KC_QCAP];
+    __shared__ int s_tail, s_top;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_tail = 0; s_top = -1; }
+    __syncthreads();
+
+    auto push = [&](int u) {
+        const int pos = atomicAdd(&s_tail, 1);
+        if (pos < KC_QCAP) {
+            q[pos] = u;
+        } else {
+            const int p = atomicAdd(&ctl->pool_tail, 1);
+            pool_v[p] = u;
+            pool_prev[p] = atomicExch(&s_top, p);
+        }
+    };
+
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    for (int v = lo + tid; v < hi; v += 256)
+        if (__hip_atomic_load(&deg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k && kc_claim(claimed, v)) push(v);
+
+    const int grp = tid / KC_GROUP, lig = tid % KC_GROUP, ngrp = 256 / KC_GROUP;
+    int begin = 0, processed = 0;
+    for (;;) {
+        __syncthreads();
+        int tail = min(s_tail, KC_QCAP);
+        if (begin == tail) {
+            __syncthreads();               // everyone has read s_tail
+            if (tid == 0) {                // refill from this block's spill stack (rare)
+                int m = 0, top = s_top;
+                while (top >= 0 && m < KC_QCAP / 2) { q[m++] = pool_v[top]; top = pool_prev[top]; }
+                s_top = top;
+                s_tail = m;
+            }
+            __syncthreads();
+            begin = 0;
+            tail = s_tail;
+            if (tail == 0) break;
+        }
+        for (int i = begin + grp; i < tail; i += ngrp) {
+            const int v = q[i];
+            for (int e = row_ptr[v] + lig, end = row_ptr[v + 1]; e < end; e += KC_GROUP) {
+                const int u = col[e];
+                if (u == v) continue;
+                if (__hip_atomic_load(&deg[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) {
+                    const int old = atomicSub(&deg[u], 1);
+                    if (old == k + 1) {
+                        if (kc_claim(claimed, u)) push(u);
+                    } else if (old <= k) {
+                        atomicAdd(&deg[u], 1);
+                    }
+                }
+            }
+        }
+        processed += tail - begin;
+        begin = tail;
+    }
+    if (tid == 0 && processed) {
+        atomicAdd(&ctl->visited, processed);
+        atomicMax(&ctl->max_core, k);
+    }
+}
+
+// ------------------------------------------------------------------ edge levels + histogram
+constexpr int EL_HIST = 2048;
+
+__global__ __launch_bounds__(256) void edge_level_kernel(int64_t n, const int32_t *__restrict__ row_ptr,
+                                                         const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                         const int32_t *__restrict__ core, int32_t *__restrict__ level,
+                                                         unsigned long long *count, double *wsum, int hist_len)
+{
+    __shared__ unsigned long long h_cnt[EL_HIST];
+    __shared__ double h_sum[EL_HIST];
+    const bool want_hist = (count || wsum) && hist_len > 0;
+    const bool lds_hist = want_hist && hist_len <= EL_HIST;
+    if (lds_hist)
+        for (int i = threadIdx.x; i < hist_len; i += 256) { h_cnt[i] = 0; h_sum[i] = 0.0; }
+    __syncthreads();
+    const int lig = threadIdx.x & 15;
+    const int64_t rows_per_block = 16;
+    // grid-stride over rows so that the LDS histogram is flushed once per block
+    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + (threadIdx.x >> 4); row < n;
+         row += (int64_t)gridDim.x * rows_per_block) {
+        const int cr = core[row];
+        for (int e = row_ptr[row] + lig, end = row_ptr[row + 1]; e < end; e += 16) {
+            const int lv = min(cr, core[col[e]]);
+            level[e] = lv;
+            if (want_hist) {
+                const int b = min(lv, hist_len - 1);
+                if (lds_hist) {
+                    atomicAdd(&h_cnt[b], 1ull);
+                    if (wsum) atomicAdd(&h_sum[b], (double)val[e]);
+                } else {
+                    if (count) atomicAdd(&count[b], 1ull);
+                    if (wsum) atomicAdd(&wsum[b], (double)val[e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (lds_hist)
+        for (int i = threadIdx.x; i < hist_len; i += 256) {
+            if (count && h_cnt[i]) atomicAdd(&count[i], h_cnt[i]);
+            if (wsum && h_cnt[i]) atomicAdd(&wsum[i], h_sum[i]);
+        }
+}
+
+// ------------------------------------------------------------------ stable per-row partition by slot
+__global__ __launch_bounds__(256) void slot_reorder_kernel(int64_t n, int K, const int32_t *__restrict__ row_ptr,
+                                                           const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                           const int32_t *__restrict__ level,
+                                                           const uint8_t *__restrict__ table, int table_len,
+                                                           int32_t *__restrict__ col_out, float *__restrict__ val_out,
+                                                           uint8_t *__restrict__ slot_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int start = row_ptr[row], end = row_ptr[row + 1];
+    int out = start;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (end - start <= 64) {
+        // one chunk: keep the row in registers, sweep the slots
+        const int e = start + lane;
+        const bool valid = e < end;
+        int c = 0, s = -1;
+        float w = 0.f;
+        if (valid) { c = col[e]; w = val[e]; s = table[min(level[e], table_len - 1)]; }
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            // smallest slot among the entries not placed yet (slots are emitted in increasing order)
+            int cand = ((todo >> lane) & 1ull) ? s : 0x7fffffff;
+            for (int o = 32; o; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+            const bool hit = valid && s == cand;
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = out + __popcll(m & lt);
+                col_out[pos] = c; val_out[pos] = w; slot_out[pos] = (uint8_t)s;
+            }
+            out += __popcll(m);
+            todo &= ~m;
+        }
+        return;
+    }
+    for (int s = 0; s < K; ++s) {
+        for (int base = start; base < end; base += 64) {
+            const int e = base + lane;
+            const bool hit = e < end && (int)table[min(level[e], table_len - 1)] == s;
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = out + __popcll(m & lt);
+                col_out[pos] = col[e]; val_out[pos] = val[e]; slot_out[pos] = (uint8_t)s;
+            }
+            out += __popcll(m);
+        }
+    }
+}
+
+__global__ void kcore_copy_kernel(int n, const int32_t *__restrict__ deg, int32_t *__restrict__ core)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v < n) core[v] = deg[v];
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+// =================================================================================== C ABI
+extern "C" {
+
+int ctgcn_abi_version(void) { return CTGCN_ABI_VERSION; }
+
+const char *ctgcn_last_error(void) { return g_err; }
+
+int ctgcn_device_info(char *name_host, size_t name_len, int *cu_count_host)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (name_host && name_len) snprintf(name_host, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cu_count_host) *cu_count_host = prop.multiProcessorCount;
+    return CTGCN_OK;
+}
+
+int ctgcn_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *row_ptr, const int32_t *col_idx,
+                       const float *val, const float *X, int64_t ldx, float *Y, int64_t ldy,
+                       int accumulate, void *stream)
+{
+    if (n_rows < 0 || d <= 0 || ldx < d || ldy < d) return fail(CTGCN_E_INVALID, "spmm_csr: bad sizes n=%lld d=%d ldx=%lld ldy=%lld", (long long)n_rows, d, (long long)ldx, (long long)ldy);
+    if (n_rows == 0) return CTGCN_OK;
+    if (!row_ptr || !X || !Y) return fail(CTGCN_E_INVALID, "spmm_csr: null pointer");
+    AggArgs a{};
+    a.n = n_rows; a.d = d; a.K = 1;
+    a.row_ptr = row_ptr; a.col = col_idx; a.val = val; a.slot = nullptr;
+    a.src = X; a.ldsrc = ldx; a.self = nullptr; a.out = Y; a.out_ld = ldy;
+    a.flags = CTGCN_F_NESTED; a.accumulate = accumulate ? 1 : 0;
+    const bool v4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(X) && aligned16(Y);
+    return launch_agg<true>(a, v4, (hipStream_t)stream);
+}
+
+int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
+                             const int32_t *col_idx, const float *val, const uint8_t *slot,
+                             const float *X, int64_t ldx, float *H, uint32_t flags, void *stream)
+{
+    if (n_rows < 0 || d <= 0 || ldx < d) return fail(CTGCN_E_INVALID, "core_aggregate: bad sizes n=%lld d=%d ldx=%lld", (long long)n_rows, d, (long long)ldx);
+    if (K < 1 || K > CTGCN_MAX_SLOTS) return fail(CTGCN_E_INVALID, "core_aggregate: K=%d outside [1,%d]", K, CTGCN_MAX_SLOTS);
+    if (n_rows == 0) return CTGCN_OK;
+    if (!row_ptr || !X || !H) return fail(CTGCN_E_INVALID, "core_aggregate: null pointer");
+    if (!slot && K != 1) return fail(CTGCN_E_INVALID, "core_aggregate: slot tags required when K > 1");
+    AggArgs a{};
+    a.n = n_rows; a.d = d; a.K = K;
+    a.row_ptr = row_ptr; a.col = col_idx; a.val = val; a.slot = slot;
+    a.src = X; a.ldsrc = ldx; a.self = nullptr; a.out = H; a.out_ld = (int64_t)K * d;
+    a.flags = flags; a.accumulate = 0;
+    const bool v4 = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(X) && aligned16(H);
+    return launch_agg<true>(a, v4, (hipStream_t)stream);
+}
+
+int ctgcn_core_aggregate_bwd_prep_f32(int64_t n_rows, int32_t d, int32_t K, const float *dH,
+                                      const float *H, float *Z, float *S0, uint32_t flags, void *stream)
+{
+    if (n_rows < 0 || d <= 0 || K < 1 || K > CTGCN_MAX_SLOTS) return fail(CTGCN_E_INVALID, "bwd_prep: bad sizes");
+    if (n_rows == 0) return CTGCN_OK;
+    if (!dH || !Z || ((flags & CTGCN_F_RELU) && !H)) return fail(CTGCN_E_INVALID, "bwd_prep: null pointer");
+    const bool v4 = (d % 4 == 0) && aligned16(dH) && aligned16(Z) && (!H || aligned16(H)) && (!S0 || aligned16(S0));
+    const int vec = v4 ? 4 : 1;
+    const int chunks = (d + vec - 1) / vec;
+    const int64_t total = n_rows * chunks;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "bwd_prep: grid too large");
+    if (v4)
+        hipLaunchKernelGGL(agg_bwd_prep_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_rows, d, K, chunks, dH, H, Z, S0, flags);
+    else
+        hipLaunchKernelGGL(agg_bwd_prep_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_rows, d, K, chunks, dH, H, Z, S0, flags);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
+                                 const int32_t *col_idx, const float *val, const uint8_t *slot,
+                                 const float *Z, const float *S0, float *dX, int64_t lddx,
+                                 uint32_t flags, void *stream)
+{
+    if (n_rows < 0 || d <= 0 || lddx < d || K < 1 || K > CTGCN_MAX_SLOTS) return fail(CTGCN_E_INVALID, "core_aggregate_bwd: bad sizes");
+    if (n_rows == 0) return CTGCN_OK;
+    if (!row_ptr || !Z || !dX) return fail(CTGCN_E_INVALID, "core_aggregate_bwd: null pointer");
+    if (!slot && K != 1) return fail(CTGCN_E_INVALID, "core_aggregate_bwd: slot tags required when K > 1");
+    if ((flags & CTGCN_F_SELF_LOOP) && !S0) return fail(CTGCN_E_INVALID, "core_aggregate_bwd: S0 required with SELF_LOOP");
+    AggArgs a{};
+    a.n = n_rows; a.d = d; a.K = K;
+    a.row_ptr = row_ptr; a.col = col_idx; a.val = val; a.slot = slot;
+    a.src = Z; a.ldsrc = 0; a.self = (flags & CTGCN_F_SELF_LOOP) ? S0 : nullptr;
+    a.out = dX; a.out_ld = lddx; a.flags = flags; a.accumulate = 0;
+    const bool v4 = (d % 4 == 0) && (lddx % 4 == 0) && aligned16(Z) && aligned16(dX) && (!a.self || aligned16(a.self));
+    return launch_agg<false>(a, v4, (hipStream_t)stream);
+}
+
+size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t K)
+{
+    (void)nnz; (void)d; (void)K;
+    if (op == CTGCN_OP_KCORE) {
+        const size_t nn = (size_t)(n > 0 ? n : 0);
+        return align_up(sizeof(KcoreCtl), 256) + align_up(nn * 4, 256) /*deg*/ + align_up((nn + 31) / 32 * 4, 256) /*claimed*/
+               + 2 * align_up(nn * 4, 256) /*pool*/;
+    }
+    return 0;
+}
+
+int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, int32_t *core,
+                    void *workspace, size_t workspace_bytes, int32_t *max_core_host, void *stream)
+{
+    if (n < 0 || n > 0x7fffffffLL) return fail(CTGCN_E_INVALID, "kcore: n=%lld out of range", (long long)n);
+    if (max_core_host) *max_core_host = 0;
+    if (n == 0) return CTGCN_OK;
+    if (!row_ptr || !core || !workspace) return fail(CTGCN_E_INVALID, "kcore: null pointer");
+    const size_t need = ctgcn_workspace_bytes(CTGCN_OP_KCORE, n, 0, 0, 0);
+    if (workspace_bytes < need) return fail(CTGCN_E_WORKSPACE, "kcore: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    KcoreCtl *ctl = (KcoreCtl *)ws; ws += align_up(sizeof(KcoreCtl), 256);
+    int32_t *deg = (int32_t *)ws; ws += align_up((size_t)n * 4, 256);
+    unsigned *claimed = (unsigned *)ws; const size_t claimed_bytes = align_up(((size_t)n + 31) / 32 * 4, 256); ws += claimed_bytes;
+    int32_t *pool_v = (int32_t *)ws; ws += align_up((size_t)n * 4, 256);
+    int32_t *pool_prev = (int32_t *)ws;
+
+    HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(KcoreCtl), st));
+    HIP_TRY(hipMemsetAsync(claimed, 0, claimed_bytes, st));
+    const int nn = (int)n;
+    hipLaunchKernelGGL(kcore_init_kernel, dim3((unsigned)(((int64_t)nn * 8 + 255) / 256)), dim3(256), 0, st, nn, row_ptr, col_idx, deg);
+    HIP_TRY(hipGetLastError());
+
+    int blocks = (nn + 1023) / 1024;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    const int chunk = (nn + blocks - 1) / blocks;
+    constexpr int BATCH = 16;
+    KcoreCtl h{};
+    for (int level = 0;; level += BATCH) {
+        for (int b = 0; b < BATCH; ++b)
+            hipLaunchKernelGGL(kcore_level_kernel, dim3(blocks), dim3(256), 0, st, nn, level + b, chunk, row_ptr, col_idx, deg,
+                               claimed, pool_v, pool_prev, ctl);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&h, ctl, sizeof(KcoreCtl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h.visited >= nn) break;
+        if (level > nn) return fail(CTGCN_E_HIP, "kcore: did not converge (visited %d of %d)", h.visited, nn);
+    }
+    hipLaunchKernelGGL(kcore_copy_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, deg, core);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    if (max_core_host) *max_core_host = h.max_core;
+    return CTGCN_OK;
+}
+
+int ctgcn_edge_levels_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx,
+                          const float *val, const int32_t *core, int32_t *level,
+                          int64_t *count, double *wsum, int32_t hist_len, void *stream)
+{
+    if (n < 0 || hist_len < 0) return fail(CTGCN_E_INVALID, "edge_levels: bad sizes");
+    if (n == 0) return CTGCN_OK;
+    if (!row_ptr || !core) return fail(CTGCN_E_INVALID, "edge_levels: null pointer");
+    if (wsum && !val) return fail(CTGCN_E_INVALID, "edge_levels: val required for wsum");
+    int64_t blocks = (n + 15) / 16;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(edge_level_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, row_ptr, col_idx, val, core,
+                       level, (unsigned long long *)count, wsum, (int)hist_len);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32_t *col_idx,
+                       const float *val, const int32_t *level, const uint8_t *slot_of_level,
+                       int32_t table_len, int32_t *col_out, float *val_out, uint8_t *slot_out, void *stream)
+{
+    if (n < 0 || K < 1 || K > CTGCN_MAX_SLOTS || table_len < 1) return fail(CTGCN_E_INVALID, "slot_reorder: bad sizes");
+    if (n == 0) return CTGCN_OK;
+    if (!row_ptr || !slot_of_level) return fail(CTGCN_E_INVALID, "slot_reorder: null pointer");
+    if (col_idx && (col_out == col_idx || val_out == val)) return fail(CTGCN_E_INVALID, "slot_reorder: outputs alias inputs");
+    const int64_t blocks = (n + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "slot_reorder: grid too large");
+    hipLaunchKernelGGL(slot_reorder_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, (int)K, row_ptr, col_idx, val,
+                       level, slot_of_level, (int)table_len, col_out, val_out, slot_out);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+}  // extern "C"

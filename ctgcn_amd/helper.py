@@ -1,0 +1,127 @@
+"""DataLoader with the reference's constructor and get_core_adj_list signature (reference helper.py:12-82),
+returning one CoreAdj per snapshot instead of K torch sparse tensors per snapshot.
+
+get_core_adj_list reads the per-k .npz files the reference's preprocessing writes
+(<core_base_path>/<snapshot>/<kk>.npz, scipy CSR, N x N).  get_core_adj_list_from_graphs is the native route:
+it never materialises per-k files — snapshot edge lists go to the GPU, the HIP k-core peel tags every edge
+with its level, and the loader semantics are applied through a level -> slot table.
+"""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .core_adj import CoreAdj
+from .utils import get_sp_adj_mat, read_edge_rows, symmetric_csr_from_rows
+
+
+class DataLoader(object):
+    def __init__(self, node_list, max_time_num, has_cuda=False):
+        self.max_time_num = max_time_num
+        self.full_node_list = node_list
+        self.node_num = len(node_list)
+        self.node2idx_dict = dict(zip(node_list, np.arange(self.node_num)))
+        self.has_cuda = has_cuda
+
+    @property
+    def device(self):
+        return torch.device('cuda') if self.has_cuda else torch.device('cpu')
+
+    def _window(self, start_idx, duration):
+        return range(start_idx, min(start_idx + duration, self.max_time_num))
+
+    # ----------------------------------------------------------------------------- .npz route
+    def get_core_adj_list(self, core_base_path, start_idx, duration, max_core=-1):
+        """list[T] of CoreAdj (len(CoreAdj) == K_t).  Loader rules kept bit for bit (reference helper.py:51-82):
+        snapshots and files visited in sorted() order; max_core == -1 becomes the first visited snapshot's file
+        count and STAYS that for the rest of the window; files 1..max_core are kept and visited from the
+        largest k down; the first gets + I; a later matrix equal in sum to its predecessor is dropped."""
+        date_dirs = sorted(os.listdir(core_base_path))
+        assert start_idx < len(date_dirs)
+        window = []
+        for i in self._window(start_idx, duration):
+            folder = os.path.join(core_base_path, date_dirs[i])
+            names = sorted(os.listdir(folder))
+            if max_core == -1:
+                max_core = len(names)
+            chosen = names[:max_core][::-1]
+            kept, prev = [], None
+            for j, name in enumerate(chosen):
+                mat = sp.load_npz(os.path.join(folder, name))
+                if j > 0 and (mat - prev).sum() == 0:
+                    prev = mat
+                    continue
+                prev = mat
+                kept.append(mat)
+            if not kept:
+                window.append([])       # snapshot without edges: the reference also yields an empty list
+                continue
+            window.append(CoreAdj.from_matrices(kept, self_loop=True, device=self.device))
+        return window
+
+    # -------------------------------------------------------------------------- native route
+    def get_core_adj_list_from_graphs(self, origin_base_path, start_idx, duration, max_core=-1, sep='\t',
+                                      return_core_numbers=False):
+        """Same result as preprocessing (structure_generation.py) followed by get_core_adj_list, computed on
+        the GPU straight from the snapshot edge lists under origin_base_path."""
+        if not self.has_cuda:
+            raise RuntimeError("the native route runs the HIP k-core peel: construct DataLoader(has_cuda=True)")
+        files = sorted(os.listdir(origin_base_path))
+        assert start_idx < len(files)
+        window, cores = [], []
+        for i in self._window(start_idx, duration):
+            src, dst, w = read_edge_rows(os.path.join(origin_base_path, files[i]), self.node2idx_dict, sep)
+            csr = symmetric_csr_from_rows(src, dst, w, self.node_num)
+            adj, core, file_count = core_adj_from_scipy(csr, max_core, self.device)
+            if max_core == -1:
+                max_core = file_count
+            window.append(adj if adj is not None else [])
+            cores.append(core)
+        return (window, cores) if return_core_numbers else window
+
+    # --------------------------------------------------- thin plumbing kept for reference-shaped drivers
+    def get_date_adj_list(self, origin_base_path, start_idx, duration, sep='\t', normalize=False, row_norm=False,
+                          add_eye=False, data_type='tensor'):
+        """Snapshot adjacency matrices (reference helper.py:27-47); core-based methods only use them to derive
+        edge lists (train.py:60-62).  Normalisation is not part of the CTGCN path and is not offered."""
+        assert data_type in ['tensor', 'matrix']
+        if normalize:
+            raise NotImplementedError("normalised adjacency is only used by the reference's baselines")
+        files = sorted(os.listdir(origin_base_path))
+        out = []
+        for i in self._window(start_idx, duration):
+            mat = get_sp_adj_mat(os.path.join(origin_base_path, files[i]), self.full_node_list, sep=sep)
+            if add_eye:
+                mat = (mat + sp.eye(mat.shape[0])).tocoo()
+            out.append(_coo_tensor(mat, self.device) if data_type == 'tensor' else mat)
+        return out
+
+    def get_feature_list(self, feature_base_path, start_idx, duration, sep='\t', shuffle=False):
+        """One-hot (sparse identity) node features when no feature files exist (reference helper.py:161-172)."""
+        if feature_base_path is not None:
+            raise NotImplementedError("feature files are outside the CTGCN hot path; pass dense tensors directly")
+        x_list = []
+        for _ in self._window(start_idx, duration):
+            cols = np.random.permutation(self.node_num) if shuffle else np.arange(self.node_num)
+            mat = sp.coo_matrix((np.ones(self.node_num), (np.arange(self.node_num), cols)), shape=(self.node_num,) * 2)
+            x_list.append(_coo_tensor(mat, self.device))
+        return x_list, self.node_num
+
+
+def _coo_tensor(mat, device):
+    mat = mat.tocoo()
+    idx = torch.from_numpy(np.vstack((mat.row, mat.col)).astype(np.int64))
+    return torch.sparse_coo_tensor(idx, torch.from_numpy(mat.data).float(), torch.Size(mat.shape)).to(device)
+
+
+def core_adj_from_scipy(csr, max_core, device):
+    """Upload a symmetric zero-diagonal scipy CSR and run the device builder (CoreAdj.from_graph)."""
+    csr = sp.csr_matrix(csr)
+    csr.sort_indices()
+    if csr.nnz >= 2 ** 31:
+        raise ValueError("more than 2^31-1 stored entries")
+    row_ptr = torch.from_numpy(csr.indptr.astype(np.int32)).to(device)
+    col = torch.from_numpy(csr.indices.astype(np.int32)).to(device)
+    val = torch.from_numpy(csr.data.astype(np.float32)).to(device)
+    return CoreAdj.from_graph(row_ptr, col, val, max_core=max_core)

@@ -1,0 +1,84 @@
+"""CoreDiffusion and MLP layers with the reference's constructor/forward signatures and state_dict keys
+(reference layers.py:9-63 and :67-106), running the sparse aggregation on the HIP kernel.
+
+Only the aggregation (reference layers.py:41-48 + the stack/transpose of :58) is replaced; the core-axis
+GRU/LSTM, the sum over cores and the LayerNorm stay PyTorch-ROCm modules (dense, MFMA via MIOpen/hipBLASLt).
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from .core_adj import CoreAdj
+
+_RNN = {"GRU": nn.GRU, "LSTM": nn.LSTM}
+_adj_cache = {}
+
+
+def as_core_adj(adj_list, device):
+    """Accept what the reference's callers pass: a CoreAdj (our loader) or a python list of torch sparse
+    matrices (reference loader, helper.py:51-82).  Lists are fused once and cached by identity."""
+    if isinstance(adj_list, CoreAdj):
+        return adj_list if adj_list.device == device else adj_list.to(device)
+    key = tuple((id(a), a._values().data_ptr() if a.is_sparse else a.data_ptr()) for a in adj_list) + (str(device),)
+    hit = _adj_cache.get(key)
+    if hit is None:
+        if len(_adj_cache) > 256:
+            _adj_cache.clear()
+        hit = _adj_cache[key] = CoreAdj.from_matrices(list(adj_list), device=device)
+    return hit
+
+
+class CoreDiffusion(nn.Module):
+    """K-core diffusion layer: H_j = relu(sum_{i<=j} A_i x), RNN over j, sum over j, LayerNorm."""
+
+    def __init__(self, input_dim, output_dim, core_num=1, bias=True, rnn_type='GRU'):
+        super().__init__()
+        assert rnn_type in _RNN
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.core_num, self.bias, self.rnn_type = core_num, bias, rnn_type
+        # `linear` is never used in forward (nor in the reference, layers.py:24) but is part of the checkpoint schema
+        self.linear = nn.Linear(input_dim, output_dim)
+        self.rnn = _RNN[rnn_type](input_size=input_dim, hidden_size=output_dim, num_layers=1, bias=bias, batch_first=True)
+        self.norm = nn.LayerNorm(output_dim)
+
+    def aggregate(self, x, adj_list):
+        """[N, K, input_dim] = all K rectified cumulative aggregations, one kernel launch."""
+        return ops.core_aggregate(x, as_core_adj(adj_list, x.device), relu=True)
+
+    def forward(self, x, adj_list):
+        seq = self.aggregate(x, adj_list)            # [batch = N, seq = K, feat]
+        states, _ = self.rnn(seq)
+        return self.norm(states.sum(dim=1))
+
+
+class MLP(nn.Module):
+    """Stack of Linear layers, SELU after each when activate_type == 'N' (reference layers.py:67-106).
+    Key names: `linear.*` for one layer, `linears.{i}.*` otherwise."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, layer_num, bias=True, activate_type='N'):
+        super().__init__()
+        assert activate_type in ['L', 'N']
+        assert layer_num > 0
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.layer_num, self.bias, self.activate_type = layer_num, bias, activate_type
+        if layer_num == 1:
+            self.linear = nn.Linear(input_dim, output_dim, bias=bias)
+        else:
+            widths = [input_dim] + [hidden_dim] * (layer_num - 1) + [output_dim]
+            self.linears = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(widths[:-1], widths[1:]))
+
+    @staticmethod
+    def _apply_linear(layer, h):
+        if h.is_sparse:          # one-hot / sparse features (helper.py:161-172): sparse @ W^T
+            out = torch.sparse.mm(h, layer.weight.t())
+            return out if layer.bias is None else out + layer.bias
+        return layer(h)
+
+    def forward(self, x):
+        stack = [self.linear] if self.layer_num == 1 else list(self.linears)
+        for layer in stack:
+            x = self._apply_linear(layer, x)
+            if self.activate_type == 'N':
+                x = F.selu(x)
+        return x

@@ -1,0 +1,116 @@
+"""CDN / CGCN / CTGCN with the reference's signatures, attribute names (incl. the `duffision` spelling the
+checkpoints depend on) and return conventions — reference models.py:8-42, 129-187, 191-253.
+
+CTGCN additionally supports snapshot-parallel execution (one process per GPU, snapshots sharded over
+ranks, one all-gather of the per-snapshot hidden states right before the temporal RNN) — see
+ctgcn_amd/snapshot_parallel.py.  With no process group the behaviour is the reference's.
+"""
+import torch
+from torch import nn
+
+from .layers import CoreDiffusion, MLP
+from . import snapshot_parallel as sp_par
+
+
+class CDN(nn.Module):
+    """Stack of CoreDiffusion layers applied to the SAME adjacency list."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, diffusion_num, bias=True, rnn_type='GRU'):
+        super().__init__()
+        if diffusion_num < 1:
+            raise ValueError("number of layers should be positive!")
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.diffusion_num, self.bias, self.rnn_type = diffusion_num, bias, rnn_type
+        dims = [input_dim] + [hidden_dim] * (diffusion_num - 1) + [output_dim]
+        self.diffusion_list = nn.ModuleList(
+            CoreDiffusion(a, b, bias=bias, rnn_type=rnn_type) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x, adj_list):
+        for layer in self.diffusion_list:
+            x = layer(x, adj_list)
+        return x
+
+
+def _check_types(model_type, trans_activate_type):
+    assert model_type in ['C', 'S']
+    assert trans_activate_type in ['L', 'N']
+
+
+def _branch_dims(model_type, hidden_dim, output_dim):
+    """(mlp output width, CDN input width): 'C' diffuses at hidden width, 'S' at output width."""
+    return (hidden_dim, hidden_dim) if model_type == 'C' else (output_dim, output_dim)
+
+
+class CGCN(nn.Module):
+    """Static k-core GCN: one shared MLP + CDN applied to a snapshot or to each snapshot of a list."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, trans_num, diffusion_num, bias=True, rnn_type='GRU',
+                 model_type='C', trans_activate_type='L'):
+        super().__init__()
+        _check_types(model_type, trans_activate_type)
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.trans_num, self.diffusion_num, self.bias = trans_num, diffusion_num, bias
+        self.rnn_type, self.model_type, self.trans_activate_type = rnn_type, model_type, trans_activate_type
+        self.method_name = 'CGCN-' + model_type
+        mlp_out, cdn_in = _branch_dims(model_type, hidden_dim, output_dim)
+        self.mlp = MLP(input_dim, hidden_dim, mlp_out, trans_num, bias=bias, activate_type=trans_activate_type)
+        self.duffision = CDN(cdn_in, output_dim, output_dim, diffusion_num, rnn_type=rnn_type)
+
+    def cgcn(self, x, adj):
+        trans = self.mlp(x)
+        emb = self.duffision(trans, adj)
+        return (emb, trans) if self.model_type == 'S' else emb
+
+    def forward(self, x, adj):
+        if not isinstance(x, list):
+            return self.cgcn(x, adj)
+        results = [self.cgcn(x_t, adj_t) for x_t, adj_t in zip(x, adj)]
+        if self.model_type == 'C':
+            return results
+        return [r[0] for r in results], [r[1] for r in results]
+
+
+class CTGCN(nn.Module):
+    """Temporal k-core GCN: per-snapshot MLP + CDN (own weights per snapshot), then a GRU/LSTM over time and
+    a LayerNorm.  Returns [T, N, output_dim] ('C') or that plus the per-snapshot MLP outputs ('S')."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, trans_num, diffusion_num, duration, bias=True, rnn_type='GRU',
+                 model_type='C', trans_activate_type='L'):
+        super().__init__()
+        _check_types(model_type, trans_activate_type)
+        assert rnn_type in ['LSTM', 'GRU']
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.rnn_type, self.model_type, self.trans_activate_type = rnn_type, model_type, trans_activate_type
+        self.method_name = 'CTGCN-' + model_type
+        self.duration, self.trans_num, self.diffusion_num, self.bias = duration, trans_num, diffusion_num, bias
+        mlp_out, cdn_in = _branch_dims(model_type, hidden_dim, output_dim)
+        self.mlp_list = nn.ModuleList(
+            MLP(input_dim, hidden_dim, mlp_out, trans_num, bias=bias, activate_type=trans_activate_type)
+            for _ in range(duration))
+        self.duffision_list = nn.ModuleList(
+            CDN(cdn_in, output_dim, output_dim, diffusion_num, rnn_type=rnn_type) for _ in range(duration))
+        rnn_cls = nn.LSTM if rnn_type == 'LSTM' else nn.GRU
+        self.rnn = rnn_cls(output_dim, output_dim, num_layers=1, bias=bias, batch_first=True)
+        self.norm = nn.LayerNorm(output_dim)
+        self.process_group = None      # set by snapshot_parallel.shard_ctgcn()
+
+    def snapshot_branch(self, t, x, adj):
+        """Everything that is independent per snapshot: reference models.py:244-246."""
+        trans = self.mlp_list[t](x)
+        return self.duffision_list[t](trans, adj), trans
+
+    def temporal_head(self, hx):
+        """hx [N, T, d] -> [T, N, d]: reference models.py:249-250."""
+        out, _ = self.rnn(hx)
+        return self.norm(out).transpose(0, 1)
+
+    def forward(self, x_list, adj_list):
+        if self.process_group is not None:
+            return sp_par.ctgcn_forward_sharded(self, x_list, adj_list)
+        hx, trans = [], []
+        for t in range(len(x_list)):
+            h, tr = self.snapshot_branch(t, x_list[t], adj_list[t])
+            hx.append(h)
+            trans.append(tr)
+        out = self.temporal_head(torch.stack(hx).transpose(0, 1))
+        return out if self.model_type == 'C' else (out, trans)

@@ -1,0 +1,180 @@
+"""Torch-facing wrappers over the C ABI (include/ctgcn_hip.h).  PyTorch is plumbing here: it owns
+device memory, streams and the autograd graph; every kernel is in libctgcn_hip.so.
+
+All entry points require CUDA (ROCm) tensors and raise otherwise — there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.CtgcnHipError(
+                "ctgcn_amd runs on MI355X only: got a %s tensor. Move inputs (features and CoreAdj) to the GPU; "
+                "there is no CPU fallback." % t.device)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_launch_timer = None
+
+
+def set_launch_timer(callback):
+    """callback(name, start_event, end_event, meta) is invoked for every aggregation launch with HIP events
+    recorded on the launch stream right before / after the kernel (bench.py's roofline measurement).
+    None disables it (default)."""
+    global _launch_timer
+    _launch_timer = callback
+
+
+class _timed(object):
+    def __init__(self, name, **meta):
+        self.name, self.meta = name, meta
+
+    def __enter__(self):
+        if _launch_timer is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _launch_timer is not None and exc[0] is None:
+            self.end.record()
+            _launch_timer(self.name, self.start, self.end, self.meta)
+        return False
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------- k-core
+def kcore(row_ptr, col):
+    """Core number of every vertex (reference: networkx.core_number at structure_generation.py:35).
+    row_ptr/col: symmetric CSR structure on the GPU.  Returns (core int32[n] on the GPU, max core)."""
+    _need_cuda(row_ptr, col)
+    lib = _lib.load()
+    row_ptr, col = _i32(row_ptr), _i32(col)
+    n = row_ptr.numel() - 1
+    core = torch.empty(n, dtype=torch.int32, device=row_ptr.device)
+    if n == 0:
+        return core, 0
+    with torch.cuda.device(row_ptr.device):
+        nbytes = lib.ctgcn_workspace_bytes(_lib.OP_KCORE, n, col.numel(), 0, 0)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=row_ptr.device)
+        mx = ctypes.c_int32(0)
+        check(lib.ctgcn_kcore_i32(n, ptr(row_ptr), ptr(col), ptr(core), ptr(ws), nbytes, ctypes.byref(mx), _stream()),
+              "ctgcn_kcore_i32")
+    return core, int(mx.value)
+
+
+def edge_levels(row_ptr, col, val, core, hist_len):
+    """level[e] = min(core[row], core[col]) plus the per-level entry count / weight sum."""
+    _need_cuda(row_ptr, col, val, core)
+    lib = _lib.load()
+    n = row_ptr.numel() - 1
+    dev = row_ptr.device
+    level = torch.empty(col.numel(), dtype=torch.int32, device=dev)
+    count = torch.zeros(hist_len, dtype=torch.int64, device=dev)
+    wsum = torch.zeros(hist_len, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ctgcn_edge_levels_i32(n, ptr(row_ptr), ptr(col), ptr(val), ptr(core), ptr(level), ptr(count), ptr(wsum),
+                                        hist_len, _stream()), "ctgcn_edge_levels_i32")
+    return level, count, wsum
+
+
+def slot_reorder(row_ptr, col, val, level, table, K):
+    _need_cuda(row_ptr, col, val, level, table)
+    lib = _lib.load()
+    n = row_ptr.numel() - 1
+    col2, val2 = torch.empty_like(col), torch.empty_like(val)
+    slot2 = torch.empty(col.numel(), dtype=torch.uint8, device=col.device)
+    with torch.cuda.device(col.device):
+        check(lib.ctgcn_slot_reorder(n, K, ptr(row_ptr), ptr(col), ptr(val), ptr(level), ptr(table), table.numel(),
+                                     ptr(col2), ptr(val2), ptr(slot2), _stream()), "ctgcn_slot_reorder")
+    return col2, val2, slot2
+
+
+# ------------------------------------------------------------------------------------- plain SpMM
+def spmm_csr(row_ptr, col, val, x, out=None, accumulate=False):
+    """Y = A·X (or Y += A·X): one torch.sparse.mm of layers.py:43/45."""
+    _need_cuda(row_ptr, col, val, x)
+    lib = _lib.load()
+    if x.dtype != torch.float32:
+        raise TypeError("fp32 features expected")
+    x = x if x.stride(-1) == 1 else x.contiguous()
+    n = row_ptr.numel() - 1
+    d = x.shape[1]
+    if out is None:
+        out = torch.empty(n, d, dtype=torch.float32, device=x.device)
+        accumulate = False
+    with torch.cuda.device(x.device):
+        check(lib.ctgcn_spmm_csr_f32(n, d, ptr(row_ptr), ptr(col), ptr(val), ptr(x), x.stride(0), ptr(out), out.stride(0),
+                                     1 if accumulate else 0, _stream()), "ctgcn_spmm_csr_f32")
+    return out
+
+
+# -------------------------------------------------------------------- CoreDiffusion aggregation
+def _aggregate_fwd(adj, x, relu):
+    lib = _lib.load()
+    n, d = x.shape
+    H = torch.empty(n, adj.K, d, dtype=torch.float32, device=x.device)
+    flags = adj.flags | (_lib.F_RELU if relu else 0)
+    with torch.cuda.device(x.device), _timed("agg_fwd", n=n, d=d, K=adj.K, nnz=adj.nnz):
+        check(lib.ctgcn_core_aggregate_f32(n, d, adj.K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x),
+                                           x.stride(0), ptr(H), flags, _stream()), "ctgcn_core_aggregate_f32")
+    return H
+
+
+def _aggregate_bwd(adj, H, dH, relu):
+    lib = _lib.load()
+    n, K, d = dH.shape
+    flags = adj.flags | (_lib.F_RELU if relu else 0)
+    Z = torch.empty_like(dH)
+    S0 = torch.empty(n, d, dtype=torch.float32, device=dH.device) if adj.self_loop else None
+    dX = torch.empty(n, d, dtype=torch.float32, device=dH.device)
+    t_ptr, t_col, t_val, t_slot = adj.transposed()
+    with torch.cuda.device(dH.device):
+        check(lib.ctgcn_core_aggregate_bwd_prep_f32(n, d, K, ptr(dH), ptr(H), ptr(Z), ptr(S0), flags, _stream()),
+              "ctgcn_core_aggregate_bwd_prep_f32")
+        check(lib.ctgcn_core_aggregate_bwd_f32(n, d, K, ptr(t_ptr), ptr(t_col), ptr(t_val), ptr(t_slot), ptr(Z), ptr(S0),
+                                               ptr(dX), d, flags, _stream()), "ctgcn_core_aggregate_bwd_f32")
+    return dX
+
+
+class _CoreAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj, relu):
+        H = _aggregate_fwd(adj, x, relu)
+        ctx.adj, ctx.relu = adj, relu
+        ctx.save_for_backward(H)
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        (H,) = ctx.saved_tensors
+        dH = dH.contiguous()
+        return _aggregate_bwd(ctx.adj, H, dH, ctx.relu), None, None
+
+
+def core_aggregate(x, adj, relu=True):
+    """H[N, K, d] with H[:, j, :] = relu(sum_{i<=j} A_i x)  — layers.py:41-48 and the layout of :58."""
+    _need_cuda(x, adj.col)
+    if adj.K < 1:
+        raise ValueError("empty k-core adjacency list")
+    if x.dim() != 2 or x.shape[0] != adj.n:
+        raise ValueError("features must be [%d, d], got %s" % (adj.n, tuple(x.shape)))
+    if x.dtype != torch.float32:
+        raise TypeError("fp32 features expected")
+    if x.device != adj.device:
+        raise ValueError("features on %s but adjacency on %s" % (x.device, adj.device))
+    x = x if x.stride(1) == 1 else x.contiguous()
+    return _CoreAggregate.apply(x, adj, relu)

@@ -1,0 +1,195 @@
+"""Snapshot-parallel CTGCN: one process per GPU, snapshots of a temporal window sharded over ranks.
+
+Until the temporal RNN (reference models.py:248) every snapshot t is independent AND owns its own weights
+(mlp_list[t], duffision_list[t], models.py:225-231), so a rank that owns snapshot t needs only that
+snapshot's graph, features, weights and optimizer state.  There is exactly one exchange step, placed where
+the reference stacks the per-snapshot states (models.py:248):
+
+  exchange="all_to_all" (default)  each rank keeps ONLY its node slice [N/G] of every snapshot's state and
+      runs the temporal GRU/LSTM + LayerNorm on that slice: one all-to-all of (T/G)·N·d·4 B sent per rank
+      (1/G of an all-gather's received volume), and the temporal step scales with G as well.
+  exchange="all_gather"            every rank receives every snapshot's full state (RCCL all-gather over
+      xGMI, as BASELINE.json's north_star words it) and runs the temporal step on its node slice
+      (or on all nodes with replicate_head=True).
+
+Backward is the transposed collective (all-to-all / reduce-scatter).  The temporal rnn/norm weights are
+replicated; sum their grads with allreduce_replicated_grads() after backward.  With gather_output=True the
+output node slices are all-gathered so every rank returns the reference's full [T, N, d].
+
+The backend is whatever the process group was created with: "nccl" (= RCCL) on MI355X, "gloo" in CPU tests.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+# --------------------------------------------------------------------------------------- planning
+def plan_assignment(costs, world):
+    """Greedy longest-processing-time assignment of snapshots to ranks, at most ceil(T/world) each.
+    costs[t]: relative cost of snapshot t (e.g. aggregated edges).  Returns list[world] of sorted index lists.
+    Cumulative dynamic graphs grow with t (reference graph.py:101-108), so round-robin would leave the last
+    rank ~40% over the mean at T=16, G=8."""
+    T = len(costs)
+    cap = math.ceil(T / world) if T else 0
+    load = [0.0] * world
+    owned = [[] for _ in range(world)]
+    for t in sorted(range(T), key=lambda i: (-float(costs[i]), i)):
+        r = min((r for r in range(world) if len(owned[r]) < cap), key=lambda r: (load[r], r))
+        owned[r].append(t)
+        load[r] += float(costs[t])
+    return [sorted(o) for o in owned]
+
+
+class ShardPlan(object):
+    def __init__(self, assignment, num_nodes):
+        self.assignment = [list(a) for a in assignment]
+        self.world = len(assignment)
+        self.T = sum(len(a) for a in assignment)
+        self.per = max((len(a) for a in assignment), default=0)       # slots per rank in the exchange buffer
+        self.n = int(num_nodes)
+        self.n_slice = (self.n + self.world - 1) // self.world
+        self.n_pad = self.n_slice * self.world
+        # position of snapshot t in the rank-major [world, per] exchange layout
+        self.slot_of = {}
+        for r, lst in enumerate(self.assignment):
+            for i, t in enumerate(lst):
+                self.slot_of[t] = r * self.per + i
+        assert sorted(self.slot_of) == list(range(self.T)), "assignment must cover 0..T-1 exactly once"
+
+    def owner(self, t):
+        return self.slot_of[t] // self.per
+
+    def node_range(self, rank):
+        lo = rank * self.n_slice
+        return lo, min(self.n, lo + self.n_slice)
+
+
+def shard_ctgcn(model, num_nodes, costs=None, assignment=None, group=None, exchange="all_to_all", gather_output=True,
+                replicate_head=False):
+    """Turn a CTGCN into its snapshot-parallel form on the current process group. Returns the ShardPlan."""
+    assert exchange in ("all_to_all", "all_gather")
+    group = group if group is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    if assignment is None:
+        costs = [1.0] * model.duration if costs is None else costs
+        assignment = plan_assignment(costs, world)
+    plan = ShardPlan(assignment, num_nodes)
+    assert plan.T == model.duration and plan.world == world
+    model.process_group, model.shard_plan = group, plan
+    model.shard_exchange, model.shard_gather_output, model.shard_replicate_head = exchange, gather_output, replicate_head
+    return plan
+
+
+def owned_parameters(model):
+    """Parameters this rank must optimise: its snapshots' mlp/CDN weights + the replicated temporal head."""
+    rank = dist.get_rank(model.process_group)
+    mine = model.shard_plan.assignment[rank]
+    for t in mine:
+        yield from model.mlp_list[t].parameters()
+        yield from model.duffision_list[t].parameters()
+    yield from model.rnn.parameters()
+    yield from model.norm.parameters()
+
+
+def allreduce_replicated_grads(model):
+    """Sum the grads of the replicated temporal rnn/norm weights (each rank saw only its node slice)."""
+    if model.shard_replicate_head:
+        return
+    for p in list(model.rnn.parameters()) + list(model.norm.parameters()):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        dist.all_reduce(p.grad, group=model.process_group)
+
+
+# ------------------------------------------------------------------------ collectives with autograd
+class _TimeToNodeAllToAll(torch.autograd.Function):
+    """[per, n_pad, d] (my snapshots, all nodes) -> [world, per, n_slice, d] (all snapshots, my nodes)."""
+
+    @staticmethod
+    def forward(ctx, local, group):
+        world = dist.get_world_size(group)
+        per, n_pad, d = local.shape
+        ctx.group, ctx.shape = group, (per, n_pad, d)
+        send = local.view(per, world, n_pad // world, d).transpose(0, 1).contiguous()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+        return recv
+
+    @staticmethod
+    def backward(ctx, grad):
+        per, n_pad, d = ctx.shape
+        grad = grad.contiguous()
+        back = torch.empty_like(grad)
+        dist.all_to_all_single(back, grad, group=ctx.group)
+        return back.transpose(0, 1).reshape(per, n_pad, d), None
+
+
+class _AllGather(torch.autograd.Function):
+    """x [..] -> [world, ..]; backward = reduce-scatter (sum of every rank's grad for my contribution)."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        x = x.contiguous()
+        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        grad = grad.contiguous()
+        out = torch.empty(grad.shape[1:], dtype=grad.dtype, device=grad.device)
+        if dist.get_backend(ctx.group) == "gloo":      # gloo has no reduce_scatter
+            dist.all_reduce(grad, group=ctx.group)
+            out.copy_(grad[dist.get_rank(ctx.group)])
+        else:
+            dist.reduce_scatter_tensor(out, grad, group=ctx.group)
+        return out, None
+
+
+# ------------------------------------------------------------------------------------ sharded forward
+def ctgcn_forward_sharded(model, x_list, adj_list):
+    """CTGCN.forward under a ShardPlan.  x_list / adj_list have length T; entries of snapshots this rank does
+    not own are ignored (may be None)."""
+    group, plan = model.process_group, model.shard_plan
+    rank = dist.get_rank(group)
+    mine = plan.assignment[rank]
+    assert len(x_list) == plan.T, "window length %d != plan %d" % (len(x_list), plan.T)
+
+    states, trans_local = [], {}
+    for t in mine:
+        h, tr = model.snapshot_branch(t, x_list[t], adj_list[t])
+        states.append(h)
+        trans_local[t] = tr
+    ref = states[0] if states else None
+    if ref is None:      # a rank may own nothing when T < world: it still takes part in the exchange
+        p = next(model.rnn.parameters())
+        ref = torch.zeros(plan.n, model.output_dim, dtype=p.dtype, device=p.device)
+    d = ref.shape[1]
+    pad_rows = plan.n_pad - plan.n
+    rows = [torch.nn.functional.pad(h, (0, 0, 0, pad_rows)) if pad_rows else h for h in states]
+    while len(rows) < plan.per:                      # uneven T/world: empty slot, never read back
+        rows.append(torch.zeros(plan.n_pad, d, dtype=ref.dtype, device=ref.device))
+    local = torch.stack(rows)                        # [per, n_pad, d]
+
+    order = [plan.slot_of[t] for t in range(plan.T)]
+    lo, hi = plan.node_range(rank)
+    if model.shard_exchange == "all_to_all":
+        got = _TimeToNodeAllToAll.apply(local, group)                       # [world, per, n_slice, d]
+        seq = got.reshape(plan.world * plan.per, plan.n_slice, d)[order]    # time order, my nodes
+        seq = seq[:, : hi - lo]
+    else:
+        got = _AllGather.apply(local, group)                                # [world, per, n_pad, d]
+        seq = got.reshape(plan.world * plan.per, plan.n_pad, d)[order]
+        seq = seq[:, : plan.n] if model.shard_replicate_head else seq[:, lo:hi]
+
+    out = model.temporal_head(seq.transpose(0, 1))                          # [T, nodes, d]
+    if not model.shard_replicate_head and model.shard_gather_output:
+        padded = torch.nn.functional.pad(out, (0, 0, 0, plan.n_slice - (hi - lo))) if hi - lo < plan.n_slice else out
+        full = _AllGather.apply(padded.transpose(0, 1).contiguous(), group)  # [world, n_slice, T, d]
+        out = full.reshape(plan.n_pad, plan.T, d)[: plan.n].transpose(0, 1)
+    if model.model_type == 'C':
+        return out
+    return out, [trans_local.get(t) for t in range(plan.T)]

@@ -1,0 +1,136 @@
+/*
+ * ctgcn_hip.h — C ABI of libctgcn_hip.so, the MI355X (gfx950) hot path of CTGCN.
+ *
+ * The reference (jhljx/CTGCN) is pure Python and has no FFI layer; its "operator API" for this
+ * path is four call sites.  Each entry point below names the reference call site it replaces
+ * (paths relative to the reference root).  A reference-side ctypes binding is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - every function returns 0 on success or a negative CTGCN_E_* code, never throws, never
+ *     allocates device memory (callers pass workspaces sized by ctgcn_workspace_bytes);
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); work is enqueued on it
+ *     and the call returns without synchronising, except ctgcn_kcore_i32 which must read its
+ *     termination counter back and therefore synchronises `stream` internally;
+ *   - ctgcn_last_error() returns a thread-local, NUL-terminated description of the last failure;
+ *   - CSR arrays: row_ptr int32[n_rows+1] (nnz < 2^31), col_idx int32[nnz], val float[nnz]; the per-entry
+ *     arrays may be NULL when nnz == 0;
+ *   - dense matrices are row-major fp32 with an explicit leading dimension (elements).
+ */
+#ifndef CTGCN_HIP_H
+#define CTGCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTGCN_ABI_VERSION 1
+
+enum {
+    CTGCN_OK = 0,
+    CTGCN_E_INVALID = -1,   /* bad argument (null pointer, negative size, K out of range ...) */
+    CTGCN_E_HIP = -2,       /* a HIP runtime call failed; see ctgcn_last_error()              */
+    CTGCN_E_WORKSPACE = -3, /* workspace too small                                            */
+    CTGCN_E_UNSUPPORTED = -4
+};
+
+/* flags of ctgcn_core_aggregate_f32 / ctgcn_core_aggregate_bwd_f32 */
+enum {
+    CTGCN_F_SELF_LOOP = 1,  /* slot 0 is (A + I): add X[row] once (helper.py:71-72)                     */
+    CTGCN_F_RELU = 2,       /* apply ReLU to every emitted slot (layers.py:48)                          */
+    CTGCN_F_NESTED = 4      /* edges tagged s belong to slots s..K-1 (nested k-cores).  Without it an   */
+                            /* edge belongs to slot s only (arbitrary, non-nested adjacency list).      */
+};
+
+enum { /* `op` of ctgcn_workspace_bytes */
+    CTGCN_OP_KCORE = 1
+};
+
+#define CTGCN_MAX_SLOTS 255
+
+int ctgcn_abi_version(void);
+const char *ctgcn_last_error(void);
+
+/* Name of the device the library would run on and its compute-unit count (diagnostics). */
+int ctgcn_device_info(char *name_host, size_t name_len, int *cu_count_host);
+
+/*
+ * Y = A·X  (accumulate == 0)   or   Y += A·X  (accumulate != 0).
+ * Replaces one torch.sparse.mm(adj, x), layers.py:43 / layers.py:45.
+ */
+int ctgcn_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *row_ptr, const int32_t *col_idx,
+                       const float *val, const float *X, int64_t ldx, float *Y, int64_t ldy,
+                       int accumulate, void *stream);
+
+/*
+ * The whole aggregation loop of CoreDiffusion.forward, layers.py:41-48, plus the
+ * stack/transpose of layers.py:58, in ONE pass over the edge list:
+ *     res_0 = A_0·X (+ X if SELF_LOOP);  res_j = res_{j-1} + A_j·X;  H[:, j, :] = relu?(res_j)
+ * The K matrices are given as one CSR whose entries carry a slot tag and are sorted by
+ * (row, slot, col):  NESTED: entry tagged s is present in A_s, A_{s+1}, ..., A_{K-1};
+ * otherwise it is present in A_s only.  H is [n_rows, K, d] contiguous (the [batch, core, feat]
+ * layout nn.GRU(batch_first=True) consumes at layers.py:59).   1 <= K <= CTGCN_MAX_SLOTS.
+ */
+int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
+                             const int32_t *col_idx, const float *val, const uint8_t *slot,
+                             const float *X, int64_t ldx, float *H, uint32_t flags, void *stream);
+
+/*
+ * Backward of ctgcn_core_aggregate_f32 w.r.t. X (what autograd derives for layers.py:41-48).
+ * Step 1 (ctgcn_core_aggregate_bwd_prep_f32), elementwise over [n, K, d]:
+ *     G_j = dH_j * [H_j > 0] (RELU) ; S_j = sum_{i>=j} G_i ; Z_j = NESTED ? sum_{i>=j} S_i : S_j
+ *     S0 = S_0  ([n, d], the self-loop term; may be NULL when SELF_LOOP is not set)
+ * Step 2 (ctgcn_core_aggregate_bwd_f32) on the CSR of the TRANSPOSED matrices (same arrays when
+ * the adjacency is symmetric, which every matrix the reference loader builds is):
+ *     dX[r] = S0[r] (SELF_LOOP) + sum_{e in row r} val[e] * Z[col[e], slot[e], :]
+ */
+int ctgcn_core_aggregate_bwd_prep_f32(int64_t n_rows, int32_t d, int32_t K, const float *dH,
+                                      const float *H, float *Z, float *S0, uint32_t flags,
+                                      void *stream);
+int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
+                                 const int32_t *col_idx, const float *val, const uint8_t *slot,
+                                 const float *Z, const float *S0, float *dX, int64_t lddx,
+                                 uint32_t flags, void *stream);
+
+/*
+ * Core number of every vertex of an undirected simple graph given as symmetric CSR structure
+ * (self-loop entries, if any, are ignored).  Replaces networkx.core_number at
+ * preprocessing/structure_generation.py:35.  Integer result, unique, bit-exact.
+ * workspace: ctgcn_workspace_bytes(CTGCN_OP_KCORE, n, nnz, 0, 0) bytes.
+ * max_core_host (optional) receives max(core).  Synchronises `stream`.
+ */
+int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, int32_t *core,
+                    void *workspace, size_t workspace_bytes, int32_t *max_core_host, void *stream);
+
+/*
+ * level[e] = min(core[row(e)], core[col(e)]) for every CSR entry: entry e belongs to the k-core
+ * subgraph A_k (structure_generation.py:48-53, networkx.k_core) iff level[e] >= k.
+ * Also accumulates, for L in [0, hist_len): count[L] = #entries with min(level, hist_len-1) == L
+ * and wsum[L] = sum of their weights (fp64) — what helper.py:74-75 needs to decide
+ * `delta.sum() == 0`.  count/wsum must be zeroed by the caller; either may be NULL.
+ */
+int ctgcn_edge_levels_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx,
+                          const float *val, const int32_t *core, int32_t *level,
+                          int64_t *count, double *wsum, int32_t hist_len, void *stream);
+
+/*
+ * Tag every entry with its slot (slot_of_level[min(level, table_len-1)], table of uint8 on the
+ * device) and stably re-order the entries of each row by slot, producing the (row, slot, col)
+ * order ctgcn_core_aggregate_f32 consumes.  Encodes helper.py:63-78 (file truncation, reversal,
+ * skipped matrices) once the caller has built the table.  Outputs must not alias inputs.
+ */
+int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32_t *col_idx,
+                       const float *val, const int32_t *level, const uint8_t *slot_of_level,
+                       int32_t table_len, int32_t *col_out, float *val_out, uint8_t *slot_out,
+                       void *stream);
+
+size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTGCN_HIP_H */

@@ -12,6 +12,25 @@ from . import ops
 from .core_adj import CoreAdj
 
 _RNN = {"GRU": nn.GRU, "LSTM": nn.LSTM}
+_RNN_MAX_ELEMS = 1 << 29     # MIOpen's RNN indexes its gate workspace with 32-bit ints: keep batch*seq*4*hidden below 2^31
+
+
+def rnn_over_rows(rnn, seq, reduce_sum):
+    """rnn(seq)[0] for seq [rows, steps, feat], evaluated in row chunks (rows are independent sequences, so this is
+    exact).  MIOpen rejects (miopenStatusBadParm) problems whose gate buffers exceed 2^31 elements — 1M nodes x 8
+    cores x 3*128 already does.  With reduce_sum the per-row sum over steps is taken chunk by chunk, so the
+    [rows, steps, hidden] output of the full problem is never materialised."""
+    rows, steps, _ = seq.shape
+    gates = 4 if isinstance(rnn, nn.LSTM) else 3
+    chunk = max(1, _RNN_MAX_ELEMS // max(1, steps * gates * rnn.hidden_size))
+    if rows <= chunk:
+        out = rnn(seq)[0]
+        return out.sum(dim=1) if reduce_sum else out
+    parts = []
+    for lo in range(0, rows, chunk):
+        out = rnn(seq[lo:lo + chunk])[0]
+        parts.append(out.sum(dim=1) if reduce_sum else out)
+    return torch.cat(parts, 0)
 _adj_cache = {}
 
 
@@ -48,8 +67,7 @@ class CoreDiffusion(nn.Module):
 
     def forward(self, x, adj_list):
         seq = self.aggregate(x, adj_list)            # [batch = N, seq = K, feat]
-        states, _ = self.rnn(seq)
-        return self.norm(states.sum(dim=1))
+        return self.norm(rnn_over_rows(self.rnn, seq, reduce_sum=True))
 
 
 class MLP(nn.Module):

@@ -133,9 +133,10 @@ class _AllGather(torch.autograd.Function):
         ctx.group = group
         world = dist.get_world_size(group)
         x = x.contiguous()
-        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        # concatenated-along-dim-0 output layout: the one every backend (RCCL and gloo) accepts
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x, group=group)
-        return out
+        return out.view((world,) + tuple(x.shape))
 
     @staticmethod
     def backward(ctx, grad):
@@ -145,7 +146,7 @@ class _AllGather(torch.autograd.Function):
             dist.all_reduce(grad, group=ctx.group)
             out.copy_(grad[dist.get_rank(ctx.group)])
         else:
-            dist.reduce_scatter_tensor(out, grad, group=ctx.group)
+            dist.reduce_scatter_tensor(out, grad.view((-1,) + tuple(grad.shape[2:])), group=ctx.group)
         return out, None
 
 

@@ -49,6 +49,43 @@ def _rnn(sd, prefix, rnn_type, seq):
     return mod(seq)[0]
 
 
+def _rnn_grad(sd, prefix, rnn_type, seq):
+    """Same recurrence written out with torch ops so that gradients flow to the tensors in `sd`
+    (PyTorch's documented GRU/LSTM cell equations, gate order r,z,n / i,f,g,o)."""
+    w_ih, w_hh = sd[prefix + "weight_ih_l0"], sd[prefix + "weight_hh_l0"]
+    b_ih, b_hh = sd.get(prefix + "bias_ih_l0"), sd.get(prefix + "bias_hh_l0")
+    hid = w_hh.shape[1]
+    h = seq.new_zeros(seq.shape[0], hid)
+    c = seq.new_zeros(seq.shape[0], hid)
+    outs = []
+    for t in range(seq.shape[1]):
+        gi = F.linear(seq[:, t], w_ih, b_ih)
+        gh = F.linear(h, w_hh, b_hh)
+        if rnn_type == "LSTM":
+            i, f, g, o = (gi + gh).chunk(4, 1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+        else:
+            ir, iz, inn = gi.chunk(3, 1)
+            hr, hz, hn = gh.chunk(3, 1)
+            r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+            nn_ = torch.tanh(inn + r * hn)
+            h = (1 - z) * nn_ + z * h
+        outs.append(h)
+    return torch.stack(outs, 1)
+
+
+def ctgcn_with_grad(sd, x_list, adj_list, rnn_type="GRU", model_type="C", activate="L"):
+    """ctgcn() with every recurrence unrolled in torch ops: differentiable w.r.t. the tensors of `sd`."""
+    global _rnn
+    saved = _rnn
+    _rnn = _rnn_grad
+    try:
+        return ctgcn(sd, x_list, adj_list, rnn_type, model_type, activate)
+    finally:
+        _rnn = saved
+
+
 def core_diffusion(sd, prefix, x, adj_list, rnn_type="GRU"):
     """layers.py:38-63."""
     hs = aggregate_loop(adj_list, x)

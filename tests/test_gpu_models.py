@@ -1,0 +1,196 @@
+"""Model-level parity on the GPU: the reference's own outputs (tests/golden/models_uci.npz, weighted_small.npz),
+preprocessing files, the native loader route and full-size properties."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import load_golden, csr_from, close_scaled, formula_tensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = dict(rtol=1e-4, atol=2e-5)          # after GRU + LayerNorm (MIOpen vs ATen-CPU accumulation order)
+
+
+def _write_uci(tmp_path):
+    snaps = load_golden("uci_snapshots.npz")
+    names = [str(x) for x in snaps["node_names"]]
+    os.makedirs(tmp_path / "1.format")
+    os.makedirs(tmp_path / "nodes_set")
+    (tmp_path / "nodes_set" / "nodes.csv").write_text("\n".join(names) + "\n")
+    for t, f in enumerate(snaps["files"]):
+        with open(tmp_path / "1.format" / str(f), "w") as fp:
+            fp.write("from_id\tto_id\tweight\n")
+            for s, d, w in zip(snaps["t%d_src" % t], snaps["t%d_dst" % t], snaps["t%d_w" % t]):
+                fp.write("%s\t%s\t%d\n" % (names[s], names[d], int(w)))
+    return names
+
+
+def test_structure_generator_writes_the_reference_files(tmp_path):
+    from ctgcn_amd.preprocessing import StructureInfoGenerator
+    names = _write_uci(tmp_path)
+    gen = StructureInfoGenerator(str(tmp_path), "1.format", "2.core", "nodes_set/nodes.csv")
+    assert gen.full_node_list == names
+    gen.get_kcore_graph_all_time(sep="\t", worker=4)
+    kc = load_golden("uci_kcore.npz")
+    assert sorted(os.listdir(tmp_path / "2.core")) == [str(s) for s in kc["snapshots"]]
+    for t, snap in enumerate(kc["snapshots"]):
+        files = sorted(os.listdir(tmp_path / "2.core" / str(snap)))
+        assert files == [str(f) for f in kc["t%d_files" % t]]
+        for f in files:
+            got = sp.load_npz(str(tmp_path / "2.core" / str(snap) / f))
+            want = csr_from(kc, "t%d_%s" % (t, f[:-4]), 1899)
+            assert sp.isspmatrix_csr(got) and got.shape == want.shape
+            got.sort_indices()
+            assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+            assert np.array_equal(got.data.astype(np.float64), want.data)
+
+
+def test_native_loader_route_matches_reference_loader(tmp_path):
+    import ctgcn_amd
+    names = _write_uci(tmp_path)
+    ca, kc = load_golden("uci_core_adj.npz"), load_golden("uci_kcore.npz")
+    dl = ctgcn_amd.DataLoader(names, 7, has_cuda=True)
+    for tag, start, dur, mc in (("mcm1_", 0, 7, -1), ("mc5_", 0, 7, 5), ("w4_", 4, 3, -1)):
+        got, cores = dl.get_core_adj_list_from_graphs(str(tmp_path / "1.format"), start, dur, max_core=mc, return_core_numbers=True)
+        assert [len(g) for g in got] == ca[tag + "K"].tolist()
+        for i, (adj, core) in enumerate(zip(got, cores)):
+            assert np.array_equal(core.cpu().numpy(), kc["core_t%d" % (start + i)])
+            for j, m in enumerate(adj.to_scipy_list()):
+                want = csr_from(ca, tag + "t%d_j%d" % (i, j), 1899, np.float32)
+                assert np.array_equal(m.indptr, want.indptr) and np.array_equal(m.indices, want.indices)
+                assert np.array_equal(m.data, want.data)
+
+
+def _window():
+    import ctgcn_amd
+    ca = load_golden("uci_core_adj.npz")
+    return [ctgcn_amd.CoreAdj.from_matrices([csr_from(ca, "w4_t%d_j%d" % (t, j), 1899, np.float32) for j in range(int(k))], device=DEV)
+            for t, k in enumerate(ca["w4_K"])]
+
+
+def _load(model, g, tag):
+    model.load_state_dict({k[len(tag + "sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "sd_")})
+    return model.to(DEV)
+
+
+def _check_grads(model, g, tag, rtol=2e-3):
+    for name, p in model.named_parameters():
+        want = g[tag + "grad_" + name]
+        got = np.zeros_like(want) if p.grad is None else p.grad.cpu().numpy()
+        scale = max(1e-6, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= rtol * scale, (name, np.abs(got - want).max(), scale)
+
+
+def test_ctgcn_and_cgcn_match_reference_outputs_and_grads():
+    import ctgcn_amd
+    g = load_golden("models_uci.npz")
+    adj = _window()
+    T, n = 3, 1899
+    idx = torch.arange(n).repeat(2, 1)
+    eye = [torch.sparse_coo_tensor(idx, torch.ones(n), (n, n)).to(DEV) for _ in range(T)]
+    xd = [torch.from_numpy(a).to(DEV) for a in formula_tensor((T, n, 24), 0.11, 0.3)]
+
+    def gsel(dim):
+        return torch.from_numpy(formula_tensor((T, n, dim), 0.37, 1.1)).to(DEV)
+
+    m = _load(ctgcn_amd.CTGCN(n, 16, 8, 1, 2, T), g, "ctgcn_c_")
+    out = m(eye, adj)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["ctgcn_c_out"], **TOL)
+    (out * gsel(8)).sum().backward()
+    _check_grads(m, g, "ctgcn_c_")
+
+    m = _load(ctgcn_amd.CTGCN(24, 16, 8, 3, 1, T, model_type="S", trans_activate_type="N"), g, "ctgcn_s_")
+    out, trans = m(xd, adj)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["ctgcn_s_out"], **TOL)
+    np.testing.assert_allclose(torch.stack(trans).detach().cpu().numpy(), g["ctgcn_s_trans"], **TOL)
+    (out * gsel(8)).sum().backward()
+    _check_grads(m, g, "ctgcn_s_")
+
+    m = _load(ctgcn_amd.CTGCN(24, 16, 8, 1, 2, T, rnn_type="LSTM"), g, "ctgcn_c_lstm_")
+    out = m(xd, adj)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["ctgcn_c_lstm_out"], **TOL)
+    (out * gsel(8)).sum().backward()
+    _check_grads(m, g, "ctgcn_c_lstm_")
+
+    m = _load(ctgcn_amd.CGCN(24, 16, 8, 1, 2), g, "cgcn_c_")
+    out = torch.stack(m(xd, adj))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["cgcn_c_out"], **TOL)
+    (out * gsel(8)).sum().backward()
+    _check_grads(m, g, "cgcn_c_")
+
+    m = _load(ctgcn_amd.CGCN(24, 16, 8, 3, 1, model_type="S", trans_activate_type="N"), g, "cgcn_s_")
+    emb, st = m(xd, adj)
+    np.testing.assert_allclose(torch.stack(emb).detach().cpu().numpy(), g["cgcn_s_out"], **TOL)
+    np.testing.assert_allclose(torch.stack(st).detach().cpu().numpy(), g["cgcn_s_trans"], **TOL)
+
+    m = _load(ctgcn_amd.CGCN(24, 16, 8, 2, 3, trans_activate_type="N"), g, "cgcn_c_single_")
+    out = m(xd[0], adj[0])
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["cgcn_c_single_out"], **TOL)
+
+
+def test_models_accept_the_reference_loaders_tensor_lists():
+    """drop-in: adjacency given as python lists of (uncoalesced) torch sparse COO tensors, as helper.py:79 builds them."""
+    import ctgcn_amd
+    from oracle import torch_path as TP
+    g = load_golden("models_uci.npz")
+    ca = load_golden("uci_core_adj.npz")
+    n, T = 1899, 3
+    lists = [[TP.coo_like_reference(csr_from(ca, "w4_t%d_j%d" % (t, j), n, np.float32)).to(DEV) for j in range(int(k))]
+             for t, k in enumerate(ca["w4_K"])]
+    xd = [torch.from_numpy(a).to(DEV) for a in formula_tensor((T, n, 24), 0.11, 0.3)]
+    m = _load(ctgcn_amd.CGCN(24, 16, 8, 1, 2), g, "cgcn_c_")
+    out = torch.stack(m(xd, lists))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["cgcn_c_out"], **TOL)
+
+
+def test_core_diffusion_layer_golden():
+    import ctgcn_amd
+    g = load_golden("weighted_small.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        n = int(g[p + "n"])
+        adj = ctgcn_amd.CoreAdj.from_matrices([csr_from(g, p + "adj_t1_j%d" % j, n, np.float32) for j in range(int(g[p + "adj_K"][1]))], device=DEV)
+        x = torch.from_numpy(g[p + "cd_x"]).to(DEV).requires_grad_(True)
+        layer = ctgcn_amd.CoreDiffusion(x.shape[1], g[p + "cd_out"].shape[1], rnn_type=str(g[p + "cd_rnn"]))
+        layer.load_state_dict({k[len(p + "cd_sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(p + "cd_sd_")})
+        layer.to(DEV)
+        out = layer(x, adj)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g[p + "cd_out"], **TOL)
+        (out * torch.from_numpy(g[p + "cd_gout"]).to(DEV)).sum().backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[p + "cd_dx"], rtol=1e-3, atol=5e-5)
+
+
+# ---------------------------------------------------------------- full-size, size-independent properties
+def test_full_size_properties_config5_snapshot():
+    """1M nodes, avg-deg 16 (last snapshot of BASELINE config 5): linearity, K=1 == plain SpMM, nested == per-matrix
+    representation, peel idempotence (every vertex of the k-core keeps >= k neighbours inside it)."""
+    from ctgcn_amd import ops, CoreAdj
+    from ctgcn_amd.synth import dynamic_graph_device
+    n = 1_000_000
+    rp, col, val = dynamic_graph_device(n, 16, 16, DEV, which=[15])[15]
+    adj, core, files = CoreAdj.from_graph(rp, col, val, max_core=8)
+    assert adj.K == 8 and adj.nnz == 16_000_000
+    # k-core property: within {v: core >= k}, every member has at least k neighbours in the set, and
+    # core numbers cannot be raised: a vertex of core c has fewer than c+1 neighbours of core >= c+1 ... checked via degrees
+    rows = torch.repeat_interleave(torch.arange(n, device=DEV), (rp[1:] - rp[:-1]).long())
+    cc = core.long()
+    inside = torch.zeros(n, dtype=torch.long, device=DEV).index_add_(0, rows, (cc[col.long()] >= cc[rows]).long())
+    assert bool((inside >= cc).all())
+    above = torch.zeros(n, dtype=torch.long, device=DEV).index_add_(0, rows, (cc[col.long()] > cc[rows]).long())
+    assert bool((above <= cc).all())
+    # linearity without ReLU
+    x1, x2 = torch.randn(n, 128, device=DEV), torch.randn(n, 128, device=DEV)
+    h12 = ops.core_aggregate(x1 + 2 * x2, adj, relu=False)
+    hsum = ops.core_aggregate(x1, adj, relu=False)
+    hsum.add_(ops.core_aggregate(x2, adj, relu=False), alpha=2.0)
+    err = (h12 - hsum).abs().max().item()
+    assert err <= 2e-6 * h12.abs().max().item() + 1e-4, err
+    del h12, hsum
+    # slot K-1 (all entries) minus slot K-2 ... last slot difference equals A_1 x: compare against plain SpMM
+    h = ops.core_aggregate(x1, adj, relu=False)
+    y = ops.spmm_csr(adj.row_ptr, adj.col, adj.val, x1)
+    d_last = h[:, -1] - h[:, -2]
+    assert (d_last - y).abs().max().item() <= 1e-5 * y.abs().max().item() + 2e-4

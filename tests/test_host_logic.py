@@ -1,0 +1,211 @@
+"""CPU-only checks of the product's host logic (no kernel launches): ABI surface, loader semantics,
+checkpoint schema, loud failure without a GPU, and that the product never touches the oracle."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import ROOT, load_golden, csr_from
+
+import ctgcn_amd
+from ctgcn_amd import CoreAdj, _lib
+from ctgcn_amd.core_adj import slot_table
+
+
+# ------------------------------------------------------------------------------------ C ABI surface
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ctgcn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctgcn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import ctypes
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    assert sorted(_lib.SIGNATURES) == declared, "binding and header disagree"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _lib.load().ctgcn_abi_version() == _lib.ABI_VERSION
+    assert _lib.load().ctgcn_workspace_bytes(_lib.OP_KCORE, 1000, 0, 0, 0) >= 1000 * 12
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "ctgcn_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle|oracle/|libctgcn_oracle", src, flags=re.M):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
+
+
+def test_cpu_tensors_fail_loudly():
+    model = ctgcn_amd.CGCN(6, 8, 4, 1, 1)
+    adj = CoreAdj.from_matrices([sp.eye(5, format="csr") + sp.csr_matrix(np.ones((5, 5)) - np.eye(5))])
+    with pytest.raises(_lib.CtgcnHipError, match="no CPU fallback"):
+        model(torch.randn(5, 6), adj)
+
+
+# --------------------------------------------------------------------------------- CoreAdj, host side
+def _golden_lists(tag):
+    ca = load_golden("uci_core_adj.npz")
+    n = 1899
+    return [[csr_from(ca, tag + "t%d_j%d" % (t, j), n, np.float32) for j in range(int(k))] for t, k in enumerate(ca[tag + "K"])]
+
+
+def _same(a, b):
+    a, b = sp.csr_matrix(a), sp.csr_matrix(b)
+    a.sort_indices(); b.sort_indices()
+    assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+    assert np.array_equal(a.data.astype(np.float32), b.data.astype(np.float32))
+
+
+def test_core_adj_round_trips_reference_loader_output():
+    for mats in _golden_lists("mcm1_"):
+        adj = CoreAdj.from_matrices(mats)
+        assert adj.nested and adj.self_loop and adj.symmetric and adj.K == len(mats)
+        assert adj.nnz_per_slot == [m.nnz for m in mats]
+        assert adj.nnz == mats[-1].nnz - (adj.n if len(mats) == 1 else 0)    # one pass over the largest matrix
+        for got, want in zip(adj.to_scipy_list(), mats):
+            _same(got, want)
+        # rows sorted by (slot, col)
+        rp, sl, col = adj.row_ptr.numpy(), adj.slot.numpy().astype(np.int64), adj.col.numpy().astype(np.int64)
+        rows = np.repeat(np.arange(adj.n), np.diff(rp))
+        key = (rows * 256 + sl) * adj.n + col
+        assert np.all(np.diff(key) > 0)
+
+
+def test_core_adj_general_lists():
+    rng = np.random.default_rng(0)
+    n = 40
+    mats = [sp.random(n, n, 0.1, random_state=i, format="csr", dtype=np.float32) for i in range(3)]
+    adj = CoreAdj.from_matrices(mats)
+    assert not adj.nested and not adj.self_loop
+    for got, want in zip(adj.to_scipy_list(), mats):
+        _same(got, want)
+    # nested structure but a differing weight -> must NOT be fused
+    a = mats[0]
+    b = (a + mats[1]).tocsr()
+    b2 = b.copy(); b2.data = b2.data * 1.5
+    adj = CoreAdj.from_matrices([a, b2])
+    assert not adj.nested
+    for got, want in zip(adj.to_scipy_list(), [a, b2]):
+        _same(got, want)
+    with pytest.raises(ValueError):
+        CoreAdj.from_matrices([])
+    # torch sparse COO input, as the reference loader hands over (uncoalesced)
+    coo = mats[0].tocoo()
+    t = torch.sparse_coo_tensor(np.vstack((coo.row, coo.col)), coo.data, coo.shape)
+    _same(CoreAdj.from_matrices([t]).to_scipy_list()[0], mats[0])
+
+
+def test_data_loader_reads_reference_npz_layout(tmp_path):
+    """write the reference's own per-k files (golden) to disk, read them with our DataLoader."""
+    kc, ca = load_golden("uci_kcore.npz"), load_golden("uci_core_adj.npz")
+    n = 1899
+    base = tmp_path / "2.core"
+    for t, snap in enumerate(kc["snapshots"]):
+        os.makedirs(base / str(snap))
+        for f in kc["t%d_files" % t]:
+            sp.save_npz(str(base / str(snap) / str(f)), csr_from(kc, "t%d_%s" % (t, str(f)[:-4]), n).astype(np.int64))
+    names = [str(x) for x in load_golden("uci_snapshots.npz")["node_names"]]
+    dl = ctgcn_amd.DataLoader(names, 7)
+    for tag, start, dur, mc in (("mcm1_", 0, 7, -1), ("mc5_", 0, 7, 5), ("w4_", 4, 3, -1)):
+        got = dl.get_core_adj_list(str(base), start, dur, max_core=mc)
+        assert [len(g) for g in got] == ca[tag + "K"].tolist()
+        for t, adj in enumerate(got):
+            for j, m in enumerate(adj.to_scipy_list()):
+                _same(m, csr_from(ca, tag + "t%d_j%d" % (t, j), n, np.float32))
+    with pytest.raises(AssertionError):
+        dl.get_core_adj_list(str(base), 7, 1)
+
+
+def test_slot_table_matches_loader_rules():
+    """the level->slot table of the device route reproduces the file route on every UCI snapshot."""
+    kc = load_golden("uci_kcore.npz")
+    ca = load_golden("uci_core_adj.npz")
+    n = 1899
+    sticky = {"mcm1_": -1, "mc5_": 5}
+    for tag, mc in sticky.items():
+        cur = mc
+        for t in range(7):
+            core = kc["core_t%d" % t]
+            a1 = csr_from(kc, "t%d_%s" % (t, str(kc["t%d_files" % t][0])[:-4]), n).tocoo()
+            level = np.minimum(core[a1.row], core[a1.col])
+            files = int(core.max())
+            count = np.bincount(level, minlength=files + 1)
+            wsum = np.bincount(level, weights=a1.data, minlength=files + 1)
+            table, K, levels, nnz = slot_table(count, wsum, files, cur, n)
+            if cur == -1:
+                cur = files
+            assert K == int(ca[tag + "K"][t])
+            want = [csr_from(ca, tag + "t%d_j%d" % (t, j), n, np.float32) for j in range(K)]
+            assert nnz == [m.nnz for m in want]
+            ref = CoreAdj.from_matrices(want)
+            slot = table[level]
+            order = np.lexsort((a1.col, slot, a1.row))
+            assert np.array_equal(ref.col.numpy(), a1.col[order]) and np.array_equal(ref.slot.numpy(), slot[order])
+    with pytest.raises(NotImplementedError):
+        slot_table([0, 2, 2], [0.0, 0.0, 2.0], 2, -1, 4)      # level-1 entries cancel to zero weight
+
+
+def test_symmetric_csr_last_duplicate_wins():
+    from ctgcn_amd.utils import symmetric_csr_from_rows
+    g = load_golden("weighted_small.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        n = int(g[p + "n"])
+        for s in range(2):
+            got = symmetric_csr_from_rows(g[p + "s%d_src" % s], g[p + "s%d_dst" % s], g[p + "s%d_w" % s], n)
+            _same(got, csr_from(g, p + "s%d_dateadj" % s, n))
+    m = symmetric_csr_from_rows([0, 1, 2, 2], [1, 0, 2, 0], [1.0, 5.0, 9.0, 2.0], 3)
+    assert m[0, 1] == 5.0 and m[1, 0] == 5.0 and m[2, 2] == 0 and m[0, 2] == 2.0
+
+
+# ------------------------------------------------------------------------------- checkpoint schema
+@pytest.mark.parametrize("tag,ctor", [
+    ("ctgcn_c_", lambda: ctgcn_amd.CTGCN(1899, 16, 8, 1, 2, 3, rnn_type="GRU", model_type="C", trans_activate_type="L")),
+    ("ctgcn_s_", lambda: ctgcn_amd.CTGCN(24, 16, 8, 3, 1, 3, rnn_type="GRU", model_type="S", trans_activate_type="N")),
+    ("ctgcn_c_lstm_", lambda: ctgcn_amd.CTGCN(24, 16, 8, 1, 2, 3, rnn_type="LSTM", model_type="C", trans_activate_type="L")),
+    ("cgcn_c_", lambda: ctgcn_amd.CGCN(24, 16, 8, 1, 2, rnn_type="GRU", model_type="C", trans_activate_type="L")),
+    ("cgcn_s_", lambda: ctgcn_amd.CGCN(24, 16, 8, 3, 1, rnn_type="GRU", model_type="S", trans_activate_type="N")),
+    ("cgcn_c_single_", lambda: ctgcn_amd.CGCN(24, 16, 8, 2, 3, rnn_type="GRU", model_type="C", trans_activate_type="N")),
+])
+def test_state_dict_schema_matches_reference_checkpoints(tag, ctor):
+    g = load_golden("models_uci.npz")
+    ref = {k[len(tag + "sd_"):]: g[k].shape for k in g.files if k.startswith(tag + "sd_")}
+    model = ctor()
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == ref
+    model.load_state_dict({k: torch.from_numpy(g[tag + "sd_" + k]) for k in ref}, strict=True)
+    assert model.method_name == {"ctgcn_c_": "CTGCN-C", "ctgcn_s_": "CTGCN-S", "ctgcn_c_lstm_": "CTGCN-C", "cgcn_c_": "CGCN-C",
+                                 "cgcn_s_": "CGCN-S", "cgcn_c_single_": "CGCN-C"}[tag]
+
+
+def test_constructor_error_conventions():
+    with pytest.raises(ValueError, match="number of layers should be positive!"):
+        ctgcn_amd.CDN(4, 4, 4, 0)
+    with pytest.raises(AssertionError):
+        ctgcn_amd.CoreDiffusion(4, 4, rnn_type="RNN")
+    with pytest.raises(AssertionError):
+        ctgcn_amd.CTGCN(4, 4, 4, 1, 1, 2, model_type="X")
+    with pytest.raises(AssertionError):
+        ctgcn_amd.MLP(4, 4, 4, 0)
+
+
+def test_synthetic_generator_is_seeded_and_cumulative():
+    from ctgcn_amd.synth import dynamic_graph, prefix_sizes
+    a = dynamic_graph(3000, 8, 4, seed=3)
+    b = dynamic_graph(3000, 8, 4, seed=3)
+    assert [x.nnz for x in a] == [2 * s for s in prefix_sizes(12000, 4)]
+    for x, y in zip(a, b):
+        assert (x != y).nnz == 0
+    for small, big in zip(a[:-1], a[1:]):          # snapshot i is a prefix of snapshot i+1 (graph.py:101-108)
+        assert (small.multiply(big) != small).nnz == 0
+    assert (a[-1] != a[-1].T).nnz == 0 and a[-1].diagonal().sum() == 0

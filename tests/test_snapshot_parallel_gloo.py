@@ -1,0 +1,41 @@
+"""N>1 path on CPU: world_size 2, gloo.  Covers plan_assignment, both exchange modes, uneven T/world,
+autograd through the collectives and the replicated-head grad all-reduce."""
+import socket
+
+import pytest
+import torch.multiprocessing as mp
+
+from ctgcn_amd import snapshot_parallel as spp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_plan_assignment_balances_cumulative_snapshots():
+    costs = [i + 1 for i in range(16)]
+    plan = spp.plan_assignment(costs, 8)
+    loads = [sum(costs[t] for t in r) for r in plan]
+    assert sorted(sum(plan, [])) == list(range(16)) and all(len(r) == 2 for r in plan)
+    assert max(loads) == min(loads) == 17            # pairs (t, 15-t); round-robin would give 10..24
+    assert spp.plan_assignment([5, 1, 1], 2) == [[0], [1, 2]]
+    assert spp.plan_assignment([1.0] * 3, 4) == [[0], [1], [2], []]
+    p = spp.ShardPlan([[0, 3], [1, 2]], 10)
+    assert (p.per, p.n_slice, p.n_pad) == (2, 5, 10) and p.owner(3) == 0 and p.node_range(1) == (5, 10)
+
+
+@pytest.mark.parametrize("exchange,T,n", [("all_to_all", 5, 301), ("all_gather", 4, 300)])
+def test_sharded_ctgcn_matches_unsharded(exchange, T, n):
+    from _dist_worker import run
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(run, args=(2, _free_port(), T, n, exchange, results), nprocs=2, join=True)
+    assert len(results) == 2
+    for rank in range(2):
+        err_fwd, err_bwd, err_full, assignment = results[rank]
+        assert err_fwd < 1e-5 and err_full < 1e-5, (rank, err_fwd, err_full)
+        assert err_bwd < 1e-4, (rank, err_bwd)

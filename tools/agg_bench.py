@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the aggregation kernels on snapshots of BASELINE config 5 (used for kernel A/B work and as the
+command profiled with rocprofv3 --pmc).  Prints per-snapshot kernel time and algorithmic GB/s.
+  python tools/agg_bench.py [--snapshots 15,7,0] [--iters 10] [--d 128] [--bwd] [--nodes 1000000]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ctgcn_amd import CoreAdj, ops  # noqa: E402
+from ctgcn_amd.synth import dynamic_graph_device  # noqa: E402
+
+
+def alg_bytes(n, nnz, K, d):
+    return nnz * (4 * d + 9) + n * K * 4 * d + 4 * (n + 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--snapshots", default="15")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--d", type=int, default=128)
+    ap.add_argument("--nodes", type=int, default=1_000_000)
+    ap.add_argument("--max-core", type=int, default=8)
+    ap.add_argument("--bwd", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    which = [int(s) for s in a.snapshots.split(",")]
+    graphs = dynamic_graph_device(a.nodes, 16, 16, dev, which=which)
+    for t in which:
+        rp, col, val = graphs[t]
+        adj, core, files = CoreAdj.from_graph(rp, col, val, max_core=a.max_core)
+        x = torch.randn(a.nodes, a.d, device=dev)
+        for _ in range(2):
+            h = ops.core_aggregate(x, adj)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(a.iters):
+            h = ops.core_aggregate(x, adj)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / a.iters
+        b = alg_bytes(a.nodes, adj.nnz, adj.K, a.d)
+        print("t=%2d K=%d nnz=%9d maxcore=%3d  fwd %.3f ms  %.0f GB/s (alg)  %.2f Gedges/s" % (
+            t, adj.K, adj.nnz, files, ms, b / ms / 1e6, adj.aggregated_edges / ms / 1e6), flush=True)
+        if a.bwd:
+            dh = torch.randn_like(h)
+            for _ in range(2):
+                ops._aggregate_bwd(adj, h, dh, True)
+            torch.cuda.synchronize()
+            s.record()
+            for _ in range(a.iters):
+                ops._aggregate_bwd(adj, h, dh, True)
+            e.record()
+            torch.cuda.synchronize()
+            print("      bwd (prep + gather) %.3f ms" % (s.elapsed_time(e) / a.iters), flush=True)
+        del h, x, adj
+
+
+if __name__ == "__main__":
+    main()

@@ -501,6 +501,165 @@ __global__ __launch_bounds__(256) void slot_reorder_kernel(int64_t n, int K, con
     }
 }
 
+// ================================================================================================
+// GRU over short sequences with many independent rows (core axis K <= ~22, time axis T <= ~100; rows = nodes).
+// Reference: nn.GRU(batch_first=True) + .sum(dim=1) + LayerNorm at layers.py:59-62, nn.GRU + LayerNorm at
+// models.py:249-250.  The input projection GI = x·W_ihᵀ + b is a plain library GEMM done by the caller; this
+// kernel owns the RECURRENT part, which MIOpen runs as thousands of small tensor ops:
+//     gh = h_{t-1}·W_hhᵀ ; r = σ(GI_r + gh_r) ; z = σ(GI_z + gh_z) ; n = tanh(GI_n + r·(gh_n + b_hn))
+//     h_t = n + z·(h_{t-1} − n)
+// hidden = 128 fixed.  Exact fp32: v_mfma_f32_16x16x4_f32 (an fmaf chain, one rounding per product).
+// Block = 8 waves; wave w owns hidden units [16w,16w+16) of all three gates and keeps its 128x48 slice of W_hhᵀ
+// in 96 VGPRs as ready-made MFMA B operands for the whole (persistent) kernel.  h_{t-1} of the block's 32 rows
+// lives in LDS (double buffered); each lane reads 32 consecutive k of its row with ds_read_b128 — the reduction
+// index is mapped k = 32·(lane>>4) + step so that those are exactly its A operands.  Step 0 (h = 0) issues no MFMA.
+// ================================================================================================
+typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int GRU_H = 128;
+constexpr int GRU_BM = 32;           // rows per block iteration = 2 MFMA row tiles
+constexpr int GRU_RT = GRU_BM / 16;
+constexpr int GRU_PITCH = 132;       // floats; 528 B keeps rows 16-B aligned
+
+struct GruArgs {
+    int64_t rows;
+    int32_t steps;
+    const float *gi;        // [rows, steps, 3*128]  gate order r,z,n; includes b_ih (+ b_hh for r,z)
+    const float *whh;       // [3*128, 128]
+    const float *bhn;       // [128] or null
+    const float *gamma;     // LayerNorm weight / bias [128] or null (no LayerNorm)
+    const float *beta;
+    float eps;
+    int32_t reduce_sum;     // 1: out[rows,128] = LN(sum_t h_t)   0: out[rows,steps,128] = LN(h_t)
+    float *out;
+};
+
+__device__ __forceinline__ float gru_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+
+__device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src, float *__restrict__ dst, int lane,
+                                                  const float *gamma, const float *beta, float eps)
+{
+    float2 v = *(const float2 *)(src + lane * 2);
+    if (gamma) {
+        float s = v.x + v.y;
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / GRU_H);
+        const float dx = v.x - mean, dy = v.y - mean;
+        float q = dx * dx + dy * dy;
+        for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * (1.0f / GRU_H) + eps);
+        const float2 g = *(const float2 *)(gamma + lane * 2);
+        const float2 b = beta ? *(const float2 *)(beta + lane * 2) : float2{0.f, 0.f};
+        v.x = dx * rstd * g.x + b.x;
+        v.y = dy * rstd * g.y + b.y;
+    }
+    *(float2 *)(dst + lane * 2) = v;
+}
+
+__global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
+{
+    __shared__ float hbuf[2][GRU_BM][GRU_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int hid = wave * 16 + col;
+    const int steps = a.steps;
+
+    // B operands: W[g][kk] = W_hh[g*128 + hid][32*grp + kk]
+    float W[3][32];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const f4v *src = (const f4v *)(a.whh + (int64_t)(g * GRU_H + hid) * GRU_H + 32 * grp);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f4v v = src[q];
+            W[g][4 * q + 0] = v.x; W[g][4 * q + 1] = v.y; W[g][4 * q + 2] = v.z; W[g][4 * q + 3] = v.w;
+        }
+    }
+    const float b_hn = a.bhn ? a.bhn[hid] : 0.f;
+    const int64_t ntiles = (a.rows + GRU_BM - 1) / GRU_BM;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * GRU_BM;
+        float hreg[GRU_RT][4], hsum[GRU_RT][4];
+#pragma unroll
+        for (int rt = 0; rt < GRU_RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { hreg[rt][i] = 0.f; hsum[rt][i] = 0.f; }
+
+        for (int t = 0; t < steps; ++t) {
+            // this lane's C-layout positions: rows rt*16 + grp*4 + i, hidden `hid`
+            float gi[GRU_RT][3][4];
+#pragma unroll
+            for (int rt = 0; rt < GRU_RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int64_t r = row0 + rt * 16 + grp * 4 + i;
+                    r = r < a.rows ? r : a.rows - 1;                 // clamp: loads stay unconditional
+                    const float *p = a.gi + (r * steps + t) * (3 * GRU_H) + hid;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) gi[rt][g][i] = p[g * GRU_H];
+                }
+            f4v acc[GRU_RT][3];
+#pragma unroll
+            for (int rt = 0; rt < GRU_RT; ++rt)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[rt][g] = f4v{0.f, 0.f, 0.f, 0.f};
+            if (t > 0) {
+                const float(*hprev)[GRU_PITCH] = hbuf[(t - 1) & 1];
+#pragma unroll
+                for (int rt = 0; rt < GRU_RT; ++rt) {
+                    float av[32];
+                    const f4v *src = (const f4v *)(&hprev[rt * 16 + col][32 * grp]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f4v v = src[q];
+                        av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 32; ++kk)
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                            acc[rt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], W[g][kk], acc[rt][g], 0, 0, 0);
+                }
+            }
+            float(*hcur)[GRU_PITCH] = hbuf[t & 1];
+#pragma unroll
+            for (int rt = 0; rt < GRU_RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float r = gru_sigmoid(gi[rt][0][i] + acc[rt][0][i]);
+                    const float z = gru_sigmoid(gi[rt][1][i] + acc[rt][1][i]);
+                    const float n = gru_tanh(gi[rt][2][i] + r * (acc[rt][2][i] + b_hn));
+                    const float h = n + z * (hreg[rt][i] - n);
+                    hreg[rt][i] = h;
+                    hsum[rt][i] += h;
+                    hcur[rt * 16 + grp * 4 + i][hid] = h;
+                }
+            __syncthreads();
+            if (!a.reduce_sum) {
+                for (int r = wave; r < GRU_BM; r += 8) {
+                    const int64_t row = row0 + r;
+                    if (row < a.rows)
+                        gru_layernorm_row(hcur[r], a.out + (row * steps + t) * GRU_H, lane, a.gamma, a.beta, a.eps);
+                }
+            }
+        }
+        if (a.reduce_sum) {
+            float(*sbuf)[GRU_PITCH] = hbuf[steps & 1];        // not the buffer of the last step (nobody reads it, but keep it simple)
+#pragma unroll
+            for (int rt = 0; rt < GRU_RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sbuf[rt * 16 + grp * 4 + i][hid] = hsum[rt][i];
+            __syncthreads();
+            for (int r = wave; r < GRU_BM; r += 8) {
+                const int64_t row = row0 + r;
+                if (row < a.rows) gru_layernorm_row(sbuf[r], a.out + row * GRU_H, lane, a.gamma, a.beta, a.eps);
+            }
+        }
+        __syncthreads();       // LDS is reused by the next tile
+    }
+}
+
 __global__ void kcore_copy_kernel(int n, const int32_t *__restrict__ deg, int32_t *__restrict__ core)
 {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -687,6 +846,29 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
     if (blocks > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "slot_reorder: grid too large");
     hipLaunchKernelGGL(slot_reorder_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, (int)K, row_ptr, col_idx, val,
                        level, slot_of_level, (int)table_len, col_out, val_out, slot_out);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
+                      const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
+                      int reduce_sum, float *out, void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq: hidden=%d, only %d is built", hidden, GRU_H);
+    if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq: bad sizes rows=%lld steps=%d", (long long)rows, steps);
+    if (rows == 0) return CTGCN_OK;
+    if (!gi || !w_hh || !out) return fail(CTGCN_E_INVALID, "gru_seq: null pointer");
+    if (!aligned16(w_hh) || (reinterpret_cast<uintptr_t>(out) & 7u) || (ln_weight && (reinterpret_cast<uintptr_t>(ln_weight) & 7u)))
+        return fail(CTGCN_E_INVALID, "gru_seq: w_hh must be 16-byte aligned, out / ln_weight 8-byte aligned");
+    GruArgs a{};
+    a.rows = rows; a.steps = steps; a.gi = gi; a.whh = w_hh; a.bhn = b_hn; a.gamma = ln_weight; a.beta = ln_bias;
+    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out;
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
+    const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 8-wave block per CU
+    hipLaunchKernelGGL(gru_seq_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -15,6 +15,14 @@ _RNN = {"GRU": nn.GRU, "LSTM": nn.LSTM}
 _RNN_MAX_ELEMS = 1 << 29     # MIOpen's RNN indexes its gate workspace with 32-bit ints: keep batch*seq*4*hidden below 2^31
 
 
+def rnn_reduce_norm(rnn, norm, seq, reduce_sum):
+    """norm(rnn(seq).sum(1)) or norm(rnn(seq)).  Inference with the standard GRU(hidden=128) runs the fused HIP
+    recurrent kernel; everything else (training, LSTM, other widths) goes through the PyTorch-ROCm modules."""
+    if ops.gru_fused_ok(rnn, seq):
+        return ops.gru_sequence(rnn, seq, norm, reduce_sum)
+    return norm(rnn_over_rows(rnn, seq, reduce_sum))
+
+
 def rnn_over_rows(rnn, seq, reduce_sum):
     """rnn(seq)[0] for seq [rows, steps, feat], evaluated in row chunks (rows are independent sequences, so this is
     exact).  MIOpen rejects (miopenStatusBadParm) problems whose gate buffers exceed 2^31 elements — 1M nodes x 8
@@ -48,6 +56,26 @@ def as_core_adj(adj_list, device):
     return hit
 
 
+_identity_cache = {}
+
+
+def _is_identity(sp_tensor):
+    """True iff the sparse COO tensor is exactly the N x N identity (what get_feature_list builds for one-hot
+    node features).  Checked once per tensor (one small reduction + host read), then cached by identity."""
+    key = (id(sp_tensor), sp_tensor._values().data_ptr())
+    hit = _identity_cache.get(key)
+    if hit is None:
+        n, m = sp_tensor.shape
+        idx, val = sp_tensor._indices(), sp_tensor._values()
+        hit = bool(n == m and val.numel() == n and idx.shape[0] == 2
+                   and bool(((idx[0] == idx[1]) & (val == 1)).all())
+                   and bool((idx[0].sort().values == torch.arange(n, device=idx.device)).all()))
+        if len(_identity_cache) > 1024:
+            _identity_cache.clear()
+        _identity_cache[key] = hit
+    return hit
+
+
 class CoreDiffusion(nn.Module):
     """K-core diffusion layer: H_j = relu(sum_{i<=j} A_i x), RNN over j, sum over j, LayerNorm."""
 
@@ -67,7 +95,7 @@ class CoreDiffusion(nn.Module):
 
     def forward(self, x, adj_list):
         seq = self.aggregate(x, adj_list)            # [batch = N, seq = K, feat]
-        return self.norm(rnn_over_rows(self.rnn, seq, reduce_sum=True))
+        return rnn_reduce_norm(self.rnn, self.norm, seq, reduce_sum=True)
 
 
 class MLP(nn.Module):
@@ -88,7 +116,9 @@ class MLP(nn.Module):
 
     @staticmethod
     def _apply_linear(layer, h):
-        if h.is_sparse:          # one-hot / sparse features (helper.py:161-172): sparse @ W^T
+        if h.is_sparse:          # one-hot / sparse features (helper.py:161-172)
+            if _is_identity(h):  # Linear(I) = W^T + b: one strided read of W instead of an N x N SpMM
+                return layer.weight.t() + layer.bias if layer.bias is not None else layer.weight.t().contiguous()
             out = torch.sparse.mm(h, layer.weight.t())
             return out if layer.bias is None else out + layer.bias
         return layer(h)

@@ -8,7 +8,7 @@ ctgcn_amd/snapshot_parallel.py.  With no process group the behaviour is the refe
 import torch
 from torch import nn
 
-from .layers import CoreDiffusion, MLP, rnn_over_rows
+from .layers import CoreDiffusion, MLP, rnn_reduce_norm
 from . import snapshot_parallel as sp_par
 
 
@@ -101,7 +101,7 @@ class CTGCN(nn.Module):
 
     def temporal_head(self, hx):
         """hx [N, T, d] -> [T, N, d]: reference models.py:249-250."""
-        return self.norm(rnn_over_rows(self.rnn, hx, reduce_sum=False)).transpose(0, 1)
+        return rnn_reduce_norm(self.rnn, self.norm, hx, reduce_sum=False).transpose(0, 1)
 
     def forward(self, x_list, adj_list):
         if self.process_group is not None:

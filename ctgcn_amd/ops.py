@@ -178,3 +178,55 @@ def core_aggregate(x, adj, relu=True):
         raise ValueError("features on %s but adjacency on %s" % (x.device, adj.device))
     x = x if x.stride(1) == 1 else x.contiguous()
     return _CoreAggregate.apply(x, adj, relu)
+
+
+# ------------------------------------------------------------- GRU over the core / time axis (+ sum, LayerNorm)
+_GI_MAX_ELEMS = 1 << 28          # fp32 elements of the input-projection buffer per row chunk (1 GiB)
+
+
+def gru_fused_ok(rnn, seq):
+    """The HIP recurrent kernel covers the configuration every shipped CTGCN config uses: single-layer
+    unidirectional batch_first GRU with hidden 128 on fp32 CUDA tensors, inference (no autograd graph)."""
+    needs_grad = torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in rnn.parameters()))
+    return (isinstance(rnn, torch.nn.GRU) and rnn.hidden_size == 128 and rnn.num_layers == 1 and not rnn.bidirectional
+            and rnn.batch_first and seq.is_cuda and seq.dtype == torch.float32 and not needs_grad)
+
+
+def gru_sequence(rnn, seq, norm, reduce_sum):
+    """LayerNorm(sum_t GRU(seq)_t) (reduce_sum) or LayerNorm(GRU(seq)) — layers.py:59-62 / models.py:249-250.
+    seq [rows, steps, d_in].  The input projection is a hipBLASLt GEMM (torch.addmm); the recurrence, the sum over
+    steps and the LayerNorm run in ONE HIP kernel (ctgcn_gru_seq_f32).  Rows are processed in chunks that bound
+    the projection buffer."""
+    lib = _lib.load()
+    rows, steps, d_in = seq.shape
+    hid = rnn.hidden_size
+    w_ih, w_hh = rnn.weight_ih_l0, rnn.weight_hh_l0.contiguous()
+    if rnn.bias:
+        bias = rnn.bias_ih_l0.clone()
+        bias[: 2 * hid] += rnn.bias_hh_l0[: 2 * hid]        # r and z gates: both biases are simply added
+        b_hn = rnn.bias_hh_l0[2 * hid:].contiguous()        # n gate: stays inside r * (W_hn h + b_hn)
+    else:
+        bias, b_hn = None, None
+    seq = seq.contiguous()
+    out = torch.empty((rows, hid) if reduce_sum else (rows, steps, hid), dtype=torch.float32, device=seq.device)
+    if rows == 0:
+        return out
+    chunk = max(32, (_GI_MAX_ELEMS // (steps * 3 * hid)) // 32 * 32)
+    gi_buf = torch.empty(min(rows, chunk) * steps, 3 * hid, dtype=torch.float32, device=seq.device)
+    w_t = w_ih.t()
+    ln_w = None if norm is None else norm.weight
+    ln_b = None if norm is None else norm.bias
+    eps = 0.0 if norm is None else float(norm.eps)
+    with torch.cuda.device(seq.device):
+        for lo in range(0, rows, chunk):
+            n = min(chunk, rows - lo)
+            gi = gi_buf[: n * steps]
+            x = seq[lo:lo + n].reshape(n * steps, d_in)
+            if bias is None:
+                torch.mm(x, w_t, out=gi)
+            else:
+                torch.addmm(bias, x, w_t, out=gi)
+            with _timed("gru_seq", rows=n, steps=steps):
+                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
+                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), _stream()), "ctgcn_gru_seq_f32")
+    return out

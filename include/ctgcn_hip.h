@@ -128,6 +128,20 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
                        int32_t table_len, int32_t *col_out, float *val_out, uint8_t *slot_out,
                        void *stream);
 
+/*
+ * Recurrent part of a single-layer GRU over `steps` for `rows` independent sequences, hidden = 128,
+ * fused with the reduction the reference applies to its output:
+ *   reduce_sum != 0 :  out[rows,128]        = LayerNorm(sum_t h_t)   nn.GRU + .sum(dim=1) + LayerNorm, layers.py:59-62
+ *   reduce_sum == 0 :  out[rows,steps,128]  = LayerNorm(h_t)         nn.GRU + LayerNorm, models.py:249-250
+ * gi [rows, steps, 384] is the input projection x·W_ih^T + b_ih (+ b_hh for the r and z gates) in PyTorch's
+ * gate order r,z,n — a plain GEMM the caller runs with its BLAS; w_hh [384,128] and b_hn [128] (the n-gate's
+ * hidden bias, NULL = 0) are the module's weight_hh_l0 and bias_hh_l0[256:384].  ln_weight == NULL skips the
+ * LayerNorm.  h_0 = 0.  Exact fp32 arithmetic (f32-input MFMA).
+ */
+int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
+                      const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
+                      int reduce_sum, float *out, void *stream);
+
 size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t K);
 
 #ifdef __cplusplus

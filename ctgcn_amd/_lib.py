@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libctgcn_hip.so")
+LIB_PATH = os.environ.get("CTGCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libctgcn_hip.so")   # env override: kernel A/B builds
 
 F_SELF_LOOP, F_RELU, F_NESTED = 1, 2, 4
 OP_KCORE = 1
@@ -30,6 +30,7 @@ SIGNATURES = {
     "ctgcn_edge_levels_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp]),
+    "ctgcn_gru_row_granule": (_i64, []),
     "ctgcn_workspace_bytes": (_sz, [_int, _i64, _i64, _i32, _i32]),
 }
 

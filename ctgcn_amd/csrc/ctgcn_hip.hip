@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void slot_reorder_kernel(int64_t n, int K, con
 // ================================================================================================
 typedef float f4v __attribute__((ext_vector_type(4)));
 constexpr int GRU_H = 128;
-constexpr int GRU_BM = 32;           // rows per block iteration = 2 MFMA row tiles
+constexpr int GRU_BM = 64;           // rows per block iteration = 4 MFMA row tiles
 constexpr int GRU_RT = GRU_BM / 16;
 constexpr int GRU_PITCH = 132;       // floats; 528 B keeps rows 16-B aligned
 
@@ -533,8 +533,9 @@ struct GruArgs {
     float *out;
 };
 
-__device__ __forceinline__ float gru_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each): far inside the fp32 tolerance of the layer, a fraction of an IEEE divide's cost
+__device__ __forceinline__ float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src, float *__restrict__ dst, int lane,
                                                   const float *gamma, const float *beta, float eps)
@@ -556,9 +557,12 @@ __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src,
     *(float2 *)(dst + lane * 2) = v;
 }
 
+template <bool REDUCE>
 __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
 {
+    // h_{t-1} / h_t (double buffered) and the running sum over steps, all [row][hidden] with a padded pitch
     __shared__ float hbuf[2][GRU_BM][GRU_PITCH];
+    __shared__ float sbuf[REDUCE ? GRU_BM : 1][GRU_PITCH];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 15, grp = lane >> 4;
     const int hid = wave * 16 + col;
@@ -577,38 +581,49 @@ __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
     }
     const float b_hn = a.bhn ? a.bhn[hid] : 0.f;
     const int64_t ntiles = (a.rows + GRU_BM - 1) / GRU_BM;
+    const int gstride = steps * 3 * GRU_H;              // GI elements per row
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * GRU_BM;
-        float hreg[GRU_RT][4], hsum[GRU_RT][4];
+        const float *gi_tile = a.gi + row0 * gstride + hid;
+        const int last = (int)min((int64_t)GRU_BM, a.rows - row0) - 1;   // rows beyond the end re-read the last valid row
+        // this lane's C-layout rows of row tile rt are rt*16 + grp*4 + i; 32-bit element offset into gi_tile
+        auto goff = [&](int rt, int i) { return min(rt * 16 + grp * 4 + i, last) * gstride; };
+
+        // ---- step 0: h_{-1} = 0, so gh = 0 and no MFMA is issued
 #pragma unroll
         for (int rt = 0; rt < GRU_RT; ++rt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { hreg[rt][i] = 0.f; hsum[rt][i] = 0.f; }
+            for (int i = 0; i < 4; ++i) {
+                const float *p = gi_tile + goff(rt, i);
+                const float r = gru_sigmoid(p[0]);
+                const float z = gru_sigmoid(p[GRU_H]);
+                const float n = gru_tanh(p[2 * GRU_H] + r * b_hn);
+                const float h = n - z * n;
+                hbuf[0][rt * 16 + grp * 4 + i][hid] = h;
+                if (REDUCE) sbuf[rt * 16 + grp * 4 + i][hid] = h;
+            }
+        __syncthreads();
+        if (!REDUCE)
+            for (int r = wave; r <= last; r += 8)
+                gru_layernorm_row(hbuf[0][r], a.out + ((row0 + r) * steps) * GRU_H, lane, a.gamma, a.beta, a.eps);
 
-        for (int t = 0; t < steps; ++t) {
-            // this lane's C-layout positions: rows rt*16 + grp*4 + i, hidden `hid`
-            float gi[GRU_RT][3][4];
+        // ---- steps 1..: software pipeline over the row tiles — the MFMAs of tile rt run with the gate math of tile rt-1
+        for (int t = 1; t < steps; ++t) {
+            const float(*hprev)[GRU_PITCH] = hbuf[(t - 1) & 1];
+            float(*hcur)[GRU_PITCH] = hbuf[t & 1];
+            const float *gi_t = gi_tile + t * 3 * GRU_H;
+            f4v acc[2][3];
+            float gi[2][3][4];
 #pragma unroll
-            for (int rt = 0; rt < GRU_RT; ++rt)
+            for (int rt = 0; rt <= GRU_RT; ++rt) {
+                const int cur = rt & 1, prv = cur ^ 1;
+                float av[32];
+                if (rt < GRU_RT) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int64_t r = row0 + rt * 16 + grp * 4 + i;
-                    r = r < a.rows ? r : a.rows - 1;                 // clamp: loads stay unconditional
-                    const float *p = a.gi + (r * steps + t) * (3 * GRU_H) + hid;
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) gi[rt][g][i] = p[g * GRU_H];
-                }
-            f4v acc[GRU_RT][3];
-#pragma unroll
-            for (int rt = 0; rt < GRU_RT; ++rt)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc[rt][g] = f4v{0.f, 0.f, 0.f, 0.f};
-            if (t > 0) {
-                const float(*hprev)[GRU_PITCH] = hbuf[(t - 1) & 1];
-#pragma unroll
-                for (int rt = 0; rt < GRU_RT; ++rt) {
-                    float av[32];
+                        for (int g = 0; g < 3; ++g) gi[cur][g][i] = gi_t[goff(rt, i) + g * GRU_H];   // used one stage later
                     const f4v *src = (const f4v *)(&hprev[rt * 16 + col][32 * grp]);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
@@ -616,46 +631,36 @@ __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
                         av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
                     }
 #pragma unroll
-                    for (int kk = 0; kk < 32; ++kk)
+                    for (int g = 0; g < 3; ++g) acc[cur][g] = f4v{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    if (rt < GRU_RT) {
 #pragma unroll
                         for (int g = 0; g < 3; ++g)
-                            acc[rt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], W[g][kk], acc[rt][g], 0, 0, 0);
+                            acc[cur][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], W[g][kk], acc[cur][g], 0, 0, 0);
+                    }
+                    if (rt > 0 && (kk & 7) == 4) {       // one element of the previous tile's gates every 8 k-steps
+                        const int i = kk >> 3;
+                        const int r_ = (rt - 1) * 16 + grp * 4 + i;
+                        const float hold = hprev[r_][hid];
+                        const float r = gru_sigmoid(gi[prv][0][i] + acc[prv][0][i]);
+                        const float z = gru_sigmoid(gi[prv][1][i] + acc[prv][1][i]);
+                        const float n = gru_tanh(gi[prv][2][i] + r * (acc[prv][2][i] + b_hn));
+                        const float h = n + z * (hold - n);
+                        hcur[r_][hid] = h;
+                        if (REDUCE) sbuf[r_][hid] += h;
+                    }
                 }
             }
-            float(*hcur)[GRU_PITCH] = hbuf[t & 1];
-#pragma unroll
-            for (int rt = 0; rt < GRU_RT; ++rt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float r = gru_sigmoid(gi[rt][0][i] + acc[rt][0][i]);
-                    const float z = gru_sigmoid(gi[rt][1][i] + acc[rt][1][i]);
-                    const float n = gru_tanh(gi[rt][2][i] + r * (acc[rt][2][i] + b_hn));
-                    const float h = n + z * (hreg[rt][i] - n);
-                    hreg[rt][i] = h;
-                    hsum[rt][i] += h;
-                    hcur[rt * 16 + grp * 4 + i][hid] = h;
-                }
             __syncthreads();
-            if (!a.reduce_sum) {
-                for (int r = wave; r < GRU_BM; r += 8) {
-                    const int64_t row = row0 + r;
-                    if (row < a.rows)
-                        gru_layernorm_row(hcur[r], a.out + (row * steps + t) * GRU_H, lane, a.gamma, a.beta, a.eps);
-                }
-            }
+            if (!REDUCE)
+                for (int r = wave; r <= last; r += 8)
+                    gru_layernorm_row(hcur[r], a.out + ((row0 + r) * steps + t) * GRU_H, lane, a.gamma, a.beta, a.eps);
         }
-        if (a.reduce_sum) {
-            float(*sbuf)[GRU_PITCH] = hbuf[steps & 1];        // not the buffer of the last step (nobody reads it, but keep it simple)
-#pragma unroll
-            for (int rt = 0; rt < GRU_RT; ++rt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sbuf[rt * 16 + grp * 4 + i][hid] = hsum[rt][i];
-            __syncthreads();
-            for (int r = wave; r < GRU_BM; r += 8) {
-                const int64_t row = row0 + r;
-                if (row < a.rows) gru_layernorm_row(sbuf[r], a.out + row * GRU_H, lane, a.gamma, a.beta, a.eps);
-            }
-        }
+        if (REDUCE)
+            for (int r = wave; r <= last; r += 8)
+                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
         __syncthreads();       // LDS is reused by the next tile
     }
 }
@@ -850,6 +855,14 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
     return CTGCN_OK;
 }
 
+int64_t ctgcn_gru_row_granule(void)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    return (int64_t)GRU_BM * cus;
+}
+
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
                       int reduce_sum, float *out, void *stream)
@@ -868,7 +881,10 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 8-wave block per CU
-    hipLaunchKernelGGL(gru_seq_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    if (a.reduce_sum)
+        hipLaunchKernelGGL(gru_seq_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(gru_seq_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -211,7 +211,12 @@ def gru_sequence(rnn, seq, norm, reduce_sum):
     out = torch.empty((rows, hid) if reduce_sum else (rows, steps, hid), dtype=torch.float32, device=seq.device)
     if rows == 0:
         return out
-    chunk = max(32, (_GI_MAX_ELEMS // (steps * 3 * hid)) // 32 * 32)
+    # chunk rows: bounded projection buffer, equal-sized chunks, each a multiple of the kernel's row granule
+    # (rows per block x CUs) so that no launch ends with a mostly idle round of blocks
+    granule = int(lib.ctgcn_gru_row_granule())
+    max_rows = max(granule, (_GI_MAX_ELEMS // (steps * 3 * hid)) // granule * granule)
+    n_chunks = -(-rows // max_rows)
+    chunk = -(-(-(-rows // n_chunks)) // granule) * granule
     gi_buf = torch.empty(min(rows, chunk) * steps, 3 * hid, dtype=torch.float32, device=seq.device)
     w_t = w_ih.t()
     ln_w = None if norm is None else norm.weight

@@ -142,6 +142,10 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
                       int reduce_sum, float *out, void *stream);
 
+/* Rows one wave of persistent blocks covers (rows per block x compute units): callers that split `rows` into
+ * chunks should use multiples of this so that every launch keeps all CUs equally busy. */
+int64_t ctgcn_gru_row_granule(void);
+
 size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t K);
 
 #ifdef __cplusplus

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("CTGCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libct
 
 F_SELF_LOOP, F_RELU, F_NESTED = 1, 2, 4
 OP_KCORE = 1
+OP_INGEST = 2
 MAX_SLOTS = 255
 ABI_VERSION = 1
 
@@ -26,6 +27,7 @@ SIGNATURES = {
     "ctgcn_core_aggregate_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _u32, _vp]),
     "ctgcn_core_aggregate_bwd_prep_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
     "ctgcn_core_aggregate_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u32, _vp]),
+    "ctgcn_edges_to_csr": (_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i64), _vp, _sz, _vp]),
     "ctgcn_kcore_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_i32), _vp]),
     "ctgcn_edge_levels_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),

@@ -4,17 +4,17 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "ctgcn_hip.hip")
+SRCS = [os.path.join(_HERE, "csrc", f) for f in ("ctgcn_hip.hip", "ctgcn_ingest.hip")]
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctgcn_hip.h")
 OUT = os.path.join(_HERE, "csrc", "libctgcn_hip.so")
 
 
 def build(force=False, verbose=False):
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(HDR))
+    newest = max([os.path.getmtime(f) for f in SRCS] + [os.path.getmtime(HDR)])
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + SRCS
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

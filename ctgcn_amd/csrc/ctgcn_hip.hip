@@ -676,6 +676,11 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 }  // namespace
 
 // =================================================================================== C ABI
+extern "C" size_t ctgcn_ingest_workspace_bytes_(int64_t n, int64_t m);   // ctgcn_ingest.hip
+
+// shared with the other translation units of the library (not part of the public header)
+extern "C" int ctgcn_set_error_(int code, const char *msg) { return fail(code, "%s", msg); }
+
 extern "C" {
 
 int ctgcn_abi_version(void) { return CTGCN_ABI_VERSION; }
@@ -774,6 +779,7 @@ size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t 
         return align_up(sizeof(KcoreCtl), 256) + align_up(nn * 4, 256) /*deg*/ + align_up((nn + 31) / 32 * 4, 256) /*claimed*/
                + 2 * align_up(nn * 4, 256) /*pool*/;
     }
+    if (op == CTGCN_OP_INGEST) return ctgcn_ingest_workspace_bytes_(n, nnz);   /* nnz = number of edge rows m */
     return 0;
 }
 

@@ -72,8 +72,7 @@ class DataLoader(object):
         window, cores = [], []
         for i in self._window(start_idx, duration):
             src, dst, w = read_edge_rows(os.path.join(origin_base_path, files[i]), self.node2idx_dict, sep)
-            csr = symmetric_csr_from_rows(src, dst, w, self.node_num)
-            adj, core, file_count = core_adj_from_scipy(csr, max_core, self.device)
+            adj, core, file_count = core_adj_from_edge_rows(src, dst, w, self.node_num, max_core, self.device)
             if max_core == -1:
                 max_core = file_count
             window.append(adj if adj is not None else [])
@@ -124,4 +123,15 @@ def core_adj_from_scipy(csr, max_core, device):
     row_ptr = torch.from_numpy(csr.indptr.astype(np.int32)).to(device)
     col = torch.from_numpy(csr.indices.astype(np.int32)).to(device)
     val = torch.from_numpy(csr.data.astype(np.float32)).to(device)
+    return CoreAdj.from_graph(row_ptr, col, val, max_core=max_core)
+
+
+def core_adj_from_edge_rows(src, dst, w, n, max_core, device):
+    """Edge rows (numpy, file order) -> CoreAdj with every stage on the GPU: de-dup / symmetrise / CSR
+    (ctgcn_edges_to_csr), k-core peel, level tags, slot reorder."""
+    from . import ops
+    s = torch.from_numpy(np.ascontiguousarray(src, dtype=np.int32)).to(device)
+    d = torch.from_numpy(np.ascontiguousarray(dst, dtype=np.int32)).to(device)
+    ww = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(device)
+    row_ptr, col, val = ops.edges_to_csr(s, d, ww, n)
     return CoreAdj.from_graph(row_ptr, col, val, max_core=max_core)

@@ -56,6 +56,30 @@ def _i32(t):
     return t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
 
 
+# ------------------------------------------------------------------------------------------- ingest
+def edges_to_csr(src, dst, w, n):
+    """Edge rows (file order; CUDA int32/int32/float32 or None) -> (row_ptr, col, val) of the symmetric,
+    de-duplicated (last row wins), zero-diagonal CSR — reference utils.py:23-58 graph semantics, on the GPU."""
+    _need_cuda(src, dst, w)
+    lib = _lib.load()
+    src, dst = _i32(src), _i32(dst)
+    if w is not None:
+        w = w if (w.dtype == torch.float32 and w.is_contiguous()) else w.to(torch.float32).contiguous()
+    m = src.numel()
+    dev = src.device
+    row_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(2 * m, dtype=torch.int32, device=dev)
+    val = torch.empty(2 * m, dtype=torch.float32, device=dev)
+    nnz = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        nbytes = lib.ctgcn_workspace_bytes(_lib.OP_INGEST, n, m, 0, 0)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        check(lib.ctgcn_edges_to_csr(n, m, ptr(src), ptr(dst), ptr(w), ptr(row_ptr), ptr(col), ptr(val), ctypes.byref(nnz),
+                                     ptr(ws), nbytes, _stream()), "ctgcn_edges_to_csr")
+    k = int(nnz.value)
+    return row_ptr, col[:k], val[:k]
+
+
 # ------------------------------------------------------------------------------------------- k-core
 def kcore(row_ptr, col):
     """Core number of every vertex (reference: networkx.core_number at structure_generation.py:35).

@@ -65,21 +65,15 @@ def dynamic_graph(n, avg_deg, snapshots, seed=DEFAULT_SEED, max_degree_hint=None
 
 
 def dynamic_graph_device(n, avg_deg, snapshots, device, seed=DEFAULT_SEED, max_degree_hint=None, which=None):
-    """Same graphs as dynamic_graph, built as device CSR triples (row_ptr int32, col int32, val float32) with
-    torch sort/bincount on the GPU (plumbing).  `which`: iterable of snapshot indices to build (default all);
+    """Same graphs as dynamic_graph, built as device CSR triples (row_ptr int32, col int32, val float32) by the
+    library's GPU ingest (ctgcn_edges_to_csr).  `which`: iterable of snapshot indices to build (default all);
     returns {t: (row_ptr, col, val)}."""
     u, v = powerlaw_edges(n, int(n * avg_deg / 2), seed, max_degree_hint=max_degree_hint)
     sizes = prefix_sizes(len(u), snapshots)
-    ud, vd = torch.from_numpy(u).to(device), torch.from_numpy(v).to(device)
+    from . import ops
+    ud, vd = torch.from_numpy(u.astype(np.int32)).to(device), torch.from_numpy(v.astype(np.int32)).to(device)
     out = {}
     for t in (range(snapshots) if which is None else which):
         m = sizes[t]
-        r = torch.cat([ud[:m], vd[:m]])
-        c = torch.cat([vd[:m], ud[:m]])
-        order = torch.argsort(r * n + c)
-        counts = torch.bincount(r, minlength=n)
-        row_ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
-        row_ptr[1:] = torch.cumsum(counts, 0)
-        out[t] = (row_ptr.to(torch.int32), c[order].to(torch.int32).contiguous(),
-                  torch.ones(2 * m, dtype=torch.float32, device=device))
+        out[t] = ops.edges_to_csr(ud[:m], vd[:m], None, n)      # HIP ingest: symmetrise + sort + CSR
     return out

@@ -47,7 +47,8 @@ enum {
 };
 
 enum { /* `op` of ctgcn_workspace_bytes */
-    CTGCN_OP_KCORE = 1
+    CTGCN_OP_KCORE = 1,
+    CTGCN_OP_INGEST = 2     /* pass the number of edge rows m as `nnz` */
 };
 
 #define CTGCN_MAX_SLOTS 255
@@ -95,6 +96,18 @@ int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int
                                  const int32_t *col_idx, const float *val, const uint8_t *slot,
                                  const float *Z, const float *S0, float *dX, int64_t lddx,
                                  uint32_t flags, void *stream);
+
+/*
+ * Edge rows (in file order) -> the snapshot's simple undirected weighted graph as symmetric, zero-diagonal CSR
+ * with sorted columns.  Replaces the graph construction at utils.py:23-30 (get_nx_graph) and utils.py:35-58
+ * (get_sp_adj_mat): every row sets weight({src,dst}) = w (1.0 when w == NULL); the LAST row naming an
+ * unordered pair wins; rows with src == dst are dropped.  src/dst: int32[m] node indices in [0, n).
+ * Outputs: row_ptr int32[n+1]; col_idx int32 / val float with capacity 2*m; *nnz_host = entries stored
+ * (2 x distinct pairs).  workspace: ctgcn_workspace_bytes(CTGCN_OP_INGEST, n, m, 0, 0).  Synchronises `stream`.
+ */
+int ctgcn_edges_to_csr(int64_t n, int64_t m, const int32_t *src, const int32_t *dst, const float *w,
+                       int32_t *row_ptr, int32_t *col_idx, float *val, int64_t *nnz_host,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Core number of every vertex of an undirected simple graph given as symmetric CSR structure

@@ -236,3 +236,50 @@ def test_native_route_equals_matrix_route():
             assert adj.nnz_per_slot == ref.nnz_per_slot, (gi, mc)
             for a, b in ((adj.row_ptr, ref.row_ptr), (adj.col, ref.col), (adj.val, ref.val), (adj.slot, ref.slot)):
                 assert torch.equal(a.cpu(), b), (gi, mc)
+
+
+# ------------------------------------------------------------------------ edge rows -> CSR on the GPU
+def _ingest_case(src, dst, w, n):
+    from ctgcn_amd import ops
+    from oracle import oracle as O
+    d = _dev()
+    rp, col, val = ops.edges_to_csr(torch.from_numpy(np.asarray(src, np.int32)).to(d), torch.from_numpy(np.asarray(dst, np.int32)).to(d),
+                                    None if w is None else torch.from_numpy(np.asarray(w, np.float32)).to(d), n)
+    ref = O.adjacency_from_edge_rows(src, dst, np.ones(len(src)) if w is None else w, n)
+    assert np.array_equal(rp.cpu().numpy(), ref.indptr) and np.array_equal(col.cpu().numpy(), ref.indices)
+    assert np.array_equal(val.cpu().numpy(), ref.data.astype(np.float32))
+
+
+def test_edges_to_csr_reference_semantics():
+    g = load_golden("weighted_small.npz")
+    for c in range(int(g["n_cases"])):
+        p = "c%d_" % c
+        for s in range(2):
+            _ingest_case(g[p + "s%d_src" % s], g[p + "s%d_dst" % s], g[p + "s%d_w" % s], int(g[p + "n"]))
+            # and against the reference's own matrix (utils.get_sp_adj_mat), bit for bit
+            from ctgcn_amd import ops
+            d = _dev()
+            rp, col, val = ops.edges_to_csr(torch.from_numpy(g[p + "s%d_src" % s]).to(d), torch.from_numpy(g[p + "s%d_dst" % s]).to(d),
+                                            torch.from_numpy(g[p + "s%d_w" % s].astype(np.float32)).to(d), int(g[p + "n"]))
+            want = csr_from(g, p + "s%d_dateadj" % s, int(g[p + "n"]))
+            assert np.array_equal(rp.cpu().numpy(), want.indptr) and np.array_equal(col.cpu().numpy(), want.indices)
+            assert np.array_equal(val.cpu().numpy().astype(np.float64), want.data)
+    snaps = load_golden("uci_snapshots.npz")          # 24 468 duplicate rows in 2004-05
+    for t in range(7):
+        _ingest_case(snaps["t%d_src" % t], snaps["t%d_dst" % t], snaps["t%d_w" % t], len(snaps["node_names"]))
+
+
+def test_edges_to_csr_edge_cases_and_scale():
+    rng = np.random.default_rng(3)
+    _ingest_case(np.zeros(0, np.int32), np.zeros(0, np.int32), None, 5)                       # no rows
+    _ingest_case([2, 2, 2], [2, 2, 2], [1.0, 2.0, 3.0], 4)                                    # only self loops
+    _ingest_case([0, 1, 0, 1, 0], [1, 0, 1, 0, 1], [1.0, 2.0, 3.0, 4.0, 5.0], 2)              # one pair, five rows: last wins
+    _ingest_case([3, 0], [0, 3], None, 4)                                                     # unweighted
+    n, m = 200000, 3000000
+    src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+    src[:1000] = dst[:1000]                                                                    # self loops
+    src[1000:200000], dst[1000:200000] = dst[400000:599000].copy(), src[400000:599000].copy()  # reversed duplicates
+    _ingest_case(src, dst, rng.integers(1, 100, m).astype(np.float64), n)
+    n = 46341                                                                                  # n*n just above 2^31
+    src, dst = rng.integers(n - 50, n, 5000), rng.integers(n - 50, n, 5000)
+    _ingest_case(src, dst, rng.integers(1, 9, 5000).astype(np.float64), n)

@@ -316,7 +316,8 @@ struct KcoreCtl {
 };
 
 constexpr int KC_QCAP = 8192;
-constexpr int KC_GROUP = 16;   // lanes cooperating on one vertex's neighbour list
+constexpr int KC_GROUP = 16;   // lanes cooperating on one vertex's neighbour list ...
+constexpr int KC_LONG = 48;    // ... unless it is longer than this: then a whole wave takes it
 
 __global__ __launch_bounds__(256) void kcore_init_kernel(int n, const int32_t *__restrict__ row_ptr,
                                                          const int32_t *__restrict__ col, int32_t *__restrict__ deg)
@@ -365,6 +366,19 @@ __global__ __launch_bounds__(256) void kcore_level_kernel(int n, int k, int chun
         if (__hip_atomic_load(&deg[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == k && kc_claim(claimed, v)) push(v);
 
     const int grp = tid / KC_GROUP, lig = tid % KC_GROUP, ngrp = 256 / KC_GROUP;
+    const int wv = tid >> 6, wl = tid & 63;
+    // remove v: decrement every live neighbour; whoever takes a neighbour from k+1 to k owns (claims + queues) it
+    auto relax = [&](int v, int u) {
+        if (u == v) return;
+        if (__hip_atomic_load(&deg[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) {
+            const int old = atomicSub(&deg[u], 1);
+            if (old == k + 1) {
+                if (kc_claim(claimed, u)) push(u);
+            } else if (old <= k) {
+                atomicAdd(&deg[u], 1);
+            }
+        }
+    };
     int begin = 0, processed = 0;
     for (;;) {
         __syncthreads();
@@ -382,20 +396,19 @@ __global__ __launch_bounds__(256) void kcore_level_kernel(int n, int k, int chun
             tail = s_tail;
             if (tail == 0) break;
         }
+        // pass A: short neighbour lists, one 16-lane group per vertex; pass B: long lists (hubs, the dense top
+        // cores), one whole wave per vertex — the chase is latency bound, so hubs must not crawl 16 lanes at a time
         for (int i = begin + grp; i < tail; i += ngrp) {
             const int v = q[i];
-            for (int e = row_ptr[v] + lig, end = row_ptr[v + 1]; e < end; e += KC_GROUP) {
-                const int u = col[e];
-                if (u == v) continue;
-                if (__hip_atomic_load(&deg[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > k) {
-                    const int old = atomicSub(&deg[u], 1);
-                    if (old == k + 1) {
-                        if (kc_claim(claimed, u)) push(u);
-                    } else if (old <= k) {
-                        atomicAdd(&deg[u], 1);
-                    }
-                }
-            }
+            const int s0 = row_ptr[v], e0 = row_ptr[v + 1];
+            if (e0 - s0 > KC_LONG) continue;
+            for (int e = s0 + lig; e < e0; e += KC_GROUP) relax(v, col[e]);
+        }
+        for (int i = begin + wv; i < tail; i += 4) {
+            const int v = q[i];
+            const int s0 = row_ptr[v], e0 = row_ptr[v + 1];
+            if (e0 - s0 <= KC_LONG) continue;
+            for (int e = s0 + wl; e < e0; e += 64) relax(v, col[e]);
         }
         processed += tail - begin;
         begin = tail;

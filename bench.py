@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="synthetic-1m", choices=sorted(WORKLOADS))
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"])
+    ap.add_argument("--train", action="store_true",
+                    help="time forward + backward + Adam step (surrogate loss out.square().mean(); the reference's "
+                         "negative-sampling loss is outside the hot path) instead of the embedding forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
@@ -134,9 +137,22 @@ def main():
     launches = []
     ops.set_launch_timer(lambda name, start, end, meta: launches.append((name, start, end, meta)))
 
+    if args.train:
+        model.train()
+        params = list(spp.owned_parameters(model)) if use_dist else list(model.parameters())
+        opt = torch.optim.Adam(params, lr=1e-3)
+
     def step():
-        with torch.no_grad():
-            return model(x_list, adj_list)
+        if not args.train:
+            with torch.no_grad():
+                return model(x_list, adj_list)
+        opt.zero_grad(set_to_none=True)
+        out = model(x_list, adj_list)
+        out.square().mean().backward()
+        if use_dist:
+            spp.allreduce_replicated_grads(model)
+        opt.step()
+        return out.detach()
 
     def fence():
         torch.cuda.synchronize()
@@ -207,7 +223,7 @@ def main():
         cpu = cpu_baseline(adj_list[T - 1], emb, args.cpu_budget_s, log)
 
     line = {
-        "metric": "aggregated edges/s over T-snapshot window (CTGCN-C embedding forward)",
+        "metric": "aggregated edges/s over T-snapshot window (CTGCN-C %s)" % ("training step: forward + backward + Adam" if args.train else "embedding forward"),
         "value": agg_edges_step / (ms_per_step * 1e-3),
         "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

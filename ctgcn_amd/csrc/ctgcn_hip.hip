@@ -544,6 +544,7 @@ struct GruArgs {
     float eps;
     int32_t reduce_sum;     // 1: out[rows,128] = LN(sum_t h_t)   0: out[rows,steps,128] = LN(h_t)
     float *out;
+    float *gates;           // optional [rows, steps, 4, 128]: r, z, n, q = W_hn h + b_hn, saved for the backward kernel
 };
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each): far inside the fp32 tolerance of the layer, a fraction of an IEEE divide's cost
@@ -570,7 +571,7 @@ __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src,
     *(float2 *)(dst + lane * 2) = v;
 }
 
-template <bool REDUCE>
+template <bool REDUCE, bool SAVE>
 __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
 {
     // h_{t-1} / h_t (double buffered) and the running sum over steps, all [row][hidden] with a padded pitch
@@ -615,6 +616,10 @@ __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
                 const float h = n - z * n;
                 hbuf[0][rt * 16 + grp * 4 + i][hid] = h;
                 if (REDUCE) sbuf[rt * 16 + grp * 4 + i][hid] = h;
+                if (SAVE && rt * 16 + grp * 4 + i <= last) {
+                    float *gp = a.gates + ((row0 + rt * 16 + grp * 4 + i) * steps) * (4 * GRU_H) + hid;
+                    gp[0] = r; gp[GRU_H] = z; gp[2 * GRU_H] = n; gp[3 * GRU_H] = b_hn;
+                }
             }
         __syncthreads();
         if (!REDUCE)
@@ -663,6 +668,10 @@ __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
                         const float h = n + z * (hold - n);
                         hcur[r_][hid] = h;
                         if (REDUCE) sbuf[r_][hid] += h;
+                        if (SAVE && r_ <= last) {
+                            float *gp = a.gates + ((row0 + r_) * steps + t) * (4 * GRU_H) + hid;
+                            gp[0] = r; gp[GRU_H] = z; gp[2 * GRU_H] = n; gp[3 * GRU_H] = acc[prv][2][i] + b_hn;
+                        }
                     }
                 }
             }
@@ -674,6 +683,112 @@ __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
         if (REDUCE)
             for (int r = wave; r <= last; r += 8)
                 gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+        __syncthreads();       // LDS is reused by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the GRU recurrence (what autograd derives for nn.GRU at layers.py:59 / models.py:249).
+// Walks t = steps-1 .. 0 with dh = dh_seq[t] (or the broadcast dh_sum) + the recurrent term carried in registers:
+//   dn = dh(1-z); dz = dh(h_{t-1}-n); da_n = dn(1-n²); da_z = dz z(1-z); da_r = da_n q r(1-r)
+//   dGI[t] = (da_r, da_z, da_n)      dGHn[t] = da_n r      dh_{t-1} = dh z + (da_r, da_z, da_n r)·W_hh
+// Same block shape as the forward: wave w owns hidden units [16w,16w+16) of dh and keeps W_hh[:, 16w..] (384 x 16)
+// in 96 VGPRs as MFMA B operands; the block's dGH rows go through LDS (double buffered) as A operands.
+// The weight gradients are plain GEMMs over the materialised dGI / dGHn and stay with the caller's BLAS.
+// ------------------------------------------------------------------------------------------------
+constexpr int GRUB_BM = 32;
+constexpr int GRUB_RT = GRUB_BM / 16;
+constexpr int GRUB_PITCH = 3 * GRU_H + 4;
+
+struct GruBwdArgs {
+    int64_t rows;
+    int32_t steps;
+    const float *gates;    // [rows, steps, 4, 128]
+    const float *hseq;     // [rows, steps, 128]
+    const float *dh_seq;   // [rows, steps, 128] or null
+    const float *dh_sum;   // [rows, 128] added at every step, or null
+    const float *whh;      // [384, 128]
+    float *dgi;            // [rows, steps, 384]
+    float *dghn;           // [rows, steps, 128]
+};
+
+__global__ __launch_bounds__(512, 2) void gru_seq_bwd_kernel(const GruBwdArgs a)
+{
+    __shared__ float gbuf[2][GRUB_BM][GRUB_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int hid = wave * 16 + col;
+    const int steps = a.steps;
+
+    // B operands: dh_prev[:, hid] = sum_k dGH[:, k] W_hh[k][hid];  k = g*128 + 32*grp + kk
+    float W[3][32];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) W[g][kk] = a.whh[(int64_t)(g * GRU_H + 32 * grp + kk) * GRU_H + hid];
+
+    const int64_t ntiles = (a.rows + GRUB_BM - 1) / GRUB_BM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * GRUB_BM;
+        const int last = (int)min((int64_t)GRUB_BM, a.rows - row0) - 1;
+        float drec[GRUB_RT][4];
+#pragma unroll
+        for (int rt = 0; rt < GRUB_RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) drec[rt][i] = 0.f;
+
+        for (int t = steps - 1; t >= 0; --t) {
+            float(*gcur)[GRUB_PITCH] = gbuf[t & 1];
+#pragma unroll
+            for (int rt = 0; rt < GRUB_RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r_ = rt * 16 + grp * 4 + i;
+                    const int64_t row = row0 + min(r_, last);
+                    const float *gp = a.gates + (row * steps + t) * (4 * GRU_H) + hid;
+                    const float r = gp[0], z = gp[GRU_H], n = gp[2 * GRU_H], q = gp[3 * GRU_H];
+                    const float hprev = t > 0 ? a.hseq[(row * steps + t - 1) * GRU_H + hid] : 0.f;
+                    float dh = drec[rt][i];
+                    if (a.dh_seq) dh += a.dh_seq[(row * steps + t) * GRU_H + hid];
+                    if (a.dh_sum) dh += a.dh_sum[row * GRU_H + hid];
+                    const float dan = dh * (1.f - z) * (1.f - n * n);
+                    const float daz = dh * (hprev - n) * z * (1.f - z);
+                    const float dar = dan * q * r * (1.f - r);
+                    const float dgn = dan * r;
+                    drec[rt][i] = dh * z;                       // direct path; the W_hh path is added after the MFMAs
+                    gcur[r_][hid] = dar;
+                    gcur[r_][GRU_H + hid] = daz;
+                    gcur[r_][2 * GRU_H + hid] = dgn;
+                    if (r_ <= last) {
+                        float *o = a.dgi + (row * steps + t) * (3 * GRU_H) + hid;
+                        o[0] = dar; o[GRU_H] = daz; o[2 * GRU_H] = dan;
+                        a.dghn[(row * steps + t) * GRU_H + hid] = dgn;
+                    }
+                }
+            if (t == 0) break;                                   // h_{-1} is the constant 0: nothing to propagate
+            __syncthreads();
+#pragma unroll
+            for (int rt = 0; rt < GRUB_RT; ++rt) {
+                f4v acc0 = f4v{0.f, 0.f, 0.f, 0.f}, acc1 = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    float av[32];
+                    const f4v *src = (const f4v *)(&gcur[rt * 16 + col][g * GRU_H + 32 * grp]);
+#pragma unroll
+                    for (int qd = 0; qd < 8; ++qd) {
+                        const f4v v = src[qd];
+                        av[4 * qd + 0] = v.x; av[4 * qd + 1] = v.y; av[4 * qd + 2] = v.z; av[4 * qd + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 32; kk += 2) {         // two accumulators: dependent MFMAs are 64 cycles apart
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], W[g][kk], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk + 1], W[g][kk + 1], acc1, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) drec[rt][i] += acc0[i] + acc1[i];
+            }
+        }
         __syncthreads();       // LDS is reused by the next tile
     }
 }
@@ -884,7 +999,7 @@ int64_t ctgcn_gru_row_granule(void)
 
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, void *stream)
+                      int reduce_sum, float *out, float *gates_out, void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq: hidden=%d, only %d is built", hidden, GRU_H);
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq: bad sizes rows=%lld steps=%d", (long long)rows, steps);
@@ -894,16 +1009,40 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
         return fail(CTGCN_E_INVALID, "gru_seq: w_hh must be 16-byte aligned, out / ln_weight 8-byte aligned");
     GruArgs a{};
     a.rows = rows; a.steps = steps; a.gi = gi; a.whh = w_hh; a.bhn = b_hn; a.gamma = ln_weight; a.beta = ln_bias;
-    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out;
+    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = gates_out;
+    if (gates_out && (reduce_sum || ln_weight)) return fail(CTGCN_E_INVALID, "gru_seq: gates_out needs reduce_sum == 0 and no LayerNorm (raw h sequence)");
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 8-wave block per CU
     if (a.reduce_sum)
-        hipLaunchKernelGGL(gru_seq_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((gru_seq_kernel<true, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (a.gates)
+        hipLaunchKernelGGL((gru_seq_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(gru_seq_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((gru_seq_kernel<false, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *h_seq,
+                          const float *dh_seq, const float *dh_sum, const float *w_hh, float *d_gi, float *d_ghn,
+                          void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq_bwd: hidden=%d, only %d is built", hidden, GRU_H);
+    if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq_bwd: bad sizes");
+    if (rows == 0) return CTGCN_OK;
+    if (!gates || !h_seq || !w_hh || !d_gi || !d_ghn || (!dh_seq && !dh_sum)) return fail(CTGCN_E_INVALID, "gru_seq_bwd: null pointer");
+    GruBwdArgs a{};
+    a.rows = rows; a.steps = steps; a.gates = gates; a.hseq = h_seq; a.dh_seq = dh_seq; a.dh_sum = dh_sum; a.whh = w_hh;
+    a.dgi = d_gi; a.dghn = d_ghn;
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t ntiles = (rows + GRUB_BM - 1) / GRUB_BM;
+    const int64_t blocks = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

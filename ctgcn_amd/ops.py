@@ -209,53 +209,154 @@ _GI_MAX_ELEMS = 1 << 28          # fp32 elements of the input-projection buffer 
 
 
 def gru_fused_ok(rnn, seq):
-    """The HIP recurrent kernel covers the configuration every shipped CTGCN config uses: single-layer
-    unidirectional batch_first GRU with hidden 128 on fp32 CUDA tensors, inference (no autograd graph)."""
-    needs_grad = torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in rnn.parameters()))
+    """The HIP recurrent kernels cover the configuration every shipped CTGCN config uses: single-layer
+    unidirectional batch_first GRU with hidden 128 on fp32 CUDA tensors (forward and backward)."""
     return (isinstance(rnn, torch.nn.GRU) and rnn.hidden_size == 128 and rnn.num_layers == 1 and not rnn.bidirectional
-            and rnn.batch_first and seq.is_cuda and seq.dtype == torch.float32 and not needs_grad)
+            and rnn.batch_first and seq.is_cuda and seq.dtype == torch.float32)
+
+
+def _gru_bias(rnn, hid):
+    if not rnn.bias:
+        return None, None
+    bias = rnn.bias_ih_l0.detach().clone()
+    bias[: 2 * hid] += rnn.bias_hh_l0.detach()[: 2 * hid]     # r and z gates: both biases are simply added
+    return bias, rnn.bias_hh_l0.detach()[2 * hid:].contiguous()   # n gate: b_hn stays inside r * (W_hn h + b_hn)
+
+
+def _row_chunks(lib, rows, steps, hid):
+    """Equal row chunks, multiples of the kernel's row granule (rows per block x CUs), bounded projection buffer."""
+    granule = int(lib.ctgcn_gru_row_granule())
+    max_rows = max(granule, (_GI_MAX_ELEMS // (steps * 4 * hid)) // granule * granule)
+    n_chunks = -(-rows // max_rows)
+    chunk = -(-(-(-rows // n_chunks)) // granule) * granule
+    return [(lo, min(chunk, rows - lo)) for lo in range(0, rows, chunk)]
+
+
+def _project(x2d, w_ih, bias, out):
+    if bias is None:
+        torch.mm(x2d, w_ih.t(), out=out)
+    else:
+        torch.addmm(bias, x2d, w_ih.t(), out=out)
+
+
+def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
+    lib = _lib.load()
+    rows, steps, d_in = seq.shape
+    hid = w_hh.shape[1]
+    out = torch.empty((rows, hid) if reduce_sum else (rows, steps, hid), dtype=torch.float32, device=seq.device)
+    if rows == 0:
+        return out
+    chunks = _row_chunks(lib, rows, steps, hid)
+    gi_buf = torch.empty(chunks[0][1] * steps, 3 * hid, dtype=torch.float32, device=seq.device)
+    with torch.cuda.device(seq.device):
+        for lo, n in chunks:
+            gi = gi_buf[: n * steps]
+            _project(seq[lo:lo + n].reshape(n * steps, d_in), w_ih, bias, gi)
+            with _timed("gru_seq", rows=n, steps=steps):
+                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
+                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), None, _stream()), "ctgcn_gru_seq_f32")
+    return out
+
+
+class _GruSeq(torch.autograd.Function):
+    """LayerNorm(sum_t GRU(seq)_t) or LayerNorm(GRU(seq)).  Forward = the fused inference kernels.  Backward
+    recomputes the raw h sequence and the gates chunk by chunk (so nothing but `seq` is kept alive between forward
+    and backward), runs the HIP backward recurrence and leaves the weight/input GEMMs to hipBLASLt."""
+
+    @staticmethod
+    def forward(ctx, seq, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b, eps, reduce_sum):
+        hid = w_hh.shape[1]
+        if b_ih is not None:
+            bias = b_ih.detach().clone()
+            bias[: 2 * hid] += b_hh.detach()[: 2 * hid]
+            b_hn = b_hh.detach()[2 * hid:].contiguous()
+        else:
+            bias, b_hn = None, None
+        seq_c = seq.contiguous()
+        out = _gru_forward(seq_c, w_ih.detach(), w_hh.detach().contiguous(), bias, b_hn, ln_w, ln_b, eps, reduce_sum)
+        ctx.save_for_backward(seq_c, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b)
+        ctx.eps, ctx.reduce_sum = eps, reduce_sum
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        seq, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b = ctx.saved_tensors
+        reduce_sum, eps = ctx.reduce_sum, ctx.eps
+        rows, steps, d_in = seq.shape
+        hid = w_hh.shape[1]
+        dev = seq.device
+        w_ih_d, w_hh_d = w_ih.detach(), w_hh.detach().contiguous()
+        if b_ih is not None:
+            bias = b_ih.detach().clone()
+            bias[: 2 * hid] += b_hh.detach()[: 2 * hid]
+            b_hn = b_hh.detach()[2 * hid:].contiguous()
+        else:
+            bias, b_hn = None, None
+        dout = dout.contiguous()
+        dseq = torch.empty_like(seq)
+        dw_ih = torch.zeros_like(w_ih_d)
+        dw_hh = torch.zeros_like(w_hh_d)
+        db_gi = torch.zeros(3 * hid, dtype=torch.float32, device=dev)
+        db_hn = torch.zeros(hid, dtype=torch.float32, device=dev)
+        dln_w = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
+        dln_b = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
+        chunks = _row_chunks(lib, rows, steps, hid)
+        cmax = chunks[0][1]
+        gi_buf = torch.empty(cmax * steps, 3 * hid, dtype=torch.float32, device=dev)       # reused as d_gi
+        gates_buf = torch.empty(cmax * steps, 4 * hid, dtype=torch.float32, device=dev)
+        hseq_buf = torch.empty(cmax, steps, hid, dtype=torch.float32, device=dev)
+        dghn_buf = torch.empty(cmax * steps, hid, dtype=torch.float32, device=dev)
+        hprev_buf = torch.zeros(cmax, steps, hid, dtype=torch.float32, device=dev)         # [:, 0] stays 0
+        with torch.cuda.device(dev):
+            for lo, n in chunks:
+                x2d = seq[lo:lo + n].reshape(n * steps, d_in)
+                gi, gates, hseq = gi_buf[: n * steps], gates_buf[: n * steps], hseq_buf[:n]
+                _project(x2d, w_ih_d, bias, gi)
+                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq),
+                                            ptr(gates), _stream()), "ctgcn_gru_seq_f32")
+                # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)
+                g_out = dout[lo:lo + n]
+                pre = hseq.sum(1) if reduce_sum else hseq
+                if ln_w is not None:
+                    with torch.enable_grad():
+                        p = pre.detach().requires_grad_(True)
+                        lw, lb = ln_w.detach().requires_grad_(True), ln_b.detach().requires_grad_(True)
+                        torch.nn.functional.layer_norm(p, (hid,), lw, lb, eps).backward(g_out)
+                    dpre = p.grad
+                    dln_w += lw.grad
+                    dln_b += lb.grad
+                else:
+                    dpre = g_out
+                dpre = dpre.contiguous()
+                dgi, dghn = gi, dghn_buf[: n * steps]                                       # gi is dead: reuse as d_gi
+                check(lib.ctgcn_gru_seq_bwd_f32(n, steps, hid, ptr(gates), ptr(hseq), None if reduce_sum else ptr(dpre),
+                                                ptr(dpre) if reduce_sum else None, ptr(w_hh_d), ptr(dgi), ptr(dghn), _stream()),
+                      "ctgcn_gru_seq_bwd_f32")
+                torch.mm(dgi, w_ih_d, out=dseq[lo:lo + n].view(n * steps, d_in))
+                dw_ih.addmm_(dgi.t(), x2d)
+                db_gi += dgi.sum(0)
+                db_hn += dghn.sum(0)
+                hprev = hprev_buf[:n]
+                hprev[:, 1:] = hseq[:, :-1]
+                hp2d = hprev.view(n * steps, hid)
+                dw_hh[: 2 * hid].addmm_(dgi[:, : 2 * hid].t(), hp2d)
+                dw_hh[2 * hid:].addmm_(dghn.t(), hp2d)
+        db_ih = db_hh = None
+        if b_ih is not None:
+            db_ih = db_gi
+            db_hh = torch.cat([db_gi[: 2 * hid], db_hn])
+        return dseq, dw_ih, dw_hh, db_ih, db_hh, dln_w, dln_b, None, None
 
 
 def gru_sequence(rnn, seq, norm, reduce_sum):
     """LayerNorm(sum_t GRU(seq)_t) (reduce_sum) or LayerNorm(GRU(seq)) — layers.py:59-62 / models.py:249-250.
-    seq [rows, steps, d_in].  The input projection is a hipBLASLt GEMM (torch.addmm); the recurrence, the sum over
-    steps and the LayerNorm run in ONE HIP kernel (ctgcn_gru_seq_f32).  Rows are processed in chunks that bound
-    the projection buffer."""
-    lib = _lib.load()
-    rows, steps, d_in = seq.shape
-    hid = rnn.hidden_size
-    w_ih, w_hh = rnn.weight_ih_l0, rnn.weight_hh_l0.contiguous()
-    if rnn.bias:
-        bias = rnn.bias_ih_l0.clone()
-        bias[: 2 * hid] += rnn.bias_hh_l0[: 2 * hid]        # r and z gates: both biases are simply added
-        b_hn = rnn.bias_hh_l0[2 * hid:].contiguous()        # n gate: stays inside r * (W_hn h + b_hn)
-    else:
-        bias, b_hn = None, None
-    seq = seq.contiguous()
-    out = torch.empty((rows, hid) if reduce_sum else (rows, steps, hid), dtype=torch.float32, device=seq.device)
-    if rows == 0:
-        return out
-    # chunk rows: bounded projection buffer, equal-sized chunks, each a multiple of the kernel's row granule
-    # (rows per block x CUs) so that no launch ends with a mostly idle round of blocks
-    granule = int(lib.ctgcn_gru_row_granule())
-    max_rows = max(granule, (_GI_MAX_ELEMS // (steps * 3 * hid)) // granule * granule)
-    n_chunks = -(-rows // max_rows)
-    chunk = -(-(-(-rows // n_chunks)) // granule) * granule
-    gi_buf = torch.empty(min(rows, chunk) * steps, 3 * hid, dtype=torch.float32, device=seq.device)
-    w_t = w_ih.t()
+    seq [rows, steps, d_in].  The input projection is a hipBLASLt GEMM; the recurrence, the sum over steps and the
+    LayerNorm run in ONE HIP kernel (ctgcn_gru_seq_f32); with autograd enabled the backward runs
+    ctgcn_gru_seq_bwd_f32 (see _GruSeq)."""
+    b_ih = rnn.bias_ih_l0 if rnn.bias else None
+    b_hh = rnn.bias_hh_l0 if rnn.bias else None
     ln_w = None if norm is None else norm.weight
     ln_b = None if norm is None else norm.bias
     eps = 0.0 if norm is None else float(norm.eps)
-    with torch.cuda.device(seq.device):
-        for lo in range(0, rows, chunk):
-            n = min(chunk, rows - lo)
-            gi = gi_buf[: n * steps]
-            x = seq[lo:lo + n].reshape(n * steps, d_in)
-            if bias is None:
-                torch.mm(x, w_t, out=gi)
-            else:
-                torch.addmm(bias, x, w_t, out=gi)
-            with _timed("gru_seq", rows=n, steps=steps):
-                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
-                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), _stream()), "ctgcn_gru_seq_f32")
-    return out
+    return _GruSeq.apply(seq, rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, ln_w, ln_b, eps, bool(reduce_sum))

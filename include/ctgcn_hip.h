@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 1
+#define CTGCN_ABI_VERSION 2
 
 enum {
     CTGCN_OK = 0,
@@ -150,10 +150,23 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  * gate order r,z,n — a plain GEMM the caller runs with its BLAS; w_hh [384,128] and b_hn [128] (the n-gate's
  * hidden bias, NULL = 0) are the module's weight_hh_l0 and bias_hh_l0[256:384].  ln_weight == NULL skips the
  * LayerNorm.  h_0 = 0.  Exact fp32 arithmetic (f32-input MFMA).
+ * gates_out (optional; requires reduce_sum == 0 and ln_weight == NULL): [rows, steps, 4, 128] receives r, z, n and
+ * q = W_hn·h_{t-1} + b_hn for ctgcn_gru_seq_bwd_f32.
  */
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, void *stream);
+                      int reduce_sum, float *out, float *gates_out, void *stream);
+
+/*
+ * Backward of the recurrence above (autograd of nn.GRU, layers.py:59 / models.py:249).  Inputs: the saved gates and
+ * the raw h sequence h_seq [rows, steps, 128]; the upstream gradient per step dh_seq [rows, steps, 128] and/or one
+ * gradient dh_sum [rows, 128] added at every step (the .sum(dim=1) case).  Outputs, for the caller's GEMMs:
+ *   d_gi  [rows, steps, 384] = dL/d(x·W_ih^T + b_ih)      -> dX = d_gi·W_ih, dW_ih = d_gi^T·x, db_ih = sum d_gi
+ *   d_ghn [rows, steps, 128] = dL/d(W_hn·h + b_hn)         -> dW_hh = [d_gi_r, d_gi_z, d_ghn]^T·h_{t-1}, db_hh likewise
+ */
+int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *h_seq,
+                          const float *dh_seq, const float *dh_sum, const float *w_hh, float *d_gi, float *d_ghn,
+                          void *stream);
 
 /* Rows one wave of persistent blocks covers (rows per block x compute units): callers that split `rows` into
  * chunks should use multiples of this so that every launch keeps all CUs equally busy. */

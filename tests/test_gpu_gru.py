@@ -57,10 +57,52 @@ def test_fused_gru_row_chunking_and_determinism():
     assert (a - b).abs().max().item() < 1e-5        # hipBLASLt may pick another GEMM kernel for another M
 
 
-def test_training_path_still_uses_autograd_modules():
-    """with gradients enabled the modules run (MIOpen); outputs agree with the fused inference path."""
-    import ctgcn_amd
+@pytest.mark.parametrize("rows,steps,d_in,reduce_sum,bias,use_norm", [
+    (70, 8, 128, True, True, True), (1000, 5, 40, True, True, True), (513, 6, 128, False, True, True),
+    (90, 3, 128, True, False, True), (33, 1, 16, True, True, True), (200, 4, 128, False, True, False),
+])
+def test_fused_gru_gradients_match_torch_autograd(rows, steps, d_in, reduce_sum, bias, use_norm):
+    """d/d{x, W_ih, W_hh, b_ih, b_hh, ln.weight, ln.bias} of sum(out * G) vs CPU nn.GRU autograd."""
+    import copy
     from ctgcn_amd import ops
+    torch.manual_seed(7 * rows + steps)
+    rnn = torch.nn.GRU(d_in, 128, 1, bias=bias, batch_first=True)
+    norm = torch.nn.LayerNorm(128) if use_norm else None
+    if norm is not None:
+        with torch.no_grad():
+            norm.weight.uniform_(0.5, 1.5)
+            norm.bias.uniform_(-0.5, 0.5)
+    x = (torch.relu(torch.randn(rows, steps, d_in)) * 1.5).requires_grad_(True)
+    out = rnn(x)[0]
+    out = out.sum(1) if reduce_sum else out
+    out = norm(out) if norm is not None else out
+    G = torch.randn_like(out)
+    (out * G).sum().backward()
+
+    rnn_d, norm_d = copy.deepcopy(rnn).to(DEV), (copy.deepcopy(norm).to(DEV) if norm is not None else None)
+    for p in list(rnn_d.parameters()) + (list(norm_d.parameters()) if norm_d is not None else []):
+        p.grad = None
+    xd = x.detach().to(DEV).requires_grad_(True)
+    got = ops.gru_sequence(rnn_d, xd, norm_d, reduce_sum)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), out.detach().numpy(), rtol=1e-4, atol=2e-5)
+    (got * G.to(DEV)).sum().backward()
+
+    def close(a, b, name):
+        a, b = a.cpu().numpy(), b.numpy()
+        scale = max(1e-6, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 2e-4 * scale, (name, np.abs(a - b).max(), scale)
+
+    close(xd.grad, x.grad, "dx")
+    for (name, pd), (_, pc) in zip(rnn_d.named_parameters(), rnn.named_parameters()):
+        close(pd.grad, pc.grad, name)
+    if norm is not None:
+        close(norm_d.weight.grad, norm.weight.grad, "ln.weight")
+        close(norm_d.bias.grad, norm.bias.grad, "ln.bias")
+
+
+def test_training_and_inference_paths_agree():
+    """with gradients enabled the same fused forward runs (plus a HIP backward); outputs are identical."""
+    import ctgcn_amd
     torch.manual_seed(1)
     layer = ctgcn_amd.CoreDiffusion(128, 128).to(DEV)
     import scipy.sparse as sp
@@ -70,6 +112,8 @@ def test_training_path_still_uses_autograd_modules():
     x = torch.randn(500, 128, device=DEV, requires_grad=True)
     y_train = layer(x, adj)
     assert y_train.requires_grad
+    y_train.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
     with torch.no_grad():
         y_inf = layer(x, adj)
-    np.testing.assert_allclose(y_inf.cpu().numpy(), y_train.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
+    assert torch.equal(y_inf, y_train.detach())

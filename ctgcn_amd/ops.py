@@ -258,6 +258,21 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
     return out
 
 
+def _accumulate_tn(out, a2d, b2d):
+    """out[M,N] += a2d[R,M]^T @ b2d[R,N] for R >> M,N (weight gradients: R = rows*steps).  A plain TN GEMM with a
+    384x128 output only fills a few dozen workgroups; splitting R into S batches (strided batched GEMM, no copies)
+    and summing the S partial products keeps all CUs busy."""
+    R, M = a2d.shape
+    S = 1
+    while S < 256 and R % (2 * S) == 0 and R // (2 * S) >= 1024:
+        S *= 2
+    if S == 1:
+        out.addmm_(a2d.t(), b2d)
+        return
+    part = torch.bmm(a2d.view(S, R // S, M).transpose(1, 2), b2d.view(S, R // S, b2d.shape[1]))
+    out += part.sum(0)
+
+
 class _GruSeq(torch.autograd.Function):
     """LayerNorm(sum_t GRU(seq)_t) or LayerNorm(GRU(seq)).  Forward = the fused inference kernels.  Backward
     recomputes the raw h sequence and the gates chunk by chunk (so nothing but `seq` is kept alive between forward
@@ -334,14 +349,14 @@ class _GruSeq(torch.autograd.Function):
                                                 ptr(dpre) if reduce_sum else None, ptr(w_hh_d), ptr(dgi), ptr(dghn), _stream()),
                       "ctgcn_gru_seq_bwd_f32")
                 torch.mm(dgi, w_ih_d, out=dseq[lo:lo + n].view(n * steps, d_in))
-                dw_ih.addmm_(dgi.t(), x2d)
+                _accumulate_tn(dw_ih, dgi, x2d)
                 db_gi += dgi.sum(0)
                 db_hn += dghn.sum(0)
                 hprev = hprev_buf[:n]
                 hprev[:, 1:] = hseq[:, :-1]
                 hp2d = hprev.view(n * steps, hid)
-                dw_hh[: 2 * hid].addmm_(dgi[:, : 2 * hid].t(), hp2d)
-                dw_hh[2 * hid:].addmm_(dghn.t(), hp2d)
+                _accumulate_tn(dw_hh[: 2 * hid], dgi[:, : 2 * hid], hp2d)
+                _accumulate_tn(dw_hh[2 * hid:], dghn, hp2d)
         db_ih = db_hh = None
         if b_ih is not None:
             db_ih = db_gi

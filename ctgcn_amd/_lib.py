@@ -24,9 +24,9 @@ SIGNATURES = {
     "ctgcn_last_error": (_c.c_char_p, []),
     "ctgcn_device_info": (_int, [_c.c_char_p, _sz, _c.POINTER(_int)]),
     "ctgcn_spmm_csr_f32": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp]),
-    "ctgcn_core_aggregate_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _u32, _vp]),
+    "ctgcn_core_aggregate_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _u32, _vp, _i32, _i32, _vp]),
     "ctgcn_core_aggregate_bwd_prep_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
-    "ctgcn_core_aggregate_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u32, _vp]),
+    "ctgcn_core_aggregate_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u32, _vp, _i32, _i32, _vp]),
     "ctgcn_edges_to_csr": (_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i64), _vp, _sz, _vp]),
     "ctgcn_kcore_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_i32), _vp]),
     "ctgcn_edge_levels_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

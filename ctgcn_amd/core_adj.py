@@ -28,6 +28,8 @@ class CoreAdj(object):
     COO tensors equal to the reference's (built lazily, for interop only — the models never use them).
     """
 
+    LONG_ROW = 2048     # rows with more stored entries than this are "hubs": one block per row instead of one lane group
+
     def __init__(self, n, K, row_ptr, col, val, slot, self_loop, nested, symmetric, nnz_per_slot, levels=None):
         self.n, self.K = int(n), int(K)
         self.row_ptr, self.col, self.val, self.slot = row_ptr, col, val, slot
@@ -35,6 +37,7 @@ class CoreAdj(object):
         self.nnz_per_slot = [int(v) for v in nnz_per_slot]      # reference-semantics nnz(A_j), incl. the +I of slot 0
         self.levels = None if levels is None else [int(v) for v in levels]   # k value of each slot (k-core route)
         self._t = None                                           # transposed arrays, built on demand when not symmetric
+        self._long = {}                                          # cached hub-row lists (forward / transposed)
         assert 0 <= self.K <= _lib.MAX_SLOTS
 
     # ------------------------------------------------------------------ list-like surface
@@ -76,6 +79,15 @@ class CoreAdj(object):
 
     def cpu(self):
         return self.to("cpu")
+
+    def long_rows(self, transposed=False):
+        """int32 device tensor of the rows with more than LONG_ROW entries (None if there are none)."""
+        key = bool(transposed) and not self.symmetric
+        if key not in self._long:
+            rp = self.transposed()[0] if key else self.row_ptr
+            idx = torch.nonzero((rp[1:] - rp[:-1]) > self.LONG_ROW).flatten().to(torch.int32)
+            self._long[key] = idx if idx.numel() else None
+        return self._long[key]
 
     # ------------------------------------------------------------------ transposed view (backward pass)
     def transposed(self):

@@ -81,6 +81,10 @@ struct AggArgs {
     int32_t accumulate;
     int32_t chunks;        // ceil(d / VEC)
     int32_t passes;        // ceil(chunks / LPR)
+    const int32_t *long_rows;   // rows longer than long_thresh: skipped by the row-per-group kernels, one block each
+    int32_t n_long;
+    int32_t long_thresh;
+    int32_t hub_groups;    // lane groups of the hub block that share one long row
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256) void agg_fwd_kernel(const AggArgs a)
     const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
     if (row >= a.n) return;
     const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    if (end - start > a.long_thresh) return;          // hub row: agg_fwd_hub_kernel
     const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0;
     const bool relu = (a.flags & CTGCN_F_RELU) != 0;
     const bool nested = (a.flags & CTGCN_F_NESTED) != 0;
@@ -175,6 +180,7 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const AggArgs a)
     const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
     if (row >= a.n) return;
     const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    if (end - start > a.long_thresh) return;          // hub row: agg_bwd_hub_kernel
     const uint8_t *__restrict__ slot = a.slot;
     const float *__restrict__ Z = a.src;
     const int64_t zrow = (int64_t)a.K * a.d;
@@ -218,6 +224,169 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const AggArgs a)
             if (a.accumulate) P += *o;
             *o = P;
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Hub rows (longer than long_thresh entries): one 1024-thread block per row.  The row's entry range is cut into
+// `hub_groups` contiguous segments, one per lane group; every group accumulates per-slot partial sums of ITS segment
+// into LDS, group 0 then adds the partials in group order (deterministic) and runs the same R/P recurrence.
+// ------------------------------------------------------------------------------------------------
+constexpr int HUB_THREADS = 1024;
+
+template <int VEC, int LPR, int U>
+__global__ __launch_bounds__(HUB_THREADS) void agg_fwd_hub_kernel(const AggArgs a)
+{
+    using V = typename vec_of<VEC>::type;
+    extern __shared__ __align__(16) unsigned char hub_smem[];
+    V *part = reinterpret_cast<V *>(hub_smem);            // [G][K][LPR]
+    const int lig = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR, G = a.hub_groups;
+    const int64_t row = a.long_rows[blockIdx.x];
+    const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    const int seg = ((end - start + G - 1) / G + LPR - 1) / LPR * LPR;
+    const int my_s = min(end, start + grp * seg), my_e = min(end, my_s + seg);
+    const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0, relu = (a.flags & CTGCN_F_RELU) != 0;
+    const bool nested = (a.flags & CTGCN_F_NESTED) != 0;
+    const uint8_t *__restrict__ slot = a.slot;
+    const float *__restrict__ X = a.src;
+    float *__restrict__ outrow = a.out + row * a.out_ld;
+
+    for (int pass = 0; pass < a.passes; ++pass) {
+        const int ch = pass * LPR + lig;
+        const bool live = ch < a.chunks;
+        const int64_t foff = live ? (int64_t)ch * VEC : 0;
+        if (grp < G) {
+            for (int k = 0; k < a.K; ++k) part[((int64_t)grp * a.K + k) * LPR + lig] = vzero<VEC>();
+            V P = vzero<VEC>();
+            int cur = -1;
+            for (int base = my_s; base < my_e; base += LPR) {
+                const int my = base + lig;
+                int c = 0, s = 0;
+                float w = 0.f;
+                if (my < my_e) { c = a.col[my]; w = a.val[my]; s = slot ? (int)slot[my] : 0; }
+                const int cnt = min(LPR, my_e - base);
+                int j = 0;
+                for (; j + U <= cnt; j += U) {
+                    V xv[U];
+                    float wj[U];
+                    int sj[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int cj = __shfl(c, j + u, LPR);
+                        wj[u] = __shfl(w, j + u, LPR);
+                        sj[u] = __shfl(s, j + u, LPR);
+                        xv[u] = *(const V *)(X + (int64_t)cj * a.ldsrc + foff);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (sj[u] != cur) {
+                            if (cur >= 0) part[((int64_t)grp * a.K + cur) * LPR + lig] = P;
+                            P = vzero<VEC>();
+                            cur = sj[u];
+                        }
+                        P = vfma(wj[u], xv[u], P);
+                    }
+                }
+                for (; j < cnt; ++j) {
+                    const int cj = __shfl(c, j, LPR);
+                    const float w1 = __shfl(w, j, LPR);
+                    const int s1 = __shfl(s, j, LPR);
+                    const V x1 = *(const V *)(X + (int64_t)cj * a.ldsrc + foff);
+                    if (s1 != cur) {
+                        if (cur >= 0) part[((int64_t)grp * a.K + cur) * LPR + lig] = P;
+                        P = vzero<VEC>();
+                        cur = s1;
+                    }
+                    P = vfma(w1, x1, P);
+                }
+            }
+            if (cur >= 0) part[((int64_t)grp * a.K + cur) * LPR + lig] = P;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            V R = vzero<VEC>(), Pc = vzero<VEC>();
+            if (self) R = *(const V *)(X + row * a.ldsrc + foff);
+            for (int k = 0; k < a.K; ++k) {
+                V sk = vzero<VEC>();
+                for (int g = 0; g < G; ++g) sk += part[((int64_t)g * a.K + k) * LPR + lig];
+                Pc = nested ? Pc + sk : sk;
+                R += Pc;
+                V v = relu ? vmax0(R) : R;
+                if (live) {
+                    V *o = (V *)(outrow + (int64_t)k * a.d + foff);
+                    if (a.accumulate) v += *o;
+                    *o = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int VEC, int LPR, int U>
+__global__ __launch_bounds__(HUB_THREADS) void agg_bwd_hub_kernel(const AggArgs a)
+{
+    using V = typename vec_of<VEC>::type;
+    extern __shared__ __align__(16) unsigned char hub_smem[];
+    V *part = reinterpret_cast<V *>(hub_smem);            // [G][LPR]
+    const int lig = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR, G = a.hub_groups;
+    const int64_t row = a.long_rows[blockIdx.x];
+    const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    const int seg = ((end - start + G - 1) / G + LPR - 1) / LPR * LPR;
+    const int my_s = min(end, start + grp * seg), my_e = min(end, my_s + seg);
+    const uint8_t *__restrict__ slot = a.slot;
+    const float *__restrict__ Z = a.src;
+    const int64_t zrow = (int64_t)a.K * a.d;
+
+    for (int pass = 0; pass < a.passes; ++pass) {
+        const int ch = pass * LPR + lig;
+        const bool live = ch < a.chunks;
+        const int64_t foff = live ? (int64_t)ch * VEC : 0;
+        if (grp < G) {
+            V P = vzero<VEC>();
+            for (int base = my_s; base < my_e; base += LPR) {
+                const int my = base + lig;
+                int64_t off = 0;
+                float w = 0.f;
+                if (my < my_e) {
+                    off = (int64_t)a.col[my] * zrow + (slot ? (int64_t)slot[my] * a.d : 0);
+                    w = a.val[my];
+                }
+                const int cnt = min(LPR, my_e - base);
+                int j = 0;
+                for (; j + U <= cnt; j += U) {
+                    V xv[U];
+                    float wj[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int64_t oj = __shfl(off, j + u, LPR);
+                        wj[u] = __shfl(w, j + u, LPR);
+                        xv[u] = *(const V *)(Z + oj + foff);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) P = vfma(wj[u], xv[u], P);
+                }
+                for (; j < cnt; ++j) {
+                    const int64_t oj = __shfl(off, j, LPR);
+                    const float w1 = __shfl(w, j, LPR);
+                    P = vfma(w1, *(const V *)(Z + oj + foff), P);
+                }
+            }
+            part[(int64_t)grp * LPR + lig] = P;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            V P = vzero<VEC>();
+            if (a.self) P = *(const V *)(a.self + row * (int64_t)a.d + foff);
+            for (int g = 0; g < G; ++g) P += part[(int64_t)g * LPR + lig];
+            if (live) {
+                V *o = (V *)(a.out + row * a.out_ld + foff);
+                if (a.accumulate) P += *o;
+                *o = P;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -270,8 +439,10 @@ AggPlan plan_for(int d, bool vec4_ok)
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+constexpr size_t HUB_LDS_BUDGET = 144 * 1024;
+
 template <bool FWD, int VEC, int LPR>
-void launch_agg_t(const AggArgs &a, hipStream_t st)
+void launch_agg_t(AggArgs a, hipStream_t st)
 {
     constexpr int U = 4;
     const int rows_per_block = 256 / LPR;
@@ -280,6 +451,21 @@ void launch_agg_t(const AggArgs &a, hipStream_t st)
         hipLaunchKernelGGL((agg_fwd_kernel<VEC, LPR, U>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((agg_bwd_kernel<VEC, LPR, U>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    if (a.n_long > 0) {
+        const size_t per_group = (size_t)(FWD ? a.K : 1) * LPR * sizeof(typename vec_of<VEC>::type);
+        int G = HUB_THREADS / LPR;
+        while (G > 1 && per_group * G > HUB_LDS_BUDGET) --G;
+        a.hub_groups = G;
+        const size_t lds = per_group * G;
+        if (FWD) {
+            auto k = agg_fwd_hub_kernel<VEC, LPR, U>;
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3((unsigned)a.n_long), dim3(HUB_THREADS), lds, st, a);
+        } else {
+            auto k = agg_bwd_hub_kernel<VEC, LPR, U>;
+            hipLaunchKernelGGL(k, dim3((unsigned)a.n_long), dim3(HUB_THREADS), lds, st, a);
+        }
+    }
 }
 
 template <bool FWD>
@@ -289,6 +475,8 @@ int launch_agg(AggArgs a, bool vec4_ok, hipStream_t st)
     a.chunks = p.chunks;
     a.passes = p.passes;
     if (a.n == 0) return CTGCN_OK;
+    if (a.n_long <= 0 || !a.long_rows) { a.n_long = 0; a.long_thresh = 0x7fffffff; }
+    if (a.n_long > 0 && (size_t)a.K * p.lpr * (p.vec * 4) > HUB_LDS_BUDGET) { a.n_long = 0; a.long_thresh = 0x7fffffff; }   // K*d too large for the LDS partials: rows stay on the normal path
     const int64_t rows_per_block = 256 / p.lpr;
     if ((a.n + rows_per_block - 1) / rows_per_block > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "grid too large");
 #define CASE(V, L) if (p.vec == V && p.lpr == L) { launch_agg_t<FWD, V, L>(a, st); }
@@ -844,7 +1032,8 @@ int ctgcn_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *row_ptr, const 
 
 int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
                              const int32_t *col_idx, const float *val, const uint8_t *slot,
-                             const float *X, int64_t ldx, float *H, uint32_t flags, void *stream)
+                             const float *X, int64_t ldx, float *H, uint32_t flags,
+                             const int32_t *long_rows, int32_t n_long, int32_t long_threshold, void *stream)
 {
     if (n_rows < 0 || d <= 0 || ldx < d) return fail(CTGCN_E_INVALID, "core_aggregate: bad sizes n=%lld d=%d ldx=%lld", (long long)n_rows, d, (long long)ldx);
     if (K < 1 || K > CTGCN_MAX_SLOTS) return fail(CTGCN_E_INVALID, "core_aggregate: K=%d outside [1,%d]", K, CTGCN_MAX_SLOTS);
@@ -856,6 +1045,8 @@ int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t
     a.row_ptr = row_ptr; a.col = col_idx; a.val = val; a.slot = slot;
     a.src = X; a.ldsrc = ldx; a.self = nullptr; a.out = H; a.out_ld = (int64_t)K * d;
     a.flags = flags; a.accumulate = 0;
+    a.long_rows = long_rows; a.n_long = n_long; a.long_thresh = long_threshold;
+    if (n_long > 0 && long_threshold < 1) return fail(CTGCN_E_INVALID, "core_aggregate: long_threshold must be >= 1");
     const bool v4 = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(X) && aligned16(H);
     return launch_agg<true>(a, v4, (hipStream_t)stream);
 }
@@ -883,7 +1074,8 @@ int ctgcn_core_aggregate_bwd_prep_f32(int64_t n_rows, int32_t d, int32_t K, cons
 int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
                                  const int32_t *col_idx, const float *val, const uint8_t *slot,
                                  const float *Z, const float *S0, float *dX, int64_t lddx,
-                                 uint32_t flags, void *stream)
+                                 uint32_t flags, const int32_t *long_rows, int32_t n_long,
+                                 int32_t long_threshold, void *stream)
 {
     if (n_rows < 0 || d <= 0 || lddx < d || K < 1 || K > CTGCN_MAX_SLOTS) return fail(CTGCN_E_INVALID, "core_aggregate_bwd: bad sizes");
     if (n_rows == 0) return CTGCN_OK;
@@ -895,6 +1087,8 @@ int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int
     a.row_ptr = row_ptr; a.col = col_idx; a.val = val; a.slot = slot;
     a.src = Z; a.ldsrc = 0; a.self = (flags & CTGCN_F_SELF_LOOP) ? S0 : nullptr;
     a.out = dX; a.out_ld = lddx; a.flags = flags; a.accumulate = 0;
+    a.long_rows = long_rows; a.n_long = n_long; a.long_thresh = long_threshold;
+    if (n_long > 0 && long_threshold < 1) return fail(CTGCN_E_INVALID, "core_aggregate_bwd: long_threshold must be >= 1");
     const bool v4 = (d % 4 == 0) && (lddx % 4 == 0) && aligned16(Z) && aligned16(dX) && (!a.self || aligned16(a.self));
     return launch_agg<false>(a, v4, (hipStream_t)stream);
 }

@@ -153,8 +153,10 @@ def _aggregate_fwd(adj, x, relu):
     H = torch.empty(n, adj.K, d, dtype=torch.float32, device=x.device)
     flags = adj.flags | (_lib.F_RELU if relu else 0)
     with torch.cuda.device(x.device), _timed("agg_fwd", n=n, d=d, K=adj.K, nnz=adj.nnz):
+        long_rows = adj.long_rows()
         check(lib.ctgcn_core_aggregate_f32(n, d, adj.K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x),
-                                           x.stride(0), ptr(H), flags, _stream()), "ctgcn_core_aggregate_f32")
+                                           x.stride(0), ptr(H), flags, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
+                                           adj.LONG_ROW, _stream()), "ctgcn_core_aggregate_f32")
     return H
 
 
@@ -166,11 +168,13 @@ def _aggregate_bwd(adj, H, dH, relu):
     S0 = torch.empty(n, d, dtype=torch.float32, device=dH.device) if adj.self_loop else None
     dX = torch.empty(n, d, dtype=torch.float32, device=dH.device)
     t_ptr, t_col, t_val, t_slot = adj.transposed()
+    long_rows = adj.long_rows(transposed=True)
     with torch.cuda.device(dH.device):
         check(lib.ctgcn_core_aggregate_bwd_prep_f32(n, d, K, ptr(dH), ptr(H), ptr(Z), ptr(S0), flags, _stream()),
               "ctgcn_core_aggregate_bwd_prep_f32")
         check(lib.ctgcn_core_aggregate_bwd_f32(n, d, K, ptr(t_ptr), ptr(t_col), ptr(t_val), ptr(t_slot), ptr(Z), ptr(S0),
-                                               ptr(dX), d, flags, _stream()), "ctgcn_core_aggregate_bwd_f32")
+                                               ptr(dX), d, flags, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
+                                               adj.LONG_ROW, _stream()), "ctgcn_core_aggregate_bwd_f32")
     return dX
 
 

@@ -75,10 +75,14 @@ int ctgcn_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *row_ptr, const 
  * (row, slot, col):  NESTED: entry tagged s is present in A_s, A_{s+1}, ..., A_{K-1};
  * otherwise it is present in A_s only.  H is [n_rows, K, d] contiguous (the [batch, core, feat]
  * layout nn.GRU(batch_first=True) consumes at layers.py:59).   1 <= K <= CTGCN_MAX_SLOTS.
+ * long_rows (optional, device int32[n_long]): the rows with more than long_threshold entries (hubs).  They are
+ * skipped by the row-per-lane-group kernel and processed one 256-thread block each, so that a 100k-entry row does
+ * not serialise on 32 lanes.  n_long == 0 disables the split.
  */
 int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
                              const int32_t *col_idx, const float *val, const uint8_t *slot,
-                             const float *X, int64_t ldx, float *H, uint32_t flags, void *stream);
+                             const float *X, int64_t ldx, float *H, uint32_t flags,
+                             const int32_t *long_rows, int32_t n_long, int32_t long_threshold, void *stream);
 
 /*
  * Backward of ctgcn_core_aggregate_f32 w.r.t. X (what autograd derives for layers.py:41-48).
@@ -95,7 +99,8 @@ int ctgcn_core_aggregate_bwd_prep_f32(int64_t n_rows, int32_t d, int32_t K, cons
 int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
                                  const int32_t *col_idx, const float *val, const uint8_t *slot,
                                  const float *Z, const float *S0, float *dX, int64_t lddx,
-                                 uint32_t flags, void *stream);
+                                 uint32_t flags, const int32_t *long_rows, int32_t n_long,
+                                 int32_t long_threshold, void *stream);
 
 /*
  * Edge rows (in file order) -> the snapshot's simple undirected weighted graph as symmetric, zero-diagonal CSR

@@ -204,7 +204,7 @@ def test_abi_rejects_bad_arguments():
     import ctypes
     lib = _lib.load()
     x = torch.zeros(4, 4, device=_dev())
-    rc = lib.ctgcn_core_aggregate_f32(4, 4, 0, None, None, None, None, x.data_ptr(), 4, x.data_ptr(), 0, None)
+    rc = lib.ctgcn_core_aggregate_f32(4, 4, 0, None, None, None, None, x.data_ptr(), 4, x.data_ptr(), 0, None, 0, 0, None)
     assert rc == -1 and b"K=0" in lib.ctgcn_last_error()
     rc = lib.ctgcn_kcore_i32(4, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, None, None)
     assert rc == -3
@@ -283,3 +283,47 @@ def test_edges_to_csr_edge_cases_and_scale():
     n = 46341                                                                                  # n*n just above 2^31
     src, dst = rng.integers(n - 50, n, 5000), rng.integers(n - 50, n, 5000)
     _ingest_case(src, dst, rng.integers(1, 9, 5000).astype(np.float64), n)
+
+
+# ----------------------------------------------------------------------------------- hub rows
+@pytest.mark.parametrize("d,long_row", [(128, 8), (500, 16), (12, 4), (128, 2048)])
+def test_hub_rows_take_the_block_per_row_path(d, long_row):
+    """rows longer than CoreAdj.LONG_ROW go through agg_*_hub_kernel; lowering the threshold pushes most rows there."""
+    from ctgcn_amd import CoreAdj
+    from ctgcn_amd.utils import symmetric_csr_from_rows
+    from oracle import oracle as O
+    n = 6000
+    rng = np.random.default_rng(d)
+    hub_nbrs = rng.choice(np.arange(1, n), 4500, replace=False)
+    src = np.concatenate([np.zeros(4500, np.int64), rng.integers(1, n, 30000)])
+    dst = np.concatenate([hub_nbrs, rng.integers(1, n, 30000)])
+    csr = symmetric_csr_from_rows(src, dst, rng.integers(1, 5, len(src)) * 0.5, n)
+    kept = O.core_adj_list([O.kcore_matrices(csr)], 0, 1, 1, max_core=6)[0]
+    old = CoreAdj.LONG_ROW
+    try:
+        CoreAdj.LONG_ROW = long_row
+        adj = _agg_case(kept, d, seed=long_row)
+        assert adj.long_rows() is not None and adj.long_rows().numel() >= 1
+        if long_row < 100:
+            assert adj.long_rows().numel() > 100
+    finally:
+        CoreAdj.LONG_ROW = old
+
+
+def test_hub_rows_general_lists():
+    from ctgcn_amd import CoreAdj
+    rng = np.random.default_rng(1)
+    n = 500
+    mats = []
+    for j in range(5):
+        m = sp.random(n, n, density=0.05, random_state=j, format="lil", dtype=np.float32)
+        m[3, :] = rng.standard_normal(n)            # a dense (asymmetric) hub row in every matrix
+        mats.append(m.tocsr())
+    old = CoreAdj.LONG_ROW
+    try:
+        CoreAdj.LONG_ROW = 64
+        adj = _agg_case(mats, 40, seed=9, self_loop=False)
+        assert not adj.nested and adj.long_rows().numel() >= 1
+        assert adj.long_rows(transposed=True) is None or adj.long_rows(transposed=True).numel() >= 0
+    finally:
+        CoreAdj.LONG_ROW = old

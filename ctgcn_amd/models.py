@@ -55,6 +55,7 @@ class CGCN(nn.Module):
         mlp_out, cdn_in = _branch_dims(model_type, hidden_dim, output_dim)
         self.mlp = MLP(input_dim, hidden_dim, mlp_out, trans_num, bias=bias, activate_type=trans_activate_type)
         self.duffision = CDN(cdn_in, output_dim, output_dim, diffusion_num, rnn_type=rnn_type)
+        self.process_group = None      # set by snapshot_parallel.shard_cgcn()
 
     def cgcn(self, x, adj):
         trans = self.mlp(x)
@@ -64,6 +65,8 @@ class CGCN(nn.Module):
     def forward(self, x, adj):
         if not isinstance(x, list):
             return self.cgcn(x, adj)
+        if self.process_group is not None:
+            return sp_par.cgcn_forward_sharded(self, x, adj)
         results = [self.cgcn(x_t, adj_t) for x_t, adj_t in zip(x, adj)]
         if self.model_type == 'C':
             return results

@@ -194,3 +194,37 @@ def ctgcn_forward_sharded(model, x_list, adj_list):
     if model.model_type == 'C':
         return out
     return out, [trans_local.get(t) for t in range(plan.T)]
+
+
+# ------------------------------------------------------------------------------------------- CGCN (static model)
+def shard_cgcn(model, num_snapshots, costs=None, assignment=None, group=None):
+    """CGCN shares ONE set of weights across snapshots (reference models.py:158-163), so the window is plain
+    data parallelism: every rank keeps a full replica, embeds only its snapshots, and weight gradients are summed
+    with allreduce_grads() after backward.  No exchange step is needed in the forward.  Returns the assignment."""
+    group = group if group is not None else dist.group.WORLD
+    world = dist.get_world_size(group)
+    if assignment is None:
+        assignment = plan_assignment([1.0] * num_snapshots if costs is None else costs, world)
+    model.process_group, model.shard_assignment = group, [list(a) for a in assignment]
+    for p in model.parameters():                       # replicas must start identical
+        dist.broadcast(p.data, src=dist.get_global_rank(group, 0) if group is not dist.group.WORLD else 0, group=group)
+    return model.shard_assignment
+
+
+def cgcn_forward_sharded(model, x_list, adj_list):
+    """Embeds the snapshots this rank owns; entries of other snapshots are None in the returned list(s)."""
+    rank = dist.get_rank(model.process_group)
+    mine = set(model.shard_assignment[rank])
+    emb, trans = [None] * len(x_list), [None] * len(x_list)
+    for t in sorted(mine):
+        res = model.cgcn(x_list[t], adj_list[t])
+        emb[t], trans[t] = (res if model.model_type == 'S' else (res, None))
+    return emb if model.model_type == 'C' else (emb, trans)
+
+
+def allreduce_grads(model):
+    """Sum every parameter gradient over the ranks (data-parallel CGCN)."""
+    for p in model.parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        dist.all_reduce(p.grad, group=model.process_group)

@@ -86,6 +86,17 @@ def ctgcn_with_grad(sd, x_list, adj_list, rnn_type="GRU", model_type="C", activa
         _rnn = saved
 
 
+def cgcn_with_grad(sd, x, adj, rnn_type="GRU", model_type="C", activate="L"):
+    """cgcn() with every recurrence unrolled in torch ops: differentiable w.r.t. the tensors of `sd`."""
+    global _rnn
+    saved = _rnn
+    _rnn = _rnn_grad
+    try:
+        return cgcn(sd, x, adj, rnn_type, model_type, activate)
+    finally:
+        _rnn = saved
+
+
 def core_diffusion(sd, prefix, x, adj_list, rnn_type="GRU"):
     """layers.py:38-63."""
     hs = aggregate_loop(adj_list, x)

@@ -77,3 +77,41 @@ def run(rank, world, port, T, n, exchange, results):
         results[rank] = (err_fwd, err_bwd, err_full, plan.assignment)
     finally:
         dist.destroy_process_group()
+
+
+def run_cgcn(rank, world, port, T, n, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctgcn_amd
+        from ctgcn_amd import CoreAdj, ops, snapshot_parallel as spp
+        from ctgcn_amd.synth import dynamic_graph
+        from oracle import oracle as O, torch_path as TP
+        from conftest import formula_tensor
+        ops.core_aggregate = _oracle_aggregate
+        graphs = dynamic_graph(n, 6, T, seed=5)
+        lists = [O.core_adj_list([O.kcore_matrices(g)], 0, 1, 1, max_core=3)[0] for g in graphs]
+        torch.manual_seed(100 + rank)                       # replicas start DIFFERENT: shard_cgcn must broadcast rank 0's
+        model = ctgcn_amd.CGCN(10, 12, 8, 2, 2, rnn_type="GRU", model_type="C", trans_activate_type="N")
+        assignment = spp.shard_cgcn(model, T, costs=[g.nnz for g in graphs])
+        x_all = [torch.from_numpy(a) for a in formula_tensor((T, n, 10), 0.21, 0.4)]
+        gsel = torch.from_numpy(formula_tensor((T, n, 8), 0.37, 1.1))
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        ref = TP.cgcn_with_grad(sd, x_all, [[TP.coo_like_reference(m) for m in l] for l in lists], "GRU", "C", "N")
+        sum((r * gsel[t]).sum() for t, r in enumerate(ref)).backward()
+        mine = assignment[rank]
+        adj = [CoreAdj.from_matrices(lists[t]) if t in mine else None for t in range(T)]
+        out = model([x_all[t] if t in mine else None for t in range(T)], adj)
+        err_fwd = max((out[t] - ref[t]).abs().max().item() for t in mine)
+        assert all(out[t] is None for t in range(T) if t not in mine)
+        sum((out[t] * gsel[t]).sum() for t in mine).backward()
+        spp.allreduce_grads(model)
+        err_bwd = 0.0
+        for name, p in model.named_parameters():
+            g = sd[name].grad
+            if g is None:
+                continue
+            err_bwd = max(err_bwd, (p.grad - g).abs().max().item() / (1e-6 + g.abs().max().item()))
+        results[rank] = (err_fwd, err_bwd, assignment)
+    finally:
+        dist.destroy_process_group()

@@ -39,3 +39,14 @@ def test_sharded_ctgcn_matches_unsharded(exchange, T, n):
         err_fwd, err_bwd, err_full, assignment = results[rank]
         assert err_fwd < 1e-5 and err_full < 1e-5, (rank, err_fwd, err_full)
         assert err_bwd < 1e-4, (rank, err_bwd)
+
+
+def test_sharded_cgcn_is_data_parallel():
+    from _dist_worker import run_cgcn
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(run_cgcn, args=(2, _free_port(), 5, 200, results), nprocs=2, join=True)
+    for rank in range(2):
+        err_fwd, err_bwd, assignment = results[rank]
+        assert err_fwd < 1e-5 and err_bwd < 1e-4, (rank, err_fwd, err_bwd)
+        assert sorted(sum(assignment, [])) == list(range(5))

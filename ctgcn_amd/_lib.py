@@ -31,8 +31,9 @@ SIGNATURES = {
     "ctgcn_kcore_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_i32), _vp]),
     "ctgcn_edge_levels_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp, _vp]),
+    "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp, _int, _vp]),
     "ctgcn_gru_seq_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctgcn_gru_input_proj_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_row_granule": (_i64, []),
     "ctgcn_workspace_bytes": (_sz, [_int, _i64, _i64, _i32, _i32]),
 }

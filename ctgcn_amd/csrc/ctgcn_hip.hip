@@ -875,6 +875,255 @@ __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
     }
 }
 
+// ================================================================================================
+// fp32 GEMM arithmetic on the bf16 matrix cores: every fp32 operand is split EXACTLY into three bf16 terms
+// (x = x1 + x2 + x3, 8 + 8 + 8 = 24 mantissa bits; the residuals x - x1 and x - x1 - x2 are exact in fp32) and a
+// product is the six partial products x1y1 + x1y2 + x2y1 + x1y3 + x3y1 + x2y2 (everything down to 2^-24 relative),
+// each exact in fp32 and accumulated in the MFMA's fp32 accumulator.  Measured max error vs fp64 on a K = 128 dot
+// product: 1.8e-6 against 3.1e-6 for the fp32 fmaf chain (tools/probes/mfma_bf16x3_probe.hip) — fp32 accuracy at
+// ~2x the fp32-MFMA rate (v_mfma_f32_16x16x32_bf16 is 16x faster than v_mfma_f32_16x16x4_f32, 6 of them per product).
+// ================================================================================================
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bf16_split3(float x, __bf16 &a, __bf16 &b, __bf16 &c)
+{
+    a = (__bf16)x;
+    const float r1 = x - (float)a;
+    b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    c = (__bf16)r2;
+}
+
+// 8 consecutive fp32 -> three bf16x8 fragments
+__device__ __forceinline__ void bf16_split3_x8(const float *src, bf8v &s0, bf8v &s1, bf8v &s2)
+{
+    const f4v lo = *(const f4v *)src, hi = *(const f4v *)(src + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        __bf16 a, b, c;
+        bf16_split3(lo[j], a, b, c); s0[j] = a; s1[j] = b; s2[j] = c;
+        bf16_split3(hi[j], a, b, c); s0[4 + j] = a; s1[4 + j] = b; s2[4 + j] = c;
+    }
+}
+
+// the six partial products, smallest magnitude first; index pairs (split of A, split of B)
+#define CTGCN_X3_PAIRS(F) F(2, 0) F(0, 2) F(1, 1) F(1, 0) F(0, 1) F(0, 0)
+
+// ------------------------------------------------------------------------------------------------
+// GRU input projection  GI[rows, 384] = X[rows, 128] · W_ihᵀ + bias   (the `gi` operand of gru_seq_kernel).
+// Same block shape as the recurrence: wave w owns output columns {g*128 + 16w + c} and keeps its slice of W_ihᵀ,
+// already split, in 144 VGPRs (36 bf16x8 B fragments).  The 64-row X tile is split once by the whole block and
+// staged in LDS as three bf16 planes (double buffered: the next tile's global loads fly during the MFMAs).
+// HBM-bound once the matrix pipe is this fast: 512 B read + 1536 B written per row.
+// ------------------------------------------------------------------------------------------------
+constexpr int PJ_BM = 64;
+constexpr int PJ_PITCH = GRU_H + 8;      // bf16 elements; 272-byte rows keep ds_read_b128 conflict-free
+
+struct ProjArgs {
+    int64_t rows;
+    const float *x;
+    int64_t ldx;
+    const float *w;       // [384, 128]
+    const float *bias;    // [384] or null
+    float *out;           // [rows, 384]
+};
+
+__global__ __launch_bounds__(512, 2) void gru_proj_x3_kernel(const ProjArgs a)
+{
+    __shared__ __bf16 As[2][3][PJ_BM][PJ_PITCH];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int hid = wave * 16 + col;
+
+    bf8v Wf[3][4][3];      // [split][k chunk][gate]
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            bf16_split3_x8(a.w + (int64_t)(g * GRU_H + hid) * GRU_H + c * 32 + 8 * grp, Wf[0][c][g], Wf[1][c][g], Wf[2][c][g]);
+    // The MFMA is issued transposed (weights as the A operand, X rows as the B operand): D[m = out column][n = X row],
+    // so a lane ends up with FOUR CONSECUTIVE output columns 16w + 4*grp .. +3 of X row (lane & 15): float4 I/O.
+    const int oc = wave * 16 + 4 * grp;
+    f4v bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bias[g] = a.bias ? *(const f4v *)(a.bias + g * GRU_H + oc) : f4v{0.f, 0.f, 0.f, 0.f};
+
+    const int64_t ntiles = (a.rows + PJ_BM - 1) / PJ_BM;
+    // staging role: 64 rows x 32 float4 = 2048 float4, four per thread; idx -> (row, c4)
+    auto load_tile = [&](int64_t tile, f4v (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
+            int64_t r = tile * PJ_BM + (idx >> 5);
+            r = r < a.rows ? r : a.rows - 1;
+            v[i] = *(const f4v *)(a.x + r * a.ldx + (idx & 31) * 4);
+        }
+    };
+    auto stage_tile = [&](int buf, const f4v (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
+            bf4v s0, s1, s2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 p, q, r;
+                bf16_split3(v[i][j], p, q, r);
+                s0[j] = p; s1[j] = q; s2[j] = r;
+            }
+            __bf16 *dst = &As[buf][0][idx >> 5][(idx & 31) * 4];
+            *(bf4v *)dst = s0;
+            *(bf4v *)(dst + PJ_BM * PJ_PITCH) = s1;
+            *(bf4v *)(dst + 2 * PJ_BM * PJ_PITCH) = s2;
+        }
+    };
+
+    f4v stage[4];
+    int buf = 0;
+    if ((int64_t)blockIdx.x < ntiles) {
+        load_tile(blockIdx.x, stage);
+        stage_tile(0, stage);
+    }
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int64_t next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next, stage);               // in flight during the MFMAs
+        const int64_t row0 = tile * PJ_BM;
+#pragma unroll
+        for (int rt = 0; rt < PJ_BM / 16; ++rt) {
+            f4v acc[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bf8v af[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) af[sp] = *(const bf8v *)(&As[buf][sp][rt * 16 + col][c * 32 + 8 * grp]);
+#define CTGCN_X3_MFMA(I, J)                                                                                          \
+                _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                        \
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[J][c][g], af[I], acc[g], 0, 0, 0);
+                CTGCN_X3_PAIRS(CTGCN_X3_MFMA)
+#undef CTGCN_X3_MFMA
+            }
+            const int64_t row = row0 + rt * 16 + col;
+            if (row < a.rows) {
+                float *o = a.out + row * (3 * GRU_H) + oc;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) *(f4v *)(o + g * GRU_H) = acc[g] + bias[g];
+            }
+        }
+        if (next < ntiles) stage_tile(buf ^ 1, stage);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gru_seq_x3_kernel: the REDUCE form of gru_seq_kernel (LayerNorm(sum_t h_t), the CoreDiffusion case = 32 of the 33
+// GRU calls of a CTGCN-C window) with the recurrent product h_{t-1}·W_hhᵀ in split-bf16 arithmetic (see above).
+// W_hhᵀ slice: 36 bf16x8 fragments (144 VGPRs) per wave; h_t is split by the lane that produces it and stored as
+// three bf16 planes in LDS (double buffered), from which the A fragments are single ds_read_b128; the fp32 h needed
+// by the z·h_{t-1} term stays in registers, the running sum in an fp32 LDS plane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
+{
+    __shared__ __bf16 Hs[2][3][GRU_BM][PJ_PITCH];
+    __shared__ float sbuf[GRU_BM][GRU_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int hid = wave * 16 + col;          // weight row this lane holds fragments of (MFMA m index)
+    const int oc = wave * 16 + 4 * grp;       // first of the 4 consecutive hidden units this lane produces
+    const int steps = a.steps;
+
+    // MFMA A operand (transposed product D[m = hidden][n = row]):  A[m = hid][k = c*32 + 8*grp + j] = W_hh[g*128 + hid][k]
+    bf8v Wf[3][4][3];      // [split][k chunk][gate]
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            bf16_split3_x8(a.whh + (int64_t)(g * GRU_H + hid) * GRU_H + c * 32 + 8 * grp, Wf[0][c][g], Wf[1][c][g], Wf[2][c][g]);
+    const f4v b_hn = a.bhn ? *(const f4v *)(a.bhn + oc) : f4v{0.f, 0.f, 0.f, 0.f};
+    const int64_t ntiles = (a.rows + GRU_BM - 1) / GRU_BM;
+    const int gstride = steps * 3 * GRU_H;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * GRU_BM;
+        const float *gi_tile = a.gi + row0 * gstride + oc;
+        const int last = (int)min((int64_t)GRU_BM, a.rows - row0) - 1;
+        // a lane's results: row rt*16 + col, hidden oc..oc+3 (float4 / bf16x4 I/O everywhere)
+        auto goff = [&](int rt) { return min(rt * 16 + col, last) * gstride; };
+        f4v hreg[GRU_RT];
+
+        auto publish = [&](int buf, int r_, const f4v h) {     // split h and store the three bf16 planes
+            bf4v p, q, r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 x, y, z;
+                bf16_split3(h[j], x, y, z);
+                p[j] = x; q[j] = y; r[j] = z;
+            }
+            *(bf4v *)(&Hs[buf][0][r_][oc]) = p;
+            *(bf4v *)(&Hs[buf][1][r_][oc]) = q;
+            *(bf4v *)(&Hs[buf][2][r_][oc]) = r;
+        };
+        auto gates = [&](const f4v gr, const f4v gz, const f4v gn, const f4v ar, const f4v az, const f4v an, const f4v hold) {
+            f4v h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float r = gru_sigmoid(gr[j] + ar[j]);
+                const float z = gru_sigmoid(gz[j] + az[j]);
+                const float n = gru_tanh(gn[j] + r * (an[j] + b_hn[j]));
+                h[j] = n + z * (hold[j] - n);
+            }
+            return h;
+        };
+        const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
+
+        // ---- step 0: h_{-1} = 0, no MFMA
+#pragma unroll
+        for (int rt = 0; rt < GRU_RT; ++rt) {
+            const float *p = gi_tile + goff(rt);
+            const f4v h = gates(*(const f4v *)p, *(const f4v *)(p + GRU_H), *(const f4v *)(p + 2 * GRU_H), zero4, zero4, zero4, zero4);
+            hreg[rt] = h;
+            publish(0, rt * 16 + col, h);
+            *(f4v *)(&sbuf[rt * 16 + col][oc]) = h;
+        }
+        __syncthreads();
+
+        for (int t = 1; t < steps; ++t) {
+            const int pb = (t - 1) & 1, cb = t & 1;
+            const float *gi_t = gi_tile + t * 3 * GRU_H;
+#pragma unroll
+            for (int rt = 0; rt < GRU_RT; ++rt) {
+                const float *p = gi_t + goff(rt);                    // issued before the MFMAs, consumed after them
+                const f4v gr = *(const f4v *)p, gz = *(const f4v *)(p + GRU_H), gn = *(const f4v *)(p + 2 * GRU_H);
+                f4v acc[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g] = zero4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bf8v af[3];          // MFMA B operand: B[k][n = row] = h_{t-1}[row rt*16 + col][k = c*32 + 8*grp + j]
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) af[sp] = *(const bf8v *)(&Hs[pb][sp][rt * 16 + col][c * 32 + 8 * grp]);
+#define CTGCN_X3_MFMA(I, J)                                                                                              \
+                    _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                        \
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[J][c][g], af[I], acc[g], 0, 0, 0);
+                    CTGCN_X3_PAIRS(CTGCN_X3_MFMA)
+#undef CTGCN_X3_MFMA
+                }
+                const f4v h = gates(gr, gz, gn, acc[0], acc[1], acc[2], hreg[rt]);
+                hreg[rt] = h;
+                publish(cb, rt * 16 + col, h);
+                f4v *sp_ = (f4v *)(&sbuf[rt * 16 + col][oc]);
+                *sp_ = *sp_ + h;
+            }
+            __syncthreads();
+        }
+        for (int r = wave; r <= last; r += 8)
+            gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+        __syncthreads();       // LDS is reused by the next tile
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward of the GRU recurrence (what autograd derives for nn.GRU at layers.py:59 / models.py:249).
 // Walks t = steps-1 .. 0 with dh = dh_seq[t] (or the broadcast dh_sum) + the recurrent term carried in registers:
@@ -1193,7 +1442,7 @@ int64_t ctgcn_gru_row_granule(void)
 
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, float *gates_out, void *stream)
+                      int reduce_sum, float *out, float *gates_out, int split_bf16, void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq: hidden=%d, only %d is built", hidden, GRU_H);
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq: bad sizes rows=%lld steps=%d", (long long)rows, steps);
@@ -1210,7 +1459,9 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 8-wave block per CU
-    if (a.reduce_sum)
+    if (a.reduce_sum && split_bf16)
+        hipLaunchKernelGGL(gru_seq_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (a.reduce_sum)
         hipLaunchKernelGGL((gru_seq_kernel<true, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else if (a.gates)
         hipLaunchKernelGGL((gru_seq_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
@@ -1237,6 +1488,26 @@ int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
     const int64_t ntiles = (rows + GRUB_BM - 1) / GRUB_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;
     hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *x, int64_t ldx,
+                             const float *w_ih, const float *bias, float *gi, void *stream)
+{
+    if (hidden != GRU_H || d_in != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_input_proj: only d_in = hidden = %d is built (got %d, %d)", GRU_H, d_in, hidden);
+    if (rows < 0 || ldx < d_in) return fail(CTGCN_E_INVALID, "gru_input_proj: bad sizes");
+    if (rows == 0) return CTGCN_OK;
+    if (!x || !w_ih || !gi) return fail(CTGCN_E_INVALID, "gru_input_proj: null pointer");
+    if (!aligned16(x) || !aligned16(w_ih) || (ldx % 4)) return fail(CTGCN_E_INVALID, "gru_input_proj: x / w_ih must be 16-byte aligned, ldx a multiple of 4");
+    ProjArgs a{};
+    a.rows = rows; a.x = x; a.ldx = ldx; a.w = w_ih; a.bias = bias; a.out = gi;
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t ntiles = (rows + PJ_BM - 1) / PJ_BM;
+    const int64_t blocks = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL(gru_proj_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

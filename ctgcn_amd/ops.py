@@ -236,7 +236,22 @@ def _row_chunks(lib, rows, steps, hid):
     return [(lo, min(chunk, rows - lo)) for lo in range(0, rows, chunk)]
 
 
+def split_mfma_enabled():
+    """fp32-accurate bf16x3 split arithmetic on the bf16 matrix cores (default).  CTGCN_FP32_MFMA_ONLY=1 forces the
+    plain fp32 paths (hipBLASLt fp32 GEMM + v_mfma_f32_16x16x4_f32 recurrence) for A/B comparisons."""
+    import os
+    return os.environ.get("CTGCN_FP32_MFMA_ONLY", "0") != "1"
+
+
 def _project(x2d, w_ih, bias, out):
+    """out[rows, 3h] = x2d @ w_ih^T + bias — the GRU input projection."""
+    if split_mfma_enabled() and x2d.shape[1] == 128 and w_ih.shape[0] == 384 and x2d.stride(1) == 1 \
+            and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0 and w_ih.is_contiguous():
+        lib = _lib.load()
+        with _timed("gru_proj", rows=x2d.shape[0]):
+            check(lib.ctgcn_gru_input_proj_f32(x2d.shape[0], 128, 128, ptr(x2d), x2d.stride(0), ptr(w_ih), ptr(bias), ptr(out),
+                                               _stream()), "ctgcn_gru_input_proj_f32")
+        return
     if bias is None:
         torch.mm(x2d, w_ih.t(), out=out)
     else:
@@ -258,7 +273,8 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
             _project(seq[lo:lo + n].reshape(n * steps, d_in), w_ih, bias, gi)
             with _timed("gru_seq", rows=n, steps=steps):
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
-                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), None, _stream()), "ctgcn_gru_seq_f32")
+                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), None, 1 if split_mfma_enabled() else 0,
+                                            _stream()), "ctgcn_gru_seq_f32")
     return out
 
 
@@ -333,7 +349,7 @@ class _GruSeq(torch.autograd.Function):
                 gi, gates, hseq = gi_buf[: n * steps], gates_buf[: n * steps], hseq_buf[:n]
                 _project(x2d, w_ih_d, bias, gi)
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq),
-                                            ptr(gates), _stream()), "ctgcn_gru_seq_f32")
+                                            ptr(gates), 0, _stream()), "ctgcn_gru_seq_f32")
                 # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)
                 g_out = dout[lo:lo + n]
                 pre = hseq.sum(1) if reduce_sum else hseq

@@ -154,13 +154,15 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  * gi [rows, steps, 384] is the input projection x·W_ih^T + b_ih (+ b_hh for the r and z gates) in PyTorch's
  * gate order r,z,n — a plain GEMM the caller runs with its BLAS; w_hh [384,128] and b_hn [128] (the n-gate's
  * hidden bias, NULL = 0) are the module's weight_hh_l0 and bias_hh_l0[256:384].  ln_weight == NULL skips the
- * LayerNorm.  h_0 = 0.  Exact fp32 arithmetic (f32-input MFMA).
+ * LayerNorm.  h_0 = 0.  split_bf16 == 0: exact fp32 (f32-input MFMA, an fmaf chain).  split_bf16 != 0 (honoured for
+ * reduce_sum != 0, ignored otherwise): fp32-accurate split arithmetic on the bf16 matrix cores — operands split
+ * exactly into three bf16 terms, six partial products, fp32 accumulation — about twice the matrix throughput.
  * gates_out (optional; requires reduce_sum == 0 and ln_weight == NULL): [rows, steps, 4, 128] receives r, z, n and
  * q = W_hn·h_{t-1} + b_hn for ctgcn_gru_seq_bwd_f32.
  */
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, float *gates_out, void *stream);
+                      int reduce_sum, float *out, float *gates_out, int split_bf16, void *stream);
 
 /*
  * Backward of the recurrence above (autograd of nn.GRU, layers.py:59 / models.py:249).  Inputs: the saved gates and
@@ -172,6 +174,15 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
 int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *h_seq,
                           const float *dh_seq, const float *dh_sum, const float *w_hh, float *d_gi, float *d_ghn,
                           void *stream);
+
+/*
+ * The GRU input projection  gi[rows, 384] = x[rows, 128]·w_ih^T + bias  (bias [384] may be NULL) for d_in = hidden = 128,
+ * in fp32-accurate split arithmetic on the bf16 matrix cores: each fp32 operand is split exactly into three bf16
+ * terms and the six significant partial products accumulate in fp32 (error vs fp64 no larger than an fp32 fmaf
+ * chain's, measured).  Other widths: use a BLAS GEMM.
+ */
+int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *x, int64_t ldx,
+                             const float *w_ih, const float *bias, float *gi, void *stream);
 
 /* Rows one wave of persistent blocks covers (rows per block x compute units): callers that split `rows` into
  * chunks should use multiples of this so that every launch keeps all CUs equally busy. */

@@ -117,3 +117,25 @@ def test_training_and_inference_paths_agree():
     with torch.no_grad():
         y_inf = layer(x, adj)
     assert torch.equal(y_inf, y_train.detach())
+
+
+@pytest.mark.parametrize("rows", [1, 63, 64, 1000, 70000])
+def test_split_bf16_projection_is_fp32_accurate(rows):
+    """ctgcn_gru_input_proj_f32 (3-way bf16 split, six products) vs an fp64 reference: its error must not exceed the
+    error of a plain fp32 GEMM of the same operands by more than a small factor, and both are ~1e-6."""
+    from ctgcn_amd import ops
+    torch.manual_seed(rows)
+    x = (torch.relu(torch.randn(rows, 128)) * 4.0)
+    w = (torch.rand(384, 128) - 0.5) * 0.18
+    b = torch.randn(384) * 0.1
+    ref = x.double() @ w.double().t() + b.double()
+    out = torch.empty(rows, 384, device=DEV)
+    assert ops.split_mfma_enabled()
+    ops._project(x.to(DEV), w.to(DEV), b.to(DEV), out)
+    err_split = (out.cpu().double() - ref).abs().max().item()
+    err_fp32 = ((x @ w.t() + b).double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err_split <= max(2.0 * err_fp32, 2e-7 * scale), (err_split, err_fp32, scale)
+    out2 = torch.empty(rows, 384, device=DEV)
+    ops._project(x.to(DEV), w.to(DEV), None, out2)
+    assert torch.allclose(out2.cpu() + b, out.cpu(), atol=1e-5)

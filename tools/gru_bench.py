@@ -38,12 +38,13 @@ def main():
         e.record()
         torch.cuda.synchronize()
     total_ms = s.elapsed_time(e) / a.iters
-    k_ms = sum(ss.elapsed_time(ee) for _, ss, ee, _ in rec) / a.iters
+    k_ms = sum(ss.elapsed_time(ee) for nm, ss, ee, _ in rec if nm == "gru_seq") / a.iters
+    p_ms = sum(ss.elapsed_time(ee) for nm, ss, ee, _ in rec if nm == "gru_proj") / a.iters
     fl_rec = a.rows * (a.steps - 1) * 2.0 * 128 * 384
     fl_in = a.rows * a.steps * 2.0 * a.din * 384
-    print("rows=%d steps=%d din=%d: total %.3f ms | recurrent kernel %.3f ms = %.1f TF/s (%.0f%% of 157.3) | projection+rest %.3f ms = %.1f TF/s"
+    print("rows=%d steps=%d din=%d: total %.3f ms | recurrent kernel %.3f ms = %.1f TF/s (%.0f%% of 157.3) | projection+rest %.3f ms = %.1f TF/s | split-proj kernel %.3f ms (%.0f GB/s)"
           % (a.rows, a.steps, a.din, total_ms, k_ms, fl_rec / k_ms / 1e9, 100 * fl_rec / k_ms / 1e9 / 157.3,
-             total_ms - k_ms, fl_in / (total_ms - k_ms) / 1e9))
+             total_ms - k_ms, fl_in / (total_ms - k_ms) / 1e9, p_ms, a.rows * a.steps * 2048.0 / max(p_ms, 1e-9) / 1e6))
 
 
 if __name__ == "__main__":

@@ -200,17 +200,29 @@ def main():
                 "algorithmic_bytes_per_launch": int(avg_bytes),
                 "frac_of_measured_copy_bw_6300": round(achieved / 6300.0, 4)}
     spmm_ms_step = sum(kern_ms) / args.steps if kern_ms else None
-    # second-largest custom kernel: the fused GRU recurrence (fp32 MFMA bound)
+    # the matrix-core kernels: GRU recurrence (+ sum/LayerNorm) and the input projection
     gru = [(s.elapsed_time(e), meta) for name, s, e, meta in launches if name == "gru_seq"]
+    proj = [(s.elapsed_time(e), meta) for name, s, e, meta in launches if name == "gru_proj"]
     roof_mfma = None
     if gru:
-        flops = sum(m["rows"] * (m["steps"] - 1) * 2.0 * 128 * 384 for _, m in gru)     # step 0 (h=0) issues no MFMA
+        split = ops.split_mfma_enabled()
+        # fp32-equivalent flops; step 0 (h = 0) issues no MFMA.  Split path: 6 bf16 products per fp32 product, so the
+        # matrix-core bound is the dense bf16 peak / 6; exact path: the fp32 MFMA peak.
+        peak = 2500.0 / 6.0 if split else 157.3
+        flops = sum(m["rows"] * (m["steps"] - 1) * 2.0 * 128 * 384 for _, m in gru)
         ms = sum(t for t, _ in gru)
-        roof_mfma = {"kernel": "gru_seq_kernel (GRU recurrence + sum/LayerNorm, v_mfma_f32_16x16x4_f32)", "bound": "mfma",
-                     "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
-                     "frac": round(flops / (ms * 1e-3) / 1e12 / 157.3, 4), "launches_timed": len(gru),
-                     "ms_per_step_rank0": round(ms / args.steps, 3)}
-
+        roof_mfma = {"kernel": ("gru_seq_x3_kernel (GRU recurrence + sum + LayerNorm; fp32 operands split 3-way into bf16, "
+                                "6 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate)") if split else
+                               "gru_seq_kernel (GRU recurrence + sum + LayerNorm, v_mfma_f32_16x16x4_f32)",
+                     "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
+                     "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
+                     "launches_timed": len(gru), "ms_per_step_rank0": round(ms / args.steps, 3)}
+        if proj:
+            pms = sum(t for t, _ in proj)
+            pbytes = sum(m["rows"] * 2048.0 for _, m in proj)          # 512 B read + 1536 B written per row
+            roof_mfma["input_projection"] = {"kernel": "gru_proj_x3_kernel", "bound": "hbm", "ms_per_step_rank0": round(pms / args.steps, 3),
+                                             "achieved": round(pbytes / (pms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": round(pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if use_dist:
         dist.barrier()
     if rank != 0:

@@ -1089,13 +1089,21 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
         }
         __syncthreads();
 
+        // GI of (step, row tile) is loaded ONE TILE AHEAD of its use: a tile's MFMA phase (~0.6 us) is shorter than the
+        // HBM latency under load, the previous tile's whole body is not
+        f4v nr, nz, nn;
+        auto fetch = [&](int t, int rt) {
+            const float *p = gi_tile + t * 3 * GRU_H + goff(rt);
+            nr = *(const f4v *)p; nz = *(const f4v *)(p + GRU_H); nn = *(const f4v *)(p + 2 * GRU_H);
+        };
+        if (steps > 1) fetch(1, 0);
         for (int t = 1; t < steps; ++t) {
             const int pb = (t - 1) & 1, cb = t & 1;
-            const float *gi_t = gi_tile + t * 3 * GRU_H;
 #pragma unroll
             for (int rt = 0; rt < GRU_RT; ++rt) {
-                const float *p = gi_t + goff(rt);                    // issued before the MFMAs, consumed after them
-                const f4v gr = *(const f4v *)p, gz = *(const f4v *)(p + GRU_H), gn = *(const f4v *)(p + 2 * GRU_H);
+                const f4v gr = nr, gz = nz, gn = nn;
+                if (rt + 1 < GRU_RT) fetch(t, rt + 1);
+                else if (t + 1 < steps) fetch(t + 1, 0);
                 f4v acc[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[g] = zero4;

@@ -194,3 +194,45 @@ def test_full_size_properties_config5_snapshot():
     y = ops.spmm_csr(adj.row_ptr, adj.col, adj.val, x1)
     d_last = h[:, -1] - h[:, -2]
     assert (d_last - y).abs().max().item() <= 1e-5 * y.abs().max().item() + 2e-4
+
+
+# ------------------------------------------------------- shipped width (hidden = 128): the fused HIP GRU kernels
+def test_ctgcn_width_128_fused_path_matches_cpu_oracle():
+    """hid = embed = 128 is what every shipped config uses and what the fused projection / recurrence kernels cover:
+    forward (split-bf16 matrix-core path) and all gradients (HIP backward recurrence) vs the CPU oracle."""
+    import ctgcn_amd
+    from ctgcn_amd import ops
+    from ctgcn_amd.helper import core_adj_from_scipy
+    from ctgcn_amd.synth import dynamic_graph
+    from oracle import oracle as O, torch_path as TP
+    n, T = 3000, 3
+    graphs = dynamic_graph(n, 10, T, seed=4)
+    adj, ref_adj = [], []
+    for g in graphs:
+        a, _, _ = core_adj_from_scipy(g, 5, DEV)
+        adj.append(a)
+        ref_adj.append([TP.coo_like_reference(m) for m in O.core_adj_list([O.kcore_matrices(g)], 0, 1, 1, 5)[0]])
+    torch.manual_seed(3)
+    model = ctgcn_amd.CTGCN(20, 128, 128, 1, 2, T).to(DEV)
+    x = [torch.randn(n, 20) for _ in range(T)]
+    gsel = torch.randn(T, n, 128)
+    assert ops.split_mfma_enabled() and ops.gru_fused_ok(model.rnn, torch.zeros(1, 1, 128, device=DEV))
+    with torch.no_grad():
+        out_inf = model([v.to(DEV) for v in x], adj)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    ref = TP.ctgcn_with_grad(sd, x, ref_adj)
+    np.testing.assert_allclose(out_inf.cpu().numpy(), ref.detach().numpy(), **TOL)
+    (ref * gsel).sum().backward()
+    out = model([v.to(DEV) for v in x], adj)
+    assert torch.equal(out.detach(), out_inf)
+    (out * gsel.to(DEV)).sum().backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        want = sd[name].grad
+        if want is None:
+            continue
+        scale = max(1e-6, float(want.abs().max()))
+        err = float((p.grad.cpu() - want).abs().max())
+        assert err <= 3e-3 * scale, (name, err, scale)
+        checked += 1
+    assert checked >= 30

@@ -236,3 +236,28 @@ def test_ctgcn_width_128_fused_path_matches_cpu_oracle():
         assert err <= 3e-3 * scale, (name, err, scale)
         checked += 1
     assert checked >= 30
+
+
+def test_full_size_split_and_exact_fp32_paths_agree(monkeypatch):
+    """config-5 sized snapshots (1M nodes): the default split-bf16 matrix-core path and the exact-fp32 MFMA path
+    (CTGCN_FP32_MFMA_ONLY=1: hipBLASLt fp32 GEMM + v_mfma_f32_16x16x4_f32 recurrence) give the same embeddings."""
+    import ctgcn_amd
+    from ctgcn_amd import CoreAdj, ops
+    from ctgcn_amd.synth import dynamic_graph_device
+    n, T = 1_000_000, 2
+    graphs = dynamic_graph_device(n, 16, 16, DEV, which=[3, 15])
+    adj = [CoreAdj.from_graph(*graphs[t], max_core=8)[0] for t in (3, 15)]
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        model = ctgcn_amd.CTGCN(64, 128, 128, 1, 2, T)
+    x = [torch.randn(n, 64, device=DEV) for _ in range(T)]
+    with torch.no_grad():
+        monkeypatch.setenv("CTGCN_FP32_MFMA_ONLY", "0")
+        assert ops.split_mfma_enabled()
+        a = model(x, adj)
+        monkeypatch.setenv("CTGCN_FP32_MFMA_ONLY", "1")
+        assert not ops.split_mfma_enabled()
+        b = model(x, adj)
+    assert torch.isfinite(a).all()
+    err = (a - b).abs().max().item()
+    assert err <= 2e-5 + 1e-4 * b.abs().max().item(), err

@@ -28,7 +28,7 @@ SIGNATURES = {
     "ctgcn_core_aggregate_bwd_prep_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
     "ctgcn_core_aggregate_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u32, _vp, _i32, _i32, _vp]),
     "ctgcn_edges_to_csr": (_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.POINTER(_i64), _vp, _sz, _vp]),
-    "ctgcn_kcore_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _sz, _c.POINTER(_i32), _vp]),
+    "ctgcn_kcore_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _sz, _i32, _c.POINTER(_i32), _vp]),
     "ctgcn_edge_levels_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp, _int, _vp]),

@@ -235,12 +235,13 @@ class CoreAdj(object):
         level = min(core[u], core[v]) and applies the loader semantics of helper.py:51-82 through a
         level -> slot table.  Returns (CoreAdj, core_numbers, file_count) where file_count is the number
         of per-k files the reference would have written (= max core number), which the caller needs for
-        the sticky max_core rule (helper.py:61-62).
+        the sticky max_core rule (helper.py:61-62).  With max_core = L >= 1 the loader never tells levels above L
+        apart (helper.py:63), so the peel stops at L: core numbers and file_count are then reported capped at L.
         """
         from . import ops
         n = row_ptr.numel() - 1
         if core is None:
-            core, max_k = ops.kcore(row_ptr, col)
+            core, max_k = ops.kcore(row_ptr, col, level_cap=max_core if max_core >= 1 else -1)
         else:
             max_k = int(core.max().item()) if n else 0
         file_count = max_k

@@ -1238,10 +1238,11 @@ __global__ __launch_bounds__(512, 2) void gru_seq_bwd_kernel(const GruBwdArgs a)
     }
 }
 
-__global__ void kcore_copy_kernel(int n, const int32_t *__restrict__ deg, int32_t *__restrict__ core)
+// final core numbers; with a level cap the unpeeled vertices (current degree >= cap) are reported as `cap`
+__global__ void kcore_copy_kernel(int n, int cap, const int32_t *__restrict__ deg, int32_t *__restrict__ core)
 {
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (v < n) core[v] = deg[v];
+    if (v < n) core[v] = min(deg[v], cap);
 }
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -1363,7 +1364,7 @@ size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t 
 }
 
 int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, int32_t *core,
-                    void *workspace, size_t workspace_bytes, int32_t *max_core_host, void *stream)
+                    void *workspace, size_t workspace_bytes, int32_t level_cap, int32_t *max_core_host, void *stream)
 {
     if (n < 0 || n > 0x7fffffffLL) return fail(CTGCN_E_INVALID, "kcore: n=%lld out of range", (long long)n);
     if (max_core_host) *max_core_host = 0;
@@ -1390,9 +1391,10 @@ int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, i
     if (blocks > 2048) blocks = 2048;
     const int chunk = (nn + blocks - 1) / blocks;
     constexpr int BATCH = 16;
+    const int cap = level_cap > 0 ? level_cap : 0x7fffffff;      // peel levels 0 .. cap-1 only
     KcoreCtl h{};
-    for (int level = 0;; level += BATCH) {
-        for (int b = 0; b < BATCH; ++b)
+    for (int level = 0; level < cap; level += BATCH) {
+        for (int b = 0; b < BATCH && level + b < cap; ++b)
             hipLaunchKernelGGL(kcore_level_kernel, dim3(blocks), dim3(256), 0, st, nn, level + b, chunk, row_ptr, col_idx, deg,
                                claimed, pool_v, pool_prev, ctl);
         HIP_TRY(hipGetLastError());
@@ -1401,10 +1403,10 @@ int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, i
         if (h.visited >= nn) break;
         if (level > nn) return fail(CTGCN_E_HIP, "kcore: did not converge (visited %d of %d)", h.visited, nn);
     }
-    hipLaunchKernelGGL(kcore_copy_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, deg, core);
+    hipLaunchKernelGGL(kcore_copy_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, cap, deg, core);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
-    if (max_core_host) *max_core_host = h.max_core;
+    if (max_core_host) *max_core_host = h.visited >= nn ? h.max_core : cap;     // survivors exist: max core >= cap, reported as cap
     return CTGCN_OK;
 }
 

@@ -81,9 +81,10 @@ def edges_to_csr(src, dst, w, n):
 
 
 # ------------------------------------------------------------------------------------------- k-core
-def kcore(row_ptr, col):
+def kcore(row_ptr, col, level_cap=-1):
     """Core number of every vertex (reference: networkx.core_number at structure_generation.py:35).
-    row_ptr/col: symmetric CSR structure on the GPU.  Returns (core int32[n] on the GPU, max core)."""
+    row_ptr/col: symmetric CSR structure on the GPU.  Returns (core int32[n] on the GPU, max core).
+    level_cap = L > 0 peels only levels below L and reports every core number >= L as L."""
     _need_cuda(row_ptr, col)
     lib = _lib.load()
     row_ptr, col = _i32(row_ptr), _i32(col)
@@ -95,8 +96,8 @@ def kcore(row_ptr, col):
         nbytes = lib.ctgcn_workspace_bytes(_lib.OP_KCORE, n, col.numel(), 0, 0)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=row_ptr.device)
         mx = ctypes.c_int32(0)
-        check(lib.ctgcn_kcore_i32(n, ptr(row_ptr), ptr(col), ptr(core), ptr(ws), nbytes, ctypes.byref(mx), _stream()),
-              "ctgcn_kcore_i32")
+        check(lib.ctgcn_kcore_i32(n, ptr(row_ptr), ptr(col), ptr(core), ptr(ws), nbytes, int(level_cap), ctypes.byref(mx),
+                                  _stream()), "ctgcn_kcore_i32")
     return core, int(mx.value)
 
 

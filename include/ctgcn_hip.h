@@ -119,10 +119,14 @@ int ctgcn_edges_to_csr(int64_t n, int64_t m, const int32_t *src, const int32_t *
  * (self-loop entries, if any, are ignored).  Replaces networkx.core_number at
  * preprocessing/structure_generation.py:35.  Integer result, unique, bit-exact.
  * workspace: ctgcn_workspace_bytes(CTGCN_OP_KCORE, n, nnz, 0, 0) bytes.
- * max_core_host (optional) receives max(core).  Synchronises `stream`.
+ * level_cap <= 0: exact core numbers.  level_cap = L > 0: only levels 0..L-1 are peeled and every vertex whose core
+ * number is >= L is reported as L — all a loader with max_core = L needs (helper.py:63 keeps k <= max_core, so the
+ * levels above it are never told apart), at a fraction of the peel depth.
+ * max_core_host (optional) receives max(core) (capped likewise).  Synchronises `stream`.
  */
 int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, int32_t *core,
-                    void *workspace, size_t workspace_bytes, int32_t *max_core_host, void *stream);
+                    void *workspace, size_t workspace_bytes, int32_t level_cap, int32_t *max_core_host,
+                    void *stream);
 
 /*
  * level[e] = min(core[row(e)], core[col(e)]) for every CSR entry: entry e belongs to the k-core

@@ -76,6 +76,18 @@ def test_kcore_random_vs_oracle(n, m, seed):
     assert mx == int(ref.max(initial=0))
 
 
+def test_kcore_level_cap_reports_min_of_core_and_cap():
+    from ctgcn_amd import ops
+    from oracle import oracle as O
+    csr = _rand_graph(50000, 600000, 13)
+    rp, col, _ = _upload(csr)
+    ref = O.core_numbers(csr)
+    for cap in (1, 2, 5, int(ref.max()), int(ref.max()) + 7):
+        core, mx = ops.kcore(rp, col, level_cap=cap)
+        assert np.array_equal(core.cpu().numpy(), np.minimum(ref, cap)), cap
+        assert mx == min(int(ref.max()), cap)
+
+
 def test_kcore_long_path_and_queue_spill():
     """a 300k-vertex path (every vertex peels at level 1 through a chain of pushes) and a graph whose
     level-k frontier exceeds one block's LDS queue."""
@@ -206,7 +218,7 @@ def test_abi_rejects_bad_arguments():
     x = torch.zeros(4, 4, device=_dev())
     rc = lib.ctgcn_core_aggregate_f32(4, 4, 0, None, None, None, None, x.data_ptr(), 4, x.data_ptr(), 0, None, 0, 0, None)
     assert rc == -1 and b"K=0" in lib.ctgcn_last_error()
-    rc = lib.ctgcn_kcore_i32(4, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, None, None)
+    rc = lib.ctgcn_kcore_i32(4, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, -1, None, None)
     assert rc == -3
     with pytest.raises(_lib.CtgcnHipError):
         _lib.check(rc, "kcore")
@@ -230,7 +242,9 @@ def test_native_route_equals_matrix_route():
         for mc in (-1, 3):
             adj, core, files = core_adj_from_scipy(csr, mc, _dev())
             mats = O.kcore_matrices(csr)
-            assert files == len(mats)
+            assert files == (len(mats) if mc < 0 else min(len(mats), mc))          # capped peel reports min(max core, max_core)
+            want_core = O.core_numbers(csr)
+            assert np.array_equal(core.cpu().numpy(), want_core if mc < 0 else np.minimum(want_core, mc))
             ref = CoreAdj.from_matrices(O.core_adj_list([mats], 0, 1, 1, max_core=mc)[0], device="cpu")
             assert (adj.K, adj.nested, adj.self_loop, adj.symmetric) == (ref.K, True, True, True)
             assert adj.nnz_per_slot == ref.nnz_per_slot, (gi, mc)

@@ -56,8 +56,12 @@ def test_native_loader_route_matches_reference_loader(tmp_path):
     for tag, start, dur, mc in (("mcm1_", 0, 7, -1), ("mc5_", 0, 7, 5), ("w4_", 4, 3, -1)):
         got, cores = dl.get_core_adj_list_from_graphs(str(tmp_path / "1.format"), start, dur, max_core=mc, return_core_numbers=True)
         assert [len(g) for g in got] == ca[tag + "K"].tolist()
+        eff = mc                      # the sticky rule: -1 becomes the first snapshot's max core, which then caps the peel
         for i, (adj, core) in enumerate(zip(got, cores)):
-            assert np.array_equal(core.cpu().numpy(), kc["core_t%d" % (start + i)])
+            want = kc["core_t%d" % (start + i)]
+            assert np.array_equal(core.cpu().numpy(), want if eff < 0 else np.minimum(want, eff))
+            if eff < 0:
+                eff = int(want.max())
             for j, m in enumerate(adj.to_scipy_list()):
                 want = csr_from(ca, tag + "t%d_j%d" % (i, j), 1899, np.float32)
                 assert np.array_equal(m.indptr, want.indptr) and np.array_equal(m.indices, want.indices)

@@ -1024,10 +1024,11 @@ __global__ __launch_bounds__(512, 2) void gru_proj_x3_kernel(const ProjArgs a)
 // three bf16 planes in LDS (double buffered), from which the A fragments are single ds_read_b128; the fp32 h needed
 // by the z·h_{t-1} term stays in registers, the running sum in an fp32 LDS plane.
 // ------------------------------------------------------------------------------------------------
+template <bool REDUCE, bool SAVE>
 __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
 {
     __shared__ __bf16 Hs[2][3][GRU_BM][PJ_PITCH];
-    __shared__ float sbuf[GRU_BM][GRU_PITCH];
+    __shared__ float sbuf[GRU_BM][GRU_PITCH];      // REDUCE: running sum over steps; otherwise: fp32 h_t staged for the row-wise LayerNorm / store
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 15, grp = lane >> 4;
     const int hid = wave * 16 + col;          // weight row this lane holds fragments of (MFMA m index)
@@ -1065,14 +1066,21 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
             *(bf4v *)(&Hs[buf][1][r_][oc]) = q;
             *(bf4v *)(&Hs[buf][2][r_][oc]) = r;
         };
-        auto gates = [&](const f4v gr, const f4v gz, const f4v gn, const f4v ar, const f4v az, const f4v an, const f4v hold) {
-            f4v h;
+        // gate math for the lane's 4 hidden units of one row; REDUCE == false also emits the raw h (and, SAVE, the gates)
+        auto gates = [&](const f4v gr, const f4v gz, const f4v gn, const f4v ar, const f4v az, const f4v an, const f4v hold,
+                         int t, int r_) {
+            f4v h, rv, zv, nv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float r = gru_sigmoid(gr[j] + ar[j]);
-                const float z = gru_sigmoid(gz[j] + az[j]);
-                const float n = gru_tanh(gn[j] + r * (an[j] + b_hn[j]));
-                h[j] = n + z * (hold[j] - n);
+                rv[j] = gru_sigmoid(gr[j] + ar[j]);
+                zv[j] = gru_sigmoid(gz[j] + az[j]);
+                nv[j] = gru_tanh(gn[j] + rv[j] * (an[j] + b_hn[j]));
+                h[j] = nv[j] + zv[j] * (hold[j] - nv[j]);
+            }
+            if (!REDUCE) *(f4v *)(&sbuf[r_][oc]) = h;
+            if (SAVE && r_ <= last) {
+                float *gp = a.gates + ((row0 + r_) * steps + t) * (4 * GRU_H) + oc;
+                *(f4v *)gp = rv; *(f4v *)(gp + GRU_H) = zv; *(f4v *)(gp + 2 * GRU_H) = nv; *(f4v *)(gp + 3 * GRU_H) = an + b_hn;
             }
             return h;
         };
@@ -1082,12 +1090,18 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
 #pragma unroll
         for (int rt = 0; rt < GRU_RT; ++rt) {
             const float *p = gi_tile + goff(rt);
-            const f4v h = gates(*(const f4v *)p, *(const f4v *)(p + GRU_H), *(const f4v *)(p + 2 * GRU_H), zero4, zero4, zero4, zero4);
+            const f4v h = gates(*(const f4v *)p, *(const f4v *)(p + GRU_H), *(const f4v *)(p + 2 * GRU_H), zero4, zero4, zero4, zero4, 0, rt * 16 + col);
             hreg[rt] = h;
             publish(0, rt * 16 + col, h);
-            *(f4v *)(&sbuf[rt * 16 + col][oc]) = h;
+            if (REDUCE) *(f4v *)(&sbuf[rt * 16 + col][oc]) = h;
         }
         __syncthreads();
+        auto emit_step = [&](int t) {      // per-step output: LayerNorm (or plain copy) of the staged fp32 rows, 512 B per row
+            for (int r = wave; r <= last; r += 8)
+                gru_layernorm_row(sbuf[r], a.out + ((row0 + r) * steps + t) * GRU_H, lane, a.gamma, a.beta, a.eps);
+            __syncthreads();               // the next step's gate math overwrites sbuf
+        };
+        if (!REDUCE) emit_step(0);
 
         // GI of (step, row tile) is loaded ONE TILE AHEAD of its use: a tile's MFMA phase (~0.6 us) is shorter than the
         // HBM latency under load, the previous tile's whole body is not
@@ -1118,16 +1132,20 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
                     CTGCN_X3_PAIRS(CTGCN_X3_MFMA)
 #undef CTGCN_X3_MFMA
                 }
-                const f4v h = gates(gr, gz, gn, acc[0], acc[1], acc[2], hreg[rt]);
+                const f4v h = gates(gr, gz, gn, acc[0], acc[1], acc[2], hreg[rt], t, rt * 16 + col);
                 hreg[rt] = h;
                 publish(cb, rt * 16 + col, h);
-                f4v *sp_ = (f4v *)(&sbuf[rt * 16 + col][oc]);
-                *sp_ = *sp_ + h;
+                if (REDUCE) {
+                    f4v *sp_ = (f4v *)(&sbuf[rt * 16 + col][oc]);
+                    *sp_ = *sp_ + h;
+                }
             }
             __syncthreads();
+            if (!REDUCE) emit_step(t);
         }
-        for (int r = wave; r <= last; r += 8)
-            gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+        if (REDUCE)
+            for (int r = wave; r <= last; r += 8)
+                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
         __syncthreads();       // LDS is reused by the next tile
     }
 }
@@ -1470,7 +1488,11 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 8-wave block per CU
     if (a.reduce_sum && split_bf16)
-        hipLaunchKernelGGL(gru_seq_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((gru_seq_x3_kernel<true, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (split_bf16 && a.gates)
+        hipLaunchKernelGGL((gru_seq_x3_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (split_bf16)
+        hipLaunchKernelGGL((gru_seq_x3_kernel<false, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else if (a.reduce_sum)
         hipLaunchKernelGGL((gru_seq_kernel<true, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else if (a.gates)

@@ -268,14 +268,14 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
         return out
     chunks = _row_chunks(lib, rows, steps, hid)
     gi_buf = torch.empty(chunks[0][1] * steps, 3 * hid, dtype=torch.float32, device=seq.device)
+    split = 1 if split_mfma_enabled() else 0
     with torch.cuda.device(seq.device):
         for lo, n in chunks:
             gi = gi_buf[: n * steps]
             _project(seq[lo:lo + n].reshape(n * steps, d_in), w_ih, bias, gi)
             with _timed("gru_seq", rows=n, steps=steps):
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
-                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), None, 1 if split_mfma_enabled() else 0,
-                                            _stream()), "ctgcn_gru_seq_f32")
+                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), None, split, _stream()), "ctgcn_gru_seq_f32")
     return out
 
 
@@ -350,7 +350,7 @@ class _GruSeq(torch.autograd.Function):
                 gi, gates, hseq = gi_buf[: n * steps], gates_buf[: n * steps], hseq_buf[:n]
                 _project(x2d, w_ih_d, bias, gi)
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq),
-                                            ptr(gates), 0, _stream()), "ctgcn_gru_seq_f32")
+                                            ptr(gates), 1 if split_mfma_enabled() else 0, _stream()), "ctgcn_gru_seq_f32")
                 # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)
                 g_out = dout[lo:lo + n]
                 pre = hseq.sum(1) if reduce_sum else hseq

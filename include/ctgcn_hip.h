@@ -158,8 +158,8 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  * gi [rows, steps, 384] is the input projection x·W_ih^T + b_ih (+ b_hh for the r and z gates) in PyTorch's
  * gate order r,z,n — a plain GEMM the caller runs with its BLAS; w_hh [384,128] and b_hn [128] (the n-gate's
  * hidden bias, NULL = 0) are the module's weight_hh_l0 and bias_hh_l0[256:384].  ln_weight == NULL skips the
- * LayerNorm.  h_0 = 0.  split_bf16 == 0: exact fp32 (f32-input MFMA, an fmaf chain).  split_bf16 != 0 (honoured for
- * reduce_sum != 0, ignored otherwise): fp32-accurate split arithmetic on the bf16 matrix cores — operands split
+ * LayerNorm.  h_0 = 0.  split_bf16 == 0: exact fp32 (f32-input MFMA, an fmaf chain).  split_bf16 != 0:
+ * fp32-accurate split arithmetic on the bf16 matrix cores — operands split
  * exactly into three bf16 terms, six partial products, fp32 accumulation — about twice the matrix throughput.
  * gates_out (optional; requires reduce_sum == 0 and ln_weight == NULL): [rows, steps, 4, 128] receives r, z, n and
  * q = W_hn·h_{t-1} + b_hn for ctgcn_gru_seq_bwd_f32.

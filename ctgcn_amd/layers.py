@@ -50,10 +50,11 @@ def as_core_adj(adj_list, device):
     key = tuple((id(a), a._values().data_ptr() if a.is_sparse else a.data_ptr()) for a in adj_list) + (str(device),)
     hit = _adj_cache.get(key)
     if hit is None:
-        if len(_adj_cache) > 256:
+        if len(_adj_cache) > 64:
             _adj_cache.clear()
-        hit = _adj_cache[key] = CoreAdj.from_matrices(list(adj_list), device=device)
-    return hit
+        # the entry keeps the source tensors alive, so their ids cannot be recycled while the entry exists
+        hit = _adj_cache[key] = (CoreAdj.from_matrices(list(adj_list), device=device), list(adj_list))
+    return hit[0]
 
 
 _identity_cache = {}
@@ -61,19 +62,20 @@ _identity_cache = {}
 
 def _is_identity(sp_tensor):
     """True iff the sparse COO tensor is exactly the N x N identity (what get_feature_list builds for one-hot
-    node features).  Checked once per tensor (one small reduction + host read), then cached by identity."""
+    node features).  Checked once per tensor (one small reduction + host read), then cached by identity; the
+    cache entry holds the tensor, so its id cannot be recycled while the entry exists."""
     key = (id(sp_tensor), sp_tensor._values().data_ptr())
-    hit = _identity_cache.get(key)
-    if hit is None:
+    entry = _identity_cache.get(key)
+    if entry is None:
         n, m = sp_tensor.shape
         idx, val = sp_tensor._indices(), sp_tensor._values()
-        hit = bool(n == m and val.numel() == n and idx.shape[0] == 2
-                   and bool(((idx[0] == idx[1]) & (val == 1)).all())
-                   and bool((idx[0].sort().values == torch.arange(n, device=idx.device)).all()))
-        if len(_identity_cache) > 1024:
+        flag = bool(n == m and val.numel() == n and idx.shape[0] == 2
+                    and bool(((idx[0] == idx[1]) & (val == 1)).all())
+                    and bool((idx[0].sort().values == torch.arange(n, device=idx.device)).all()))
+        if len(_identity_cache) > 256:
             _identity_cache.clear()
-        _identity_cache[key] = hit
-    return hit
+        entry = _identity_cache[key] = (flag, sp_tensor)
+    return entry[0]
 
 
 class CoreDiffusion(nn.Module):

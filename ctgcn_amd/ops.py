@@ -210,7 +210,8 @@ def core_aggregate(x, adj, relu=True):
 
 
 # ------------------------------------------------------------- GRU over the core / time axis (+ sum, LayerNorm)
-_GI_MAX_ELEMS = 1 << 28          # fp32 elements of the input-projection buffer per row chunk (1 GiB)
+import os as _os
+_GI_MAX_ELEMS = int(_os.environ.get("CTGCN_GI_MAX_ELEMS", 1 << 28))   # fp32 elements of the projection buffer per row chunk (1 GiB)
 
 
 def gru_fused_ok(rnn, seq):

@@ -1046,7 +1046,8 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
     const int64_t ntiles = (a.rows + GRU_BM - 1) / GRU_BM;
     const int gstride = steps * 3 * GRU_H;
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile_ = blockIdx.x; tile_ < ntiles; tile_ += gridDim.x) {
+        const int64_t tile = ntiles - 1 - tile_;      // newest GI first: the projection kernel wrote the high tiles last
         const int64_t row0 = tile * GRU_BM;
         const float *gi_tile = a.gi + row0 * gstride + oc;
         const int last = (int)min((int64_t)GRU_BM, a.rows - row0) - 1;
@@ -1103,41 +1104,41 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
         };
         if (!REDUCE) emit_step(0);
 
-        // GI of (step, row tile) is loaded ONE TILE AHEAD of its use: a tile's MFMA phase (~0.6 us) is shorter than the
-        // HBM latency under load, the previous tile's whole body is not
-        f4v nr, nz, nn;
-        auto fetch = [&](int t, int rt) {
-            const float *p = gi_tile + t * 3 * GRU_H + goff(rt);
-            nr = *(const f4v *)p; nz = *(const f4v *)(p + GRU_H); nn = *(const f4v *)(p + 2 * GRU_H);
-        };
-        if (steps > 1) fetch(1, 0);
+        // Software pipeline over the row tiles of a step: the gate math of tile rt-1 (a ~100-instruction VALU block) is
+        // issued in the shadow of tile rt's MFMAs instead of stalling the matrix pipe behind them.
         for (int t = 1; t < steps; ++t) {
             const int pb = (t - 1) & 1, cb = t & 1;
+            const float *gi_t = gi_tile + t * 3 * GRU_H;
+            f4v acc[2][3], gq[2][3];
 #pragma unroll
-            for (int rt = 0; rt < GRU_RT; ++rt) {
-                const f4v gr = nr, gz = nz, gn = nn;
-                if (rt + 1 < GRU_RT) fetch(t, rt + 1);
-                else if (t + 1 < steps) fetch(t + 1, 0);
-                f4v acc[3];
+            for (int rt = 0; rt <= GRU_RT; ++rt) {
+                const int cur = rt & 1, prv = cur ^ 1;
+                if (rt < GRU_RT) {
+                    const float *p = gi_t + goff(rt);
+                    gq[cur][0] = *(const f4v *)p; gq[cur][1] = *(const f4v *)(p + GRU_H); gq[cur][2] = *(const f4v *)(p + 2 * GRU_H);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g] = zero4;
+                    for (int g = 0; g < 3; ++g) acc[cur][g] = zero4;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    bf8v af[3];          // MFMA B operand: B[k][n = row] = h_{t-1}[row rt*16 + col][k = c*32 + 8*grp + j]
+                    for (int c = 0; c < 4; ++c) {
+                        bf8v af[3];      // MFMA B operand: B[k][n = row] = h_{t-1}[row rt*16 + col][k = c*32 + 8*grp + j]
 #pragma unroll
-                    for (int sp = 0; sp < 3; ++sp) af[sp] = *(const bf8v *)(&Hs[pb][sp][rt * 16 + col][c * 32 + 8 * grp]);
+                        for (int sp = 0; sp < 3; ++sp) af[sp] = *(const bf8v *)(&Hs[pb][sp][rt * 16 + col][c * 32 + 8 * grp]);
 #define CTGCN_X3_MFMA(I, J)                                                                                              \
-                    _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                        \
-                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[J][c][g], af[I], acc[g], 0, 0, 0);
-                    CTGCN_X3_PAIRS(CTGCN_X3_MFMA)
+                        _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                    \
+                            acc[cur][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[J][c][g], af[I], acc[cur][g], 0, 0, 0);
+                        CTGCN_X3_PAIRS(CTGCN_X3_MFMA)
 #undef CTGCN_X3_MFMA
+                    }
                 }
-                const f4v h = gates(gr, gz, gn, acc[0], acc[1], acc[2], hreg[rt], t, rt * 16 + col);
-                hreg[rt] = h;
-                publish(cb, rt * 16 + col, h);
-                if (REDUCE) {
-                    f4v *sp_ = (f4v *)(&sbuf[rt * 16 + col][oc]);
-                    *sp_ = *sp_ + h;
+                if (rt > 0) {
+                    const int rp = rt - 1;
+                    const f4v h = gates(gq[prv][0], gq[prv][1], gq[prv][2], acc[prv][0], acc[prv][1], acc[prv][2], hreg[rp], t, rp * 16 + col);
+                    hreg[rp] = h;
+                    publish(cb, rp * 16 + col, h);
+                    if (REDUCE) {
+                        f4v *sp_ = (f4v *)(&sbuf[rp * 16 + col][oc]);
+                        *sp_ = *sp_ + h;
+                    }
                 }
             }
             __syncthreads();

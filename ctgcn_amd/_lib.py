@@ -32,6 +32,7 @@ SIGNATURES = {
     "ctgcn_edge_levels_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp, _int, _vp]),
+    "ctgcn_lstm_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp]),
     "ctgcn_gru_seq_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_input_proj_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_row_granule": (_i64, []),

@@ -1152,6 +1152,109 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// LSTM recurrence (rnn_type = 'LSTM', reference layers.py:27-28 / models.py:234-235), same fusion as the GRU:
+//   gates = GI_t + h_{t-1}·W_hhᵀ (order i,f,g,o; both biases are already in GI);  c_t = σ(f)·c_{t-1} + σ(i)·tanh(g);
+//   h_t = σ(o)·tanh(c_t);   out = LayerNorm(Σ_t h_t)  or  LayerNorm(h_t) per step.
+// Exact fp32 (v_mfma_f32_16x16x4_f32).  Wave w owns hidden units [16w,16w+16) of all four gates: 128 VGPRs of B
+// operands; 32 rows per block iteration; the cell state never leaves registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int LSTM_BM = 32;
+constexpr int LSTM_RT = LSTM_BM / 16;
+
+template <bool REDUCE>
+__global__ __launch_bounds__(512, 2) void lstm_seq_kernel(const GruArgs a)
+{
+    __shared__ float hbuf[2][LSTM_BM][GRU_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int hid = wave * 16 + col;
+    const int steps = a.steps;
+
+    float W[4][32];          // W[g][kk] = W_hh[g*128 + hid][32*grp + kk]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f4v *src = (const f4v *)(a.whh + (int64_t)(g * GRU_H + hid) * GRU_H + 32 * grp);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f4v v = src[q];
+            W[g][4 * q + 0] = v.x; W[g][4 * q + 1] = v.y; W[g][4 * q + 2] = v.z; W[g][4 * q + 3] = v.w;
+        }
+    }
+    const int64_t ntiles = (a.rows + LSTM_BM - 1) / LSTM_BM;
+    const int gstride = steps * 4 * GRU_H;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * LSTM_BM;
+        const float *gi_tile = a.gi + row0 * gstride + hid;
+        const int last = (int)min((int64_t)LSTM_BM, a.rows - row0) - 1;
+        float creg[LSTM_RT][4], hsum[LSTM_RT][4];
+#pragma unroll
+        for (int rt = 0; rt < LSTM_RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { creg[rt][i] = 0.f; hsum[rt][i] = 0.f; }
+
+        for (int t = 0; t < steps; ++t) {
+            const float(*hprev)[GRU_PITCH] = hbuf[(t - 1) & 1];
+            float(*hcur)[GRU_PITCH] = hbuf[t & 1];
+#pragma unroll
+            for (int rt = 0; rt < LSTM_RT; ++rt) {
+                float gi[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float *p = gi_tile + min(rt * 16 + grp * 4 + i, last) * gstride + t * 4 * GRU_H;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) gi[g][i] = p[g * GRU_H];
+                }
+                f4v acc[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = f4v{0.f, 0.f, 0.f, 0.f};
+                if (t > 0) {
+                    float av[32];
+                    const f4v *src = (const f4v *)(&hprev[rt * 16 + col][32 * grp]);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f4v v = src[q];
+                        av[4 * q + 0] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 32; ++kk)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], W[g][kk], acc[g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float ig = gru_sigmoid(gi[0][i] + acc[0][i]);
+                    const float fg = gru_sigmoid(gi[1][i] + acc[1][i]);
+                    const float gg = gru_tanh(gi[2][i] + acc[2][i]);
+                    const float og = gru_sigmoid(gi[3][i] + acc[3][i]);
+                    const float c = fg * creg[rt][i] + ig * gg;
+                    const float h = og * gru_tanh(c);
+                    creg[rt][i] = c;
+                    hsum[rt][i] += h;
+                    hcur[rt * 16 + grp * 4 + i][hid] = h;
+                }
+            }
+            __syncthreads();
+            if (!REDUCE)
+                for (int r = wave; r <= last; r += 8)
+                    gru_layernorm_row(hcur[r], a.out + ((row0 + r) * steps + t) * GRU_H, lane, a.gamma, a.beta, a.eps);
+        }
+        if (REDUCE) {
+            float(*sbuf)[GRU_PITCH] = hbuf[steps & 1];
+#pragma unroll
+            for (int rt = 0; rt < LSTM_RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sbuf[rt * 16 + grp * 4 + i][hid] = hsum[rt][i];
+            __syncthreads();
+            for (int r = wave; r <= last; r += 8)
+                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward of the GRU recurrence (what autograd derives for nn.GRU at layers.py:59 / models.py:249).
 // Walks t = steps-1 .. 0 with dh = dh_seq[t] (or the broadcast dh_sum) + the recurrent term carried in registers:
 //   dn = dh(1-z); dz = dh(h_{t-1}-n); da_n = dn(1-n²); da_z = dz z(1-z); da_r = da_n q r(1-r)
@@ -1541,6 +1644,31 @@ int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const f
     const int64_t ntiles = (rows + PJ_BM - 1) / PJ_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;
     hipLaunchKernelGGL(gru_proj_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
+                       const float *ln_weight, const float *ln_bias, float ln_eps, int reduce_sum, float *out,
+                       void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "lstm_seq: hidden=%d, only %d is built", hidden, GRU_H);
+    if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "lstm_seq: bad sizes");
+    if (rows == 0) return CTGCN_OK;
+    if (!gi || !w_hh || !out) return fail(CTGCN_E_INVALID, "lstm_seq: null pointer");
+    if (!aligned16(w_hh) || (reinterpret_cast<uintptr_t>(out) & 7u)) return fail(CTGCN_E_INVALID, "lstm_seq: w_hh must be 16-byte aligned, out 8-byte aligned");
+    GruArgs a{};
+    a.rows = rows; a.steps = steps; a.gi = gi; a.whh = w_hh; a.bhn = nullptr; a.gamma = ln_weight; a.beta = ln_bias;
+    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = nullptr;
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t ntiles = (rows + LSTM_BM - 1) / LSTM_BM;
+    const int64_t blocks = ntiles < cus ? ntiles : cus;
+    if (a.reduce_sum)
+        hipLaunchKernelGGL(lstm_seq_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(lstm_seq_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

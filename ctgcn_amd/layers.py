@@ -16,10 +16,13 @@ _RNN_MAX_ELEMS = 1 << 29     # MIOpen's RNN indexes its gate workspace with 32-b
 
 
 def rnn_reduce_norm(rnn, norm, seq, reduce_sum):
-    """norm(rnn(seq).sum(1)) or norm(rnn(seq)).  Inference with the standard GRU(hidden=128) runs the fused HIP
-    recurrent kernel; everything else (training, LSTM, other widths) goes through the PyTorch-ROCm modules."""
+    """norm(rnn(seq).sum(1)) or norm(rnn(seq)).  GRU(hidden=128): fused HIP kernels, forward and backward.
+    LSTM(hidden=128): fused HIP recurrence for inference.  Everything else (other widths, LSTM training) goes through
+    the PyTorch-ROCm modules."""
     if ops.gru_fused_ok(rnn, seq):
         return ops.gru_sequence(rnn, seq, norm, reduce_sum)
+    if ops.lstm_fused_ok(rnn, seq):
+        return ops.lstm_sequence(rnn, seq, norm, reduce_sum)
     return norm(rnn_over_rows(rnn, seq, reduce_sum))
 
 

@@ -386,6 +386,44 @@ class _GruSeq(torch.autograd.Function):
         return dseq, dw_ih, dw_hh, db_ih, db_hh, dln_w, dln_b, None, None
 
 
+def lstm_fused_ok(rnn, seq):
+    """Fused LSTM recurrence: inference only, hidden 128, single layer, batch_first, fp32 CUDA."""
+    needs_grad = torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in rnn.parameters()))
+    return (isinstance(rnn, torch.nn.LSTM) and rnn.hidden_size == 128 and rnn.num_layers == 1 and not rnn.bidirectional
+            and rnn.batch_first and getattr(rnn, "proj_size", 0) == 0 and seq.is_cuda and seq.dtype == torch.float32
+            and not needs_grad)
+
+
+def lstm_sequence(rnn, seq, norm, reduce_sum):
+    """LayerNorm(sum_t LSTM(seq)_t) / LayerNorm(LSTM(seq)) with the recurrence in ctgcn_lstm_seq_f32 (inference)."""
+    lib = _lib.load()
+    rows, steps, d_in = seq.shape
+    hid = rnn.hidden_size
+    seq = seq.contiguous()
+    w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous()
+    bias = (rnn.bias_ih_l0.detach() + rnn.bias_hh_l0.detach()) if rnn.bias else None
+    out = torch.empty((rows, hid) if reduce_sum else (rows, steps, hid), dtype=torch.float32, device=seq.device)
+    if rows == 0:
+        return out
+    chunks = _row_chunks(lib, rows, steps, hid)
+    gi_buf = torch.empty(chunks[0][1] * steps, 4 * hid, dtype=torch.float32, device=seq.device)
+    ln_w = None if norm is None else norm.weight
+    ln_b = None if norm is None else norm.bias
+    eps = 0.0 if norm is None else float(norm.eps)
+    with torch.cuda.device(seq.device):
+        for lo, n in chunks:
+            gi = gi_buf[: n * steps]
+            x2d = seq[lo:lo + n].reshape(n * steps, d_in)
+            if bias is None:
+                torch.mm(x2d, w_ih.t(), out=gi)
+            else:
+                torch.addmm(bias, x2d, w_ih.t(), out=gi)
+            with _timed("lstm_seq", rows=n, steps=steps):
+                check(lib.ctgcn_lstm_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh), ptr(ln_w), ptr(ln_b), eps, 1 if reduce_sum else 0,
+                                             ptr(out[lo:lo + n]), _stream()), "ctgcn_lstm_seq_f32")
+    return out
+
+
 def gru_sequence(rnn, seq, norm, reduce_sum):
     """LayerNorm(sum_t GRU(seq)_t) (reduce_sum) or LayerNorm(GRU(seq)) — layers.py:59-62 / models.py:249-250.
     seq [rows, steps, d_in].  The input projection is a hipBLASLt GEMM; the recurrence, the sum over steps and the

@@ -169,6 +169,15 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
                       int reduce_sum, float *out, float *gates_out, int split_bf16, void *stream);
 
 /*
+ * The same for nn.LSTM (rnn_type = 'LSTM'; layers.py:27-28, models.py:234-235): gi [rows, steps, 512] = x·W_ih^T + b_ih
+ * + b_hh in PyTorch's gate order i,f,g,o; w_hh [512, 128]; h_0 = c_0 = 0.  Exact fp32 (f32-input MFMA).
+ * Inference only (no backward entry point: training goes through the framework's LSTM).
+ */
+int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
+                       const float *ln_weight, const float *ln_bias, float ln_eps, int reduce_sum, float *out,
+                       void *stream);
+
+/*
  * Backward of the recurrence above (autograd of nn.GRU, layers.py:59 / models.py:249).  Inputs: the saved gates and
  * the raw h sequence h_seq [rows, steps, 128]; the upstream gradient per step dh_seq [rows, steps, 128] and/or one
  * gradient dh_sum [rows, 128] added at every step (the .sum(dim=1) case).  Outputs, for the caller's GEMMs:

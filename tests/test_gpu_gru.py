@@ -139,3 +139,26 @@ def test_split_bf16_projection_is_fp32_accurate(rows):
     out2 = torch.empty(rows, 384, device=DEV)
     ops._project(x.to(DEV), w.to(DEV), None, out2)
     assert torch.allclose(out2.cpu() + b, out.cpu(), atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,steps,d_in,reduce_sum,bias", [
+    (1, 1, 128, True, True), (100, 8, 128, True, True), (1000, 5, 300, False, True), (4100, 12, 64, True, False),
+])
+def test_fused_lstm_matches_torch(rows, steps, d_in, reduce_sum, bias):
+    from ctgcn_amd import layers, ops
+    torch.manual_seed(rows * 3 + steps)
+    rnn = torch.nn.LSTM(d_in, 128, 1, bias=bias, batch_first=True)
+    norm = torch.nn.LayerNorm(128)
+    with torch.no_grad():
+        norm.weight.uniform_(0.5, 1.5)
+        norm.bias.uniform_(-0.5, 0.5)
+    x = torch.relu(torch.randn(rows, steps, d_in)) * 2.0
+    want = _ref(rnn, norm, x, reduce_sum)
+    rnn_d, norm_d = rnn.to(DEV), norm.to(DEV)
+    with torch.no_grad():
+        assert ops.lstm_fused_ok(rnn_d, x.to(DEV))
+        got = layers.rnn_reduce_norm(rnn_d, norm_d, x.to(DEV), reduce_sum)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    # with gradients enabled the framework LSTM runs (and agrees)
+    got_train = layers.rnn_reduce_norm(rnn_d, norm_d, x.to(DEV).requires_grad_(True), reduce_sum)
+    np.testing.assert_allclose(got_train.detach().cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(_HERE, "csrc", f) for f in ("ctgcn_hip.hip", "ctgcn_ingest.hip")]
+SRCS = [os.path.join(_HERE, "csrc", f) for f in ("ctgcn_hip.hip", "ctgcn_ingest.hip", "ctgcn_export.cpp")]
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctgcn_hip.h")
 OUT = os.path.join(_HERE, "csrc", "libctgcn_hip.so")
 
@@ -14,7 +14,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT] + SRCS
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", OUT] + SRCS
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

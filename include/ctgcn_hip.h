@@ -201,6 +201,17 @@ int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const f
  * chunks should use multiples of this so that every launch keeps all CUs equally busy. */
 int64_t ctgcn_gru_row_granule(void);
 
+/*
+ * HOST function (no GPU work): write one snapshot's embedding [n, d] float32 (host pointer, leading dimension ld) as
+ * the text file pandas produces for the reference's save_embedding, embedding.py:79-89
+ * (pd.DataFrame(data, index=names).to_csv(path, sep=sep, header=True, index=True)), byte for byte: numpy float32
+ * shortest-repr formatting, NaN as an empty field, minimal quoting of names.  names_blob_host holds the n
+ * NUL-terminated node names, name_offsets_host[i] is the offset of name i.  threads <= 0: all host threads.
+ */
+int ctgcn_write_embedding_tsv(const char *path_host, int64_t n, int32_t d, const float *data_host, int64_t ld,
+                              const char *names_blob_host, const int64_t *name_offsets_host, char sep,
+                              int32_t threads);
+
 size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t K);
 
 #ifdef __cplusplus

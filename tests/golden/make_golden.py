@@ -19,6 +19,7 @@ Outputs
                          k-core files, loader outputs, CoreDiffusion fwd/bwd
   models_uci.npz         CGCN-C/S and CTGCN-C/S forward (+ input grads) on UCI
   toy_kcore.npz          hand-sized k-core known answers
+  export_tsv.npz         bytes of the file the reference's save_embedding writes for a crafted embedding
 """
 import os
 import shutil
@@ -317,8 +318,41 @@ def gen_toy():
     np.savez_compressed(os.path.join(OUT, "toy_kcore.npz"), **d)
 
 
+# ------------------------------------------------------------------ embedding export
+def gen_export():
+    """Runs the reference trainer's save_embedding (embedding.py:79-89) on values that exercise every formatting branch
+    and stores the bytes of the file it writes."""
+    import embedding as ref_embedding
+    rng = np.random.default_rng(11)
+    n, dcols = 300, 9
+    emb = rng.standard_normal((n, dcols)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -2.0, 0.1, 123456.789, 1e-5, 1.5e-5, 1e-4, 9.999e-5, 1.0001e-4, 1e15, 1e16, 1.234e20, 3.4e38,
+                        1e-38, 1e-45, np.nan, np.inf, -np.inf, 16777216.0, 9999999.0, 99999.99, 0.30000001192092896, 5e-324,
+                        2.5, 1e7, 1.17549435e-38, 65504.0, -7.0e-10], dtype=np.float32)
+    emb.reshape(-1)[: len(special)] = special
+    emb[50] = emb[50] * 1e-6
+    emb[51] = emb[51] * 1e18
+    emb[52] = np.round(emb[52] * 100)
+    names = ["U%d" % i for i in range(n)]
+    names[3], names[4], names[5] = "tab\there", 'quo"te', "plain name"
+    tmp = tempfile.mkdtemp(prefix="golden_export_")
+    try:
+        obj = ref_embedding.BaseEmbedding.__new__(ref_embedding.BaseEmbedding)
+        obj.timestamp_list = ["2004-04.csv", "2004-05.csv"]
+        obj.full_node_list = names
+        obj.embedding_base_path = tmp
+        obj.file_sep = "\t"
+        obj.save_embedding([torch.from_numpy(emb)], 1)
+        data = open(os.path.join(tmp, "2004-05.csv"), "rb").read()
+    finally:
+        shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(OUT, "export_tsv.npz"), emb=emb, names=np.array(names),
+                        file_bytes=np.frombuffer(data, dtype=np.uint8))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    gen_export()
     gen_toy()
     gen_weighted_small()
     gen_uci()

@@ -209,3 +209,36 @@ def test_synthetic_generator_is_seeded_and_cumulative():
     for small, big in zip(a[:-1], a[1:]):          # snapshot i is a prefix of snapshot i+1 (graph.py:101-108)
         assert (small.multiply(big) != small).nnz == 0
     assert (a[-1] != a[-1].T).nnz == 0 and a[-1].diagonal().sum() == 0
+
+
+# ------------------------------------------------------------------------------------- embedding export
+def test_embedding_export_is_byte_identical_to_reference(tmp_path):
+    """ctgcn_write_embedding_tsv (host C++, std::to_chars) vs the bytes the reference's save_embedding (pandas) wrote."""
+    from ctgcn_amd import export
+    g = load_golden("export_tsv.npz")
+    names = [str(x) for x in g["names"]]
+    want = bytes(g["file_bytes"])
+    for threads in (1, 3, 0):
+        path = tmp_path / ("out%d.csv" % threads)
+        export.write_embedding(str(path), g["emb"], names, sep="\t", threads=threads)
+        got = path.read_bytes()
+        assert got == want, (threads, len(got), len(want))
+    # the trainer-shaped entry point: one file per snapshot, named after the timestamp
+    export.save_embedding(torch.from_numpy(g["emb"])[None], ["a.csv", "2004-05.csv"], 1, str(tmp_path / "emb"), names)
+    assert (tmp_path / "emb" / "2004-05.csv").read_bytes() == want
+
+
+def test_embedding_export_float_formatting_sweep(tmp_path):
+    """numpy prints a float32 the same way pandas writes it: sweep magnitudes, signs and random mantissas."""
+    from ctgcn_amd import export
+    rng = np.random.default_rng(0)
+    bits = rng.integers(0, 2 ** 32, size=20000, dtype=np.uint64).astype(np.uint32)
+    vals = bits.view(np.float32).copy()
+    vals = vals[np.isfinite(vals)][:16384].reshape(-1, 8)
+    names = ["n%d" % i for i in range(len(vals))]
+    path = tmp_path / "sweep.tsv"
+    export.write_embedding(str(path), vals, names)
+    lines = path.read_text().split("\n")[1:-1]
+    assert len(lines) == len(vals)
+    for row, line in zip(vals[::37], lines[::37]):
+        assert line.split("\t")[1:] == [str(v) for v in row]

@@ -36,6 +36,9 @@ SIGNATURES = {
     "ctgcn_gru_seq_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_input_proj_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_row_granule": (_i64, []),
+    "ctgcn_row_cumsum_f32": (_int, [_i64, _vp, _vp, _vp, _vp]),
+    "ctgcn_random_walk_pairs": (_int, [_i64, _vp, _vp, _vp, _i32, _i32, _i32, _c.c_uint64, _int, _vp, _vp, _vp, _vp]),
+    "ctgcn_neg_sampling_indices": (_int, [_i64, _vp, _vp, _vp, _i32, _i64, _vp, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctgcn_write_embedding_tsv": (_int, [_c.c_char_p, _i64, _i32, _vp, _i64, _c.c_char_p, _vp, _c.c_char, _i32]),
     "ctgcn_workspace_bytes": (_sz, [_int, _i64, _i64, _i32, _i32]),
 }

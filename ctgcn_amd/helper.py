@@ -79,6 +79,30 @@ class DataLoader(object):
             cores.append(core)
         return (window, cores) if return_core_numbers else window
 
+    # ------------------------------------------------------------ negative-sampling inputs (helper.py:26-49)
+    def get_node_pair_list(self, walk_pair_base_path, start_idx, duration):
+        """Per snapshot the co-occurrence partners of every node, read from the reference's `<snapshot>.npz` files, as
+        device-resident WalkPairs (list-like: len() == N, [i] -> partner list)."""
+        from .walks import WalkPairs
+        files = sorted(os.listdir(walk_pair_base_path))
+        out = []
+        for i in self._window(start_idx, duration):
+            m = sp.load_npz(os.path.join(walk_pair_base_path, files[i])).tocsr()
+            m.sort_indices()
+            out.append(WalkPairs(torch.from_numpy(m.indptr.astype(np.int32)).to(self.device),
+                                 torch.from_numpy(m.indices.astype(np.int32)).to(self.device)))
+        return out
+
+    def get_node_freq_list(self, node_freq_base_path, start_idx, duration):
+        """Per snapshot the negative table (`<snapshot>.json`), as an int32 tensor on the loader's device."""
+        import json
+        files = sorted(os.listdir(node_freq_base_path))
+        out = []
+        for i in self._window(start_idx, duration):
+            with open(os.path.join(node_freq_base_path, files[i]), 'r') as fp:
+                out.append(torch.tensor(json.load(fp), dtype=torch.int32, device=self.device))
+        return out
+
     # --------------------------------------------------- thin plumbing kept for reference-shaped drivers
     def get_date_adj_list(self, origin_base_path, start_idx, duration, sep='\t', normalize=False, row_norm=False,
                           add_eye=False, data_type='tensor'):

@@ -202,6 +202,33 @@ int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const f
 int64_t ctgcn_gru_row_granule(void);
 
 /*
+ * Random-walk corpus (preprocessing/random_walk.py:8-69).  ctgcn_row_cumsum_f32: cumw[e] = inclusive prefix sum of the
+ * weights within each CSR row.  ctgcn_random_walk_pairs: `walk_time` walks of walk_length steps from EVERY node (walk
+ * indices first_walk .. first_walk+walk_time-1 of the seed's stream); next hop drawn with probability proportional to
+ * the edge weight (weighted != 0) or uniformly; a walk stops at a node without neighbours.  For every walk the
+ * (L+1)·L/2 position pairs i < j are written to pair_src/pair_dst (capacity n·walk_time·(L+1)·L/2; pairs with equal
+ * endpoints or beyond the end of a short walk are written as the self pair (0,0), which ctgcn_edges_to_csr drops) and
+ * freq[a]++, freq[b]++ (int64[n], caller-zeroed) for every emitted pair — the reference's node_freq_arr.
+ * Feeding the pairs to ctgcn_edges_to_csr (w = NULL) yields the reference's symmetric 0/1 walk_spadj.
+ */
+int ctgcn_row_cumsum_f32(int64_t n, const int32_t *row_ptr, const float *val, float *cumw, void *stream);
+int ctgcn_random_walk_pairs(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, const float *cumw,
+                            int32_t walk_length, int32_t walk_time, int32_t first_walk, uint64_t seed, int weighted,
+                            int32_t *pair_src, int32_t *pair_dst, int64_t *freq, void *stream);
+
+/*
+ * Index draws of the negative-sampling loss (metrics.py:62-93).  For batch node b (batch_nodes[b], int64): all of its
+ * walk partners (row of the pair CSR) if there are at most `num`, else `num` of them uniformly without replacement;
+ * written at node_out/pos_out[offsets[b] ...] where offsets = exclusive scan of min(deg, num) (caller computes it).
+ * neg_out[num]: the table entries at `num` distinct uniformly drawn positions of neg_table (random.sample semantics).
+ * scratch: int64[num].
+ */
+int ctgcn_neg_sampling_indices(int64_t batch, const int64_t *batch_nodes, const int32_t *pair_row_ptr,
+                               const int32_t *pair_col, int32_t num, int64_t table_len, const int32_t *neg_table,
+                               uint64_t seed, const int64_t *offsets, int64_t *node_out, int64_t *pos_out,
+                               int64_t *neg_out, int64_t *scratch, void *stream);
+
+/*
  * HOST function (no GPU work): write one snapshot's embedding [n, d] float32 (host pointer, leading dimension ld) as
  * the text file pandas produces for the reference's save_embedding, embedding.py:79-89
  * (pd.DataFrame(data, index=names).to_csv(path, sep=sep, header=True, index=True)), byte for byte: numpy float32

@@ -205,3 +205,55 @@ def core_aggregate_bwd(adj_list, x, dH):
 def aggregated_edges(adj_list):
     """BASELINE metric numerator for one CoreDiffusion call: sum_k nnz(A_k)."""
     return int(sum(sp.csr_matrix(a).nnz for a in adj_list))
+
+
+# ----------------------------------------------------------------- random-walk corpus (SURVEY §8f rank 3)
+def negative_table(freq):
+    """preprocessing/random_walk.py:54-60, scalar loop as written there: node i repeated int(((f_i / tot)**0.75) / Z) times."""
+    freq = np.asarray(freq, dtype=np.int64)
+    tot = freq.sum()
+    out = []
+    for i in range(len(freq)):
+        out += [i] * int(((freq[i] / tot) ** 0.75) / 0.00001)
+    return np.array(out, dtype=np.int64)
+
+
+def matching_walk_outputs(adj, walk_length, walk_time):
+    """Exact outputs of preprocessing/random_walk.py:8-69 on a graph where every non-isolated node has exactly one
+    neighbour (walks are then deterministic): (pair matrix CSR, node frequencies)."""
+    adj = sp.csr_matrix(adj)
+    n = adj.shape[0]
+    freq = np.zeros(n, dtype=np.int64)
+    rows, cols = [], []
+    L1 = walk_length + 1
+    for v in range(n):
+        nb = adj.indices[adj.indptr[v]:adj.indptr[v + 1]]
+        assert len(nb) <= 1
+        if len(nb) == 0:
+            continue
+        walk = [v if i % 2 == 0 else int(nb[0]) for i in range(L1)]
+        for _ in range(walk_time):
+            for i in range(L1):
+                for j in range(i + 1, L1):
+                    if walk[i] != walk[j]:
+                        rows += [walk[i], walk[j]]; cols += [walk[j], walk[i]]
+                        freq[walk[i]] += 1; freq[walk[j]] += 1
+    m = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n))
+    m.data[:] = 1.0
+    m.sum_duplicates(); m.data[:] = 1.0
+    m.sort_indices()
+    return m, freq
+
+
+def neg_sampling_loss(emb_list, node_idx_list, pos_idx_list, neg_idx_list, Q):
+    """metrics.py:38-60 given the drawn indices: sum over snapshots of BCE(pos,1) + Q * BCE(neg,0), shape [1]."""
+    import torch
+    bce = torch.nn.BCEWithLogitsLoss()
+    loss = torch.zeros(1)
+    for emb, ni, pi, gi in zip(emb_list, node_idx_list, pos_idx_list, neg_idx_list):
+        if ni is None or len(ni) == 0:
+            continue
+        pos = torch.sum(emb[ni].mul(emb[pi]), dim=1)
+        neg = torch.sum(emb[ni].matmul(emb[gi].t()), dim=1)
+        loss = loss + bce(pos, torch.ones_like(pos)) + Q * bce(neg, torch.zeros_like(neg))
+    return loss

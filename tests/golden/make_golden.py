@@ -20,6 +20,8 @@ Outputs
   models_uci.npz         CGCN-C/S and CTGCN-C/S forward (+ input grads) on UCI
   toy_kcore.npz          hand-sized k-core known answers
   export_tsv.npz         bytes of the file the reference's save_embedding writes for a crafted embedding
+  negloss.npz            reference random_walk outputs (deterministic matching graph; seeded UCI statistics) and a
+                         NegativeSamplingLoss value + gradients on a draw-independent configuration
 """
 import os
 import shutil
@@ -350,8 +352,77 @@ def gen_export():
                         file_bytes=np.frombuffer(data, dtype=np.uint8))
 
 
+# --------------------------------------------------- random-walk corpus + negative-sampling loss
+def gen_negloss():
+    import json
+    import preprocessing.random_walk as ref_rw
+    import metrics as ref_metrics
+    d = {}
+    # (1) a graph on which the reference's walks are deterministic: a perfect matching (every node has ONE neighbour)
+    #     plus isolated nodes; weights arbitrary.  walk = a,b,a,b,...  -> pairs and frequencies are exact.
+    n, L, W = 40, 5, 7
+    a = np.arange(0, 30, 2)
+    w = np.linspace(0.5, 3.0, len(a))
+    adj = sp.coo_matrix((np.concatenate([w, w]), (np.concatenate([a, a + 1]), np.concatenate([a + 1, a]))), shape=(n, n))
+    tmp = tempfile.mkdtemp(prefix="golden_walk_")
+    try:
+        os.makedirs(os.path.join(tmp, "pairs")); os.makedirs(os.path.join(tmp, "freq"))
+        old = sys.stdout; sys.stdout = open(os.devnull, "w")
+        try:
+            ref_rw.random_walk(adj, os.path.join(tmp, "pairs"), os.path.join(tmp, "freq"), "m.csv", L, W, True)
+        finally:
+            sys.stdout = old
+        m = sp.load_npz(os.path.join(tmp, "pairs", "m.npz")).tocsr(); m.sort_indices()
+        put_csr(d, "match_adj", adj.tocsr()); put_csr(d, "match_pairs", m)
+        d["match_neg"] = np.array(json.load(open(os.path.join(tmp, "freq", "m.json"))), dtype=np.int64)
+        d["match_LW"] = np.array([L, W])
+        # (2) distribution reference on a real snapshot (UCI 2004-10, the smallest): seeded numpy RNG, 10 walks per node
+        names = [l.strip() for l in open(os.path.join(REF, "data", "uci", "nodes_set", "nodes.csv")) if l.strip()]
+        uci = ref_utils.get_sp_adj_mat(os.path.join(REF, "data", "uci", "1.format", "2004-10.csv"), names, sep="\t")
+        np.random.seed(12345)
+        sys.stdout = open(os.devnull, "w")
+        try:
+            ref_rw.random_walk(uci, os.path.join(tmp, "pairs"), os.path.join(tmp, "freq"), "u.csv", 5, 10, True)
+        finally:
+            sys.stdout = old
+        mu = sp.load_npz(os.path.join(tmp, "pairs", "u.npz")).tocsr()
+        neg = np.array(json.load(open(os.path.join(tmp, "freq", "u.json"))), dtype=np.int64)
+        d["uci_pairs_nnz"] = np.int64(mu.nnz)
+        d["uci_pairs_rowcount"] = np.diff(mu.indptr).astype(np.int32)
+        d["uci_neg_counts"] = np.bincount(neg, minlength=len(names)).astype(np.int32)
+    finally:
+        shutil.rmtree(tmp)
+    # (3) the loss on a configuration whose draws are deterministic: every partner list <= neg_num (all are taken) and
+    #     a negative table of exactly neg_num entries (random.sample returns a permutation; the score sums are invariant)
+    rng = np.random.default_rng(3)
+    n2, T, dim, neg_num, Q = 60, 2, 16, 5, 7
+    pair_lists, tables = [], []
+    for t in range(T):
+        rows = np.empty(n2, dtype=object)
+        for i in range(n2):
+            k = int(rng.integers(0, neg_num + 1))
+            rows[i] = sorted(rng.choice(n2, size=k, replace=False).tolist())
+        pair_lists.append(rows)
+        tables.append(rng.choice(n2, size=neg_num, replace=False).tolist())
+    emb = [torch.from_numpy(rng.standard_normal((n2, dim)).astype(np.float32)).requires_grad_(True) for _ in range(T)]
+    batch = torch.from_numpy(rng.choice(n2, size=25, replace=False).astype(np.int64))
+    loss = ref_metrics.NegativeSamplingLoss(pair_lists, tables, neg_num=neg_num, Q=Q)([emb, batch])
+    loss.backward()
+    d["loss_value"] = loss.detach().numpy()
+    d["loss_batch"] = batch.numpy()
+    d["loss_cfg"] = np.array([n2, T, dim, neg_num, Q])
+    for t in range(T):
+        d["loss_emb%d" % t] = emb[t].detach().numpy()
+        d["loss_grad%d" % t] = emb[t].grad.numpy()
+        d["loss_table%d" % t] = np.array(tables[t], dtype=np.int64)
+        d["loss_pairs%d_len" % t] = np.array([len(r) for r in pair_lists[t]], dtype=np.int32)
+        d["loss_pairs%d_flat" % t] = np.array([c for r in pair_lists[t] for c in r], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "negloss.npz"), **d)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    gen_negloss()
     gen_export()
     gen_toy()
     gen_weighted_small()

@@ -242,3 +242,18 @@ def test_embedding_export_float_formatting_sweep(tmp_path):
     assert len(lines) == len(vals)
     for row, line in zip(vals[::37], lines[::37]):
         assert line.split("\t")[1:] == [str(v) for v in row]
+
+
+def test_negative_table_matches_reference_formula():
+    """vectorised negative_table == the reference's scalar loop (oracle), incl. on the golden deterministic case."""
+    from ctgcn_amd.walks import negative_table
+    from oracle import oracle as O
+    g = load_golden("negloss.npz")
+    n = len(g["match_adj_indptr"]) - 1
+    _, freq = O.matching_walk_outputs(csr_from(g, "match_adj", n), *[int(x) for x in g["match_LW"]])
+    assert np.array_equal(negative_table(freq), g["match_neg"])
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        f = rng.integers(0, 5000, 400) * (rng.random(400) < 0.8)
+        assert np.array_equal(negative_table(f), O.negative_table(f))
+    assert len(negative_table(np.zeros(7, dtype=np.int64))) == 0

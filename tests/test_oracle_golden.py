@@ -155,3 +155,36 @@ def test_models_match_reference_outputs():
     np.testing.assert_allclose(torch.stack(tr).numpy(), g["cgcn_s_trans"], **tol)
     out = TP.cgcn(_sd(g, "cgcn_c_single_"), xd[0], adj[0], "GRU", "C", "N")
     np.testing.assert_allclose(out.numpy(), g["cgcn_c_single_out"], **tol)
+
+
+# ------------------------------------------------------------------ random walks / negative sampling (§8f rank 3)
+def test_walk_corpus_oracle_matches_reference_on_deterministic_graph():
+    g = load_golden("negloss.npz")
+    n = len(g["match_adj_indptr"]) - 1
+    adj = csr_from(g, "match_adj", n)
+    L, W = [int(x) for x in g["match_LW"]]
+    pairs, freq = O.matching_walk_outputs(adj, L, W)
+    _same_csr(pairs, csr_from(g, "match_pairs", n))
+    assert np.array_equal(O.negative_table(freq), g["match_neg"])
+
+
+def test_neg_sampling_loss_oracle_matches_reference():
+    g = load_golden("negloss.npz")
+    n2, T, dim, neg_num, Q = [int(x) for x in g["loss_cfg"]]
+    batch = g["loss_batch"]
+    embs, ni, pi, gi = [], [], [], []
+    for t in range(T):
+        lens, flat = g["loss_pairs%d_len" % t], g["loss_pairs%d_flat" % t]
+        ptr = np.concatenate([[0], np.cumsum(lens)])
+        nodes, pos = [], []
+        for b in batch:
+            part = flat[ptr[b]:ptr[b + 1]]
+            nodes += [b] * len(part); pos += part.tolist()
+        embs.append(torch.from_numpy(g["loss_emb%d" % t]).requires_grad_(True))
+        ni.append(torch.tensor(nodes, dtype=torch.int64)); pi.append(torch.tensor(pos, dtype=torch.int64))
+        gi.append(torch.from_numpy(g["loss_table%d" % t]))
+    loss = O.neg_sampling_loss(embs, ni, pi, gi, Q)
+    np.testing.assert_allclose(loss.detach().numpy(), g["loss_value"], rtol=1e-5)
+    loss.backward()
+    for t in range(T):
+        np.testing.assert_allclose(embs[t].grad.numpy(), g["loss_grad%d" % t], rtol=1e-4, atol=1e-6)

@@ -15,12 +15,10 @@ Extra objects on the JSON line:
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

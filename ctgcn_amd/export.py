@@ -1,7 +1,6 @@
 """Embedding export with the reference's file contract (reference embedding.py:79-89, consumed by evaluation/*.py,
 e.g. link_prediction.py:126-143): one `<timestamp>.csv` per snapshot, index = node names, header = 0..d-1, sep = '\\t',
 written by the library's multi-threaded host formatter instead of pandas (byte-identical output)."""
-import ctypes
 import os
 
 import numpy as np

@@ -13,7 +13,7 @@ import scipy.sparse as sp
 import torch
 
 from .core_adj import CoreAdj
-from .utils import get_sp_adj_mat, read_edge_rows, symmetric_csr_from_rows
+from .utils import get_sp_adj_mat, read_edge_rows
 
 
 class DataLoader(object):

@@ -6,7 +6,6 @@ test is the sharding plan, the exchange collectives and their autograd, not the 
 import os
 import sys
 
-import numpy as np
 import torch
 import torch.distributed as dist
 

@@ -4,7 +4,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from conftest import load_golden, csr_from, close_scaled, formula_tensor
+from conftest import load_golden, csr_from, close_scaled
 
 pytestmark = pytest.mark.gpu
 

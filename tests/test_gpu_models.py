@@ -7,7 +7,7 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from conftest import load_golden, csr_from, close_scaled, formula_tensor
+from conftest import load_golden, csr_from, formula_tensor
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

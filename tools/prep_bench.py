@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ctgcn_amd import CoreAdj, ops  # noqa: E402
+from ctgcn_amd import ops  # noqa: E402
 from ctgcn_amd.core_adj import slot_table  # noqa: E402
 from ctgcn_amd.synth import powerlaw_edges, prefix_sizes  # noqa: E402
 

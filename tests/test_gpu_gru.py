@@ -162,3 +162,21 @@ def test_fused_lstm_matches_torch(rows, steps, d_in, reduce_sum, bias):
     # with gradients enabled the framework LSTM runs (and agrees)
     got_train = layers.rnn_reduce_norm(rnn_d, norm_d, x.to(DEV).requires_grad_(True), reduce_sum)
     np.testing.assert_allclose(got_train.detach().cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_split_bf16_projection_wide_dynamic_range():
+    """operands spanning 10 orders of magnitude (and exact zeros / negatives): the 3-way split keeps fp32 accuracy."""
+    from ctgcn_amd import ops
+    torch.manual_seed(5)
+    rows = 4096
+    mag = 10.0 ** torch.empty(rows, 128).uniform_(-6, 4)
+    x = mag * torch.sign(torch.randn(rows, 128)) * (torch.rand(rows, 128) > 0.1)
+    w = (10.0 ** torch.empty(384, 128).uniform_(-4, 0)) * torch.sign(torch.randn(384, 128))
+    ref = x.double() @ w.double().t()
+    out = torch.empty(rows, 384, device=DEV)
+    ops._project(x.to(DEV), w.to(DEV), None, out)
+    # error measured against the magnitude of the terms that were summed (cancellation-aware bound)
+    scale = (x.abs().double() @ w.abs().double().t())
+    err_split = ((out.cpu().double() - ref).abs() / scale).max().item()
+    err_fp32 = (((x @ w.t()).double() - ref).abs() / scale).max().item()
+    assert err_split <= max(2.0 * err_fp32, 3e-7), (err_split, err_fp32)

@@ -1277,6 +1277,7 @@ struct GruBwdArgs {
     const float *whh;      // [384, 128]
     float *dgi;            // [rows, steps, 384]
     float *dghn;           // [rows, steps, 128]
+    float *bias_partial;   // [gridDim.x, 512] per-block column sums of (d_gi | d_ghn), or null
 };
 
 __global__ __launch_bounds__(512, 2) void gru_seq_bwd_kernel(const GruBwdArgs a)
@@ -1294,6 +1295,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_bwd_kernel(const GruBwdArgs a)
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk) W[g][kk] = a.whh[(int64_t)(g * GRU_H + 32 * grp + kk) * GRU_H + hid];
 
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};          // column sums of dar, daz, dan, dgn over this block's rows and steps
     const int64_t ntiles = (a.rows + GRUB_BM - 1) / GRUB_BM;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * GRUB_BM;
@@ -1330,6 +1332,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_bwd_kernel(const GruBwdArgs a)
                         float *o = a.dgi + (row * steps + t) * (3 * GRU_H) + hid;
                         o[0] = dar; o[GRU_H] = daz; o[2 * GRU_H] = dan;
                         a.dghn[(row * steps + t) * GRU_H + hid] = dgn;
+                        bsum[0] += dar; bsum[1] += daz; bsum[2] += dan; bsum[3] += dgn;
                     }
                 }
             if (t == 0) break;                                   // h_{-1} is the constant 0: nothing to propagate
@@ -1357,6 +1360,127 @@ __global__ __launch_bounds__(512, 2) void gru_seq_bwd_kernel(const GruBwdArgs a)
             }
         }
         __syncthreads();       // LDS is reused by the next tile
+    }
+    if (a.bias_partial) {      // the four lanes sharing a hidden unit (grp 0..3) hold disjoint rows
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bsum[i] += __shfl_xor(bsum[i], 16);
+            bsum[i] += __shfl_xor(bsum[i], 32);
+        }
+        if (grp == 0) {
+            float *o = a.bias_partial + (int64_t)blockIdx.x * (4 * GRU_H) + hid;
+            o[0] = bsum[0]; o[GRU_H] = bsum[1]; o[2 * GRU_H] = bsum[2]; o[3 * GRU_H] = bsum[3];
+        }
+    }
+}
+
+// gru_seq_bwd_x3_kernel: the same backward recurrence with dGH·W_hh in split-bf16 arithmetic (see gru_proj_x3_kernel) and the
+// transposed MFMA layout: a lane owns 4 consecutive hidden units of one row -> float4 loads of the saved gates / stores
+// of dGI, bf16x4 stores of the split dGH rows.  32 rows per block iteration: the three dGH planes [32][384] are double
+// buffered in 150 KB of LDS, one barrier per step.
+constexpr int GBX_BM = 32;
+constexpr int GBX_RT = GBX_BM / 16;
+constexpr int GBX_PITCH = 3 * GRU_H + 8;      // bf16 elements
+
+__global__ __launch_bounds__(512, 2) void gru_seq_bwd_x3_kernel(const GruBwdArgs a)
+{
+    __shared__ __bf16 Gs[2][3][GBX_BM][GBX_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int oc = wave * 16 + 4 * grp;       // the 4 hidden units this lane produces / consumes
+    const int steps = a.steps;
+
+    // MFMA A operand of the transposed product D[m = hidden j][n = row] = sum_k W_hh[k][j] dGH[row][k]:
+    // A[m = 16w+col][k = c*32 + 8*grp + jj] = W_hh[k][16w + col]   (column gather, once per kernel)
+    bf8v Wf[3][12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+        float tmp[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.whh[(int64_t)(c * 32 + 8 * grp + jj) * GRU_H + wave * 16 + col];
+        bf16_split3_x8(tmp, Wf[0][c], Wf[1][c], Wf[2][c]);
+    }
+    const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
+    f4v bsum[4] = {zero4, zero4, zero4, zero4};    // column sums of dar, daz, dan, dgn over this block's rows and steps
+    const int64_t ntiles = (a.rows + GBX_BM - 1) / GBX_BM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * GBX_BM;
+        const int last = (int)min((int64_t)GBX_BM, a.rows - row0) - 1;
+        f4v drec[GBX_RT];
+#pragma unroll
+        for (int rt = 0; rt < GBX_RT; ++rt) drec[rt] = zero4;
+
+        for (int t = steps - 1; t >= 0; --t) {
+            const int buf = t & 1;
+#pragma unroll
+            for (int rt = 0; rt < GBX_RT; ++rt) {
+                const int r_ = rt * 16 + col;
+                const int64_t e = (row0 + min(r_, last)) * steps + t;
+                const float *gp = a.gates + e * (4 * GRU_H) + oc;
+                const f4v r = *(const f4v *)gp, z = *(const f4v *)(gp + GRU_H), n = *(const f4v *)(gp + 2 * GRU_H), q = *(const f4v *)(gp + 3 * GRU_H);
+                const f4v hprev = t > 0 ? *(const f4v *)(a.hseq + (e - 1) * GRU_H + oc) : zero4;
+                f4v dh = drec[rt];
+                if (a.dh_seq) dh += *(const f4v *)(a.dh_seq + e * GRU_H + oc);
+                if (a.dh_sum) dh += *(const f4v *)(a.dh_sum + (row0 + min(r_, last)) * GRU_H + oc);
+                const f4v dan = dh * (1.f - z) * (1.f - n * n);
+                const f4v daz = dh * (hprev - n) * z * (1.f - z);
+                const f4v dar = dan * q * r * (1.f - r);
+                const f4v dgn = dan * r;
+                drec[rt] = dh * z;                        // direct path; the W_hh path is added after the MFMAs
+                auto publish = [&](int g, const f4v v) {
+                    bf4v s0, s1, s2;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        __bf16 x, y, w;
+                        bf16_split3(v[j], x, y, w);
+                        s0[j] = x; s1[j] = y; s2[j] = w;
+                    }
+                    *(bf4v *)(&Gs[buf][0][r_][g * GRU_H + oc]) = s0;
+                    *(bf4v *)(&Gs[buf][1][r_][g * GRU_H + oc]) = s1;
+                    *(bf4v *)(&Gs[buf][2][r_][g * GRU_H + oc]) = s2;
+                };
+                if (t > 0) { publish(0, dar); publish(1, daz); publish(2, dgn); }
+                if (r_ <= last) {
+                    float *o = a.dgi + e * (3 * GRU_H) + oc;
+                    *(f4v *)o = dar; *(f4v *)(o + GRU_H) = daz; *(f4v *)(o + 2 * GRU_H) = dan;
+                    *(f4v *)(a.dghn + e * GRU_H + oc) = dgn;
+                    bsum[0] += dar; bsum[1] += daz; bsum[2] += dan; bsum[3] += dgn;
+                }
+            }
+            if (t == 0) break;                            // h_{-1} is the constant 0: nothing to propagate
+            __syncthreads();
+#pragma unroll
+            for (int rt = 0; rt < GBX_RT; ++rt) {
+                f4v acc[3] = {zero4, zero4, zero4};
+#pragma unroll
+                for (int c = 0; c < 12; ++c) {
+                    bf8v af[3];      // MFMA B operand: B[k][n = row] = dGH[row rt*16 + col][k = c*32 + 8*grp + j]
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) af[sp] = *(const bf8v *)(&Gs[buf][sp][rt * 16 + col][c * 32 + 8 * grp]);
+                    // six partial products, smallest first, spread over three independent accumulators
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][c], af[2], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[2][c], af[0], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][c], af[1], acc[2], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][c], af[1], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][c], af[0], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][c], af[0], acc[2], 0, 0, 0);
+                }
+                drec[rt] += (acc[0] + acc[1]) + acc[2];
+            }
+        }
+        __syncthreads();       // LDS is reused by the next tile
+    }
+    if (a.bias_partial) {      // the 16 lanes of a group (col 0..15) hold the 16 rows of a tile for the same 4 hidden units
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = bsum[g][j];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                bsum[g][j] = v;
+            }
+            if (col == 0) *(f4v *)(a.bias_partial + (int64_t)blockIdx.x * (4 * GRU_H) + g * GRU_H + oc) = bsum[g];
+        }
     }
 }
 
@@ -1609,7 +1733,7 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
 
 int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *h_seq,
                           const float *dh_seq, const float *dh_sum, const float *w_hh, float *d_gi, float *d_ghn,
-                          void *stream)
+                          float *bias_partial, int32_t n_partial, int split_bf16, void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq_bwd: hidden=%d, only %d is built", hidden, GRU_H);
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq_bwd: bad sizes");
@@ -1621,9 +1745,18 @@ int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t ntiles = (rows + GRUB_BM - 1) / GRUB_BM;
-    const int64_t blocks = ntiles < cus ? ntiles : cus;
-    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    const int64_t ntiles = (rows + GRUB_BM - 1) / GRUB_BM;       // both variants use 32-row tiles
+    int64_t blocks = ntiles < cus ? ntiles : cus;
+    if (bias_partial) {
+        if (n_partial < 1) return fail(CTGCN_E_INVALID, "gru_seq_bwd: n_partial=%d", n_partial);
+        if (blocks > n_partial) blocks = n_partial;
+        a.bias_partial = bias_partial;                            // rows >= blocks of the table stay zero
+        HIP_TRY(hipMemsetAsync(bias_partial, 0, (size_t)n_partial * 4 * GRU_H * sizeof(float), (hipStream_t)stream));
+    }
+    if (split_bf16)
+        hipLaunchKernelGGL(gru_seq_bwd_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

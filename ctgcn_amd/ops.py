@@ -334,8 +334,8 @@ class _GruSeq(torch.autograd.Function):
         dseq = torch.empty_like(seq)
         dw_ih = torch.zeros_like(w_ih_d)
         dw_hh = torch.zeros_like(w_hh_d)
-        db_gi = torch.zeros(3 * hid, dtype=torch.float32, device=dev)
-        db_hn = torch.zeros(hid, dtype=torch.float32, device=dev)
+        db_all = torch.zeros(4 * hid, dtype=torch.float32, device=dev)                      # [d_gi (3h) | d_ghn (h)] column sums
+        bias_part = torch.empty(512, 4 * hid, dtype=torch.float32, device=dev)
         dln_w = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
         dln_b = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
         chunks = _row_chunks(lib, rows, steps, hid)
@@ -368,12 +368,12 @@ class _GruSeq(torch.autograd.Function):
                 dpre = dpre.contiguous()
                 dgi, dghn = gi, dghn_buf[: n * steps]                                       # gi is dead: reuse as d_gi
                 check(lib.ctgcn_gru_seq_bwd_f32(n, steps, hid, ptr(gates), ptr(hseq), None if reduce_sum else ptr(dpre),
-                                                ptr(dpre) if reduce_sum else None, ptr(w_hh_d), ptr(dgi), ptr(dghn), _stream()),
+                                                ptr(dpre) if reduce_sum else None, ptr(w_hh_d), ptr(dgi), ptr(dghn),
+                                                ptr(bias_part), bias_part.shape[0], 1 if split_mfma_enabled() else 0, _stream()),
                       "ctgcn_gru_seq_bwd_f32")
                 torch.mm(dgi, w_ih_d, out=dseq[lo:lo + n].view(n * steps, d_in))
                 _accumulate_tn(dw_ih, dgi, x2d)
-                db_gi += dgi.sum(0)
-                db_hn += dghn.sum(0)
+                db_all += bias_part.sum(0)          # per-block column sums written by the kernel (no re-read of d_gi / d_ghn)
                 hprev = hprev_buf[:n]
                 hprev[:, 1:] = hseq[:, :-1]
                 hp2d = hprev.view(n * steps, hid)
@@ -381,8 +381,8 @@ class _GruSeq(torch.autograd.Function):
                 _accumulate_tn(dw_hh[2 * hid:], dghn, hp2d)
         db_ih = db_hh = None
         if b_ih is not None:
-            db_ih = db_gi
-            db_hh = torch.cat([db_gi[: 2 * hid], db_hn])
+            db_ih = db_all[: 3 * hid].clone()
+            db_hh = torch.cat([db_all[: 2 * hid], db_all[3 * hid:]])
         return dseq, dw_ih, dw_hh, db_ih, db_hh, dln_w, dln_b, None, None
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 2
+#define CTGCN_ABI_VERSION 3
 
 enum {
     CTGCN_OK = 0,
@@ -183,10 +183,14 @@ int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float 
  * gradient dh_sum [rows, 128] added at every step (the .sum(dim=1) case).  Outputs, for the caller's GEMMs:
  *   d_gi  [rows, steps, 384] = dL/d(x·W_ih^T + b_ih)      -> dX = d_gi·W_ih, dW_ih = d_gi^T·x, db_ih = sum d_gi
  *   d_ghn [rows, steps, 128] = dL/d(W_hn·h + b_hn)         -> dW_hh = [d_gi_r, d_gi_z, d_ghn]^T·h_{t-1}, db_hh likewise
+ * bias_partial (nullable) [n_partial, 512]: on return its rows sum to the bias gradients — columns 0..383 = sum over
+ *   (row, step) of d_gi, columns 384..511 = of d_ghn (one row per launched block, the rest zeroed; n_partial >= the
+ *   CU count uses the whole device).  Saves re-reading d_gi / d_ghn for db_ih / db_hh.
+ * split_bf16: as in ctgcn_gru_seq_f32 (the product dGH·W_hh on the bf16 matrix cores, fp32-accurate).
  */
 int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *h_seq,
                           const float *dh_seq, const float *dh_sum, const float *w_hh, float *d_gi, float *d_ghn,
-                          void *stream);
+                          float *bias_partial, int32_t n_partial, int split_bf16, void *stream);
 
 /*
  * The GRU input projection  gi[rows, 384] = x[rows, 128]·w_ih^T + bias  (bias [384] may be NULL) for d_in = hidden = 128,

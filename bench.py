@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="time forward + backward + Adam step (surrogate loss out.square().mean(); the reference's "
                          "negative-sampling loss is outside the hot path) instead of the embedding forward")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the window from one captured hipGraph (ctgcn_amd.graph_capture; single GPU, inference): "
+                         "removes launch/Python overhead on small graphs; per-launch HIP-event timing (roofline) is off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     return ap.parse_args()
@@ -133,7 +136,13 @@ def main():
 
     # HIP-event timing of every aggregation launch (same stream the kernel is launched on)
     launches = []
-    ops.set_launch_timer(lambda name, start, end, meta: launches.append((name, start, end, meta)))
+    if args.graph:
+        if use_dist or args.train:
+            raise SystemExit("--graph: single-GPU inference only")
+        from ctgcn_amd.graph_capture import GraphedInference
+        runner = GraphedInference(model, x_list, adj_list)
+    else:
+        ops.set_launch_timer(lambda name, start, end, meta: launches.append((name, start, end, meta)))
 
     if args.train:
         model.train()
@@ -141,6 +150,8 @@ def main():
         opt = torch.optim.Adam(params, lr=1e-3)
 
     def step():
+        if args.graph:
+            return runner()
         if not args.train:
             with torch.no_grad():
                 return model(x_list, adj_list)
@@ -248,7 +259,7 @@ def main():
                    "K_per_snapshot": [stats[t]["K"] for t in range(T)],
                    "stored_entries_per_snapshot": [stats[t]["nnz"] for t in range(T)],
                    "aggregated_edges_per_step": agg_edges_step,
-                   "parallelism": "snapshot-parallel x%d (%s exchange before the temporal GRU)" % (world, args.exchange) if world > 1 else "single GPU",
+                   "parallelism": "snapshot-parallel x%d (%s exchange before the temporal GRU)" % (world, args.exchange) if world > 1 else ("single GPU, hipGraph replay" if args.graph else "single GPU"),
                    "assignment": assignment},
         "embed_wall_ms": round(ms_per_step, 3),
         "aggregation_ms_per_step_rank0": None if spmm_ms_step is None else round(spmm_ms_step, 3),

@@ -1,8 +1,9 @@
 """CoreDiffusion and MLP layers with the reference's constructor/forward signatures and state_dict keys
 (reference layers.py:9-63 and :67-106), running the sparse aggregation on the HIP kernel.
 
-Only the aggregation (reference layers.py:41-48 + the stack/transpose of :58) is replaced; the core-axis
-GRU/LSTM, the sum over cores and the LayerNorm stay PyTorch-ROCm modules (dense, MFMA via MIOpen/hipBLASLt).
+The aggregation (reference layers.py:41-48 + the stack/transpose of :58) runs in ctgcn_core_aggregate_f32; the
+core-axis GRU/LSTM + sum over cores + LayerNorm (layers.py:59-62) in the fused recurrence kernels when hidden = 128
+(ops.gru_sequence / ops.lstm_sequence), otherwise in the PyTorch-ROCm modules, chunked over rows.
 """
 import torch
 from torch import nn

@@ -265,3 +265,39 @@ def test_full_size_split_and_exact_fp32_paths_agree(monkeypatch):
     assert torch.isfinite(a).all()
     err = (a - b).abs().max().item()
     assert err <= 2e-5 + 1e-4 * b.abs().max().item(), err
+
+
+@pytest.mark.parametrize("features", ["onehot", "dense"])
+def test_hip_graph_replay_equals_eager_forward(features):
+    """GraphedInference (whole window recorded into one hipGraph) returns bit-identical embeddings to the eager forward,
+    follows in-place weight updates and, for dense features, new inputs."""
+    import ctgcn_amd
+    from ctgcn_amd.graph_capture import GraphedInference
+    adj = _window()
+    n, T = 1899, len(adj)
+    torch.manual_seed(5)
+    d_in = n if features == "onehot" else 24
+    model = ctgcn_amd.CTGCN(d_in, 128, 128, 1, 2, T, rnn_type="GRU", model_type="C", trans_activate_type="L").to(DEV).eval()
+    if features == "onehot":
+        idx = torch.arange(n, device=DEV).repeat(2, 1)
+        xs = [torch.sparse_coo_tensor(idx, torch.ones(n, device=DEV), (n, n)) for _ in range(T)]
+    else:
+        xs = [torch.randn(n, d_in, device=DEV) for _ in range(T)]
+    with torch.no_grad():
+        want = model(xs, adj).clone()
+    runner = GraphedInference(model, xs, adj)
+    assert torch.equal(runner(), want)
+    assert torch.equal(runner(), want)                       # replays are repeatable
+    with torch.no_grad():                                    # weights are read by address: updates are seen
+        for p in model.parameters():
+            p.mul_(0.9)
+        want2 = model(xs, adj).clone()
+    assert not torch.equal(want2, want)
+    assert torch.equal(runner(), want2)
+    if features == "dense":
+        xs2 = [x * 0.5 + 0.1 for x in xs]
+        with torch.no_grad():
+            want3 = model(xs2, adj).clone()
+        assert torch.equal(runner(xs2), want3)
+        with pytest.raises(ValueError):
+            runner([x[:, :3] for x in xs2])

@@ -35,6 +35,8 @@ SIGNATURES = {
     "ctgcn_lstm_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp]),
     "ctgcn_gru_seq_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _int, _vp]),
     "ctgcn_gru_input_proj_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "ctgcn_gru_input_grad_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "ctgcn_gru_weight_grad_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i32, _int, _vp]),
     "ctgcn_gru_row_granule": (_i64, []),
     "ctgcn_row_cumsum_f32": (_int, [_i64, _vp, _vp, _vp, _vp]),
     "ctgcn_random_walk_pairs": (_int, [_i64, _vp, _vp, _vp, _i32, _i32, _i32, _c.c_uint64, _int, _vp, _vp, _vp, _vp]),

@@ -1484,6 +1484,279 @@ __global__ __launch_bounds__(512, 2) void gru_seq_bwd_x3_kernel(const GruBwdArgs
     }
 }
 
+// gru_dx_x3_kernel: dX[rows, 128] = dGI[rows, 384] · W_ih   (gradient of the input projection w.r.t. its input), split-bf16
+// arithmetic.  Same operand roles as gru_seq_bwd_x3_kernel's product (K = 384 gate columns, N = 128): the wave's column
+// fragments of W_ih stay in 144 VGPRs, 32-row dGI tiles are split by the whole block into three bf16 LDS planes, double
+// buffered with the next tile's global loads in flight during the MFMAs.  HBM-bound: 1536 B read + 512 B written per row.
+struct DxArgs {
+    int64_t rows;
+    const float *g;       // [rows, 384]
+    const float *w;       // [384, 128]
+    float *out;           // [rows, ldo]
+    int64_t ldo;
+};
+
+__global__ __launch_bounds__(512, 2) void gru_dx_x3_kernel(const DxArgs a)
+{
+    __shared__ __bf16 Gs[2][3][GBX_BM][GBX_PITCH];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int oc = wave * 16 + 4 * grp;
+
+    bf8v Wf[3][12];       // A[m = 16w+col][k = c*32 + 8*grp + jj] = W[k][16w + col]
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+        float tmp[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) tmp[jj] = a.w[(int64_t)(c * 32 + 8 * grp + jj) * GRU_H + wave * 16 + col];
+        bf16_split3_x8(tmp, Wf[0][c], Wf[1][c], Wf[2][c]);
+    }
+    const int64_t ntiles = (a.rows + GBX_BM - 1) / GBX_BM;
+    // staging role: 32 rows x 96 float4 = 3072 float4, six per thread; idx -> (row, c4)
+    auto load_tile = [&](int64_t tile, f4v (&v)[6]) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = tid + 512 * i;
+            int64_t r = tile * GBX_BM + idx / 96;
+            r = r < a.rows ? r : a.rows - 1;
+            v[i] = __builtin_nontemporal_load((const f4v *)(a.g + r * (3 * GRU_H) + (idx % 96) * 4));
+        }
+    };
+    auto stage_tile = [&](int buf, const f4v (&v)[6]) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = tid + 512 * i;
+            bf4v s0, s1, s2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 p, q, r;
+                bf16_split3(v[i][j], p, q, r);
+                s0[j] = p; s1[j] = q; s2[j] = r;
+            }
+            __bf16 *dst = &Gs[buf][0][idx / 96][(idx % 96) * 4];
+            *(bf4v *)dst = s0;
+            *(bf4v *)(dst + GBX_BM * GBX_PITCH) = s1;
+            *(bf4v *)(dst + 2 * GBX_BM * GBX_PITCH) = s2;
+        }
+    };
+    f4v stage[6];
+    int buf = 0;
+    if ((int64_t)blockIdx.x < ntiles) {
+        load_tile(blockIdx.x, stage);
+        stage_tile(0, stage);
+    }
+    __syncthreads();
+    const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int64_t next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next, stage);
+        const int64_t row0 = tile * GBX_BM;
+#pragma unroll
+        for (int rt = 0; rt < GBX_RT; ++rt) {
+            f4v acc[3] = {zero4, zero4, zero4};
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                bf8v af[3];
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) af[sp] = *(const bf8v *)(&Gs[buf][sp][rt * 16 + col][c * 32 + 8 * grp]);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][c], af[2], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[2][c], af[0], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][c], af[1], acc[2], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][c], af[1], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[1][c], af[0], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wf[0][c], af[0], acc[2], 0, 0, 0);
+            }
+            const int64_t row = row0 + rt * 16 + col;
+            if (row < a.rows) *(f4v *)(a.out + row * a.ldo + oc) = (acc[0] + acc[1]) + acc[2];
+        }
+        if (next < ntiles) stage_tile(buf ^ 1, stage);
+        __syncthreads();
+    }
+}
+
+// gru_dw_x3_kernel: weight gradients  dW[384, 128] = Σ_r G[r, :]ᵀ · X[r, :]  over R = rows*steps row-steps (dW_ih: G = dGI,
+// X = the layer input; dW_hh: G = [dGI_r, dGI_z, dGHn], X = h_{t-1}), split-bf16 arithmetic.  The reduction index is the
+// ROW, so both operands are staged TRANSPOSED: a lane loads 4 consecutive rows of one column (coalesced across the
+// wave), splits them and stores bf16x4 into planes [column][row]; MFMA fragments are then single ds_read_b128.
+// A block owns 192 of the 384 gate columns (LDS: 2 buffers x 3 planes x (192 + 128) x 40 bf16 = 150 KB); blocks b and
+// b + 8 (same XCD, shared L2) walk the same rows with the two halves, so X is fetched from HBM once.  Every block pair
+// adds its partial sum to `partial[pair]` (its own slice, no atomics); the host adds the pairs (deterministic).
+// shift: X row r is taken as (r % steps ? X[r - 1] : 0) — h_{t-1} straight from the saved h sequence, no shifted copy.
+// Measured: 0.49 ms per 0.5 M row-steps = hipBLASLt's fp32 TN GEMM; load issue, staging (split + conflicting LDS
+// stores) and MFMA phases add up instead of overlapping (ablation: 0.13 + 0.18 + 0.11 ms + 0.07 fixed).  A
+// producer/consumer wave split was tried and is slower (the producers' instruction issue becomes the limit).
+constexpr int DW_KB = 32;          // rows per chunk = MFMA K
+constexpr int DW_MH = 192;         // gate columns per block
+constexpr int DW_PITCH = 40;       // bf16 per transposed plane row: 32 + 8 pad, 80-byte rows stay 16-byte aligned
+
+struct DwArgs {
+    int64_t rows;          // R
+    int32_t steps;
+    int32_t shift;
+    const float *g01;      // gate columns [0, 256)
+    int64_t ldg01;
+    const float *g2;       // gate columns [256, 384)
+    int64_t ldg2;
+    const float *x;        // [R, 128]
+    int64_t ldx;
+    float *partial;        // [pairs, 384, 128]
+    int32_t pairs;
+    int32_t accumulate;    // partial += instead of partial =
+};
+
+// 8-byte strips of a transposed plane row are stored at strip ^ swz(column): the 64 lanes of a staging store (consecutive
+// columns, same strip) would otherwise hit 8 bank pairs 8 times each (row pitch 20 dwords).  The swizzle keeps 16-byte
+// pairs of strips together, so a fragment read is still one aligned ds_read_b128 at 16-byte slot grp ^ (swz >> 1).
+__device__ __forceinline__ int dw_swz(int column) { return ((column >> 3) & 3) << 1; }
+
+__global__ __launch_bounds__(512, 2) void gru_dw_x3_kernel(const DwArgs a)
+{
+    __shared__ __bf16 Gt[2][3][DW_MH][DW_PITCH];
+    __shared__ __bf16 Xt[2][3][GRU_H][DW_PITCH];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int col = lane & 15, grp = lane >> 4;
+    const int pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7), half = (blockIdx.x >> 3) & 1;
+    const int mg = wv >> 1, ng = wv & 1;          // wave tile: m-tiles 3mg..3mg+2 (of 12), n-tiles 4ng..4ng+3 (of 8)
+
+    const int64_t nchunks = (a.rows + DW_KB - 1) / DW_KB;
+    const int64_t per = (nchunks + a.pairs - 1) / a.pairs;
+    const int64_t c_lo = min((int64_t)pair * per, nchunks), c_hi = min(c_lo + per, nchunks);
+    const int sh = a.shift ? 1 : 0;
+
+    // Staging items: idx = 512*i + 64*wave + lane; G half = 8 strips (of 4 rows) x 192 columns = 3 items per thread,
+    // X = 8 x 128 = 2 items per thread.  192 and 128 are multiples of 64, so an item's strip and 64-column group are
+    // WAVE-UNIFORM: addresses are scalar bases (row, source matrix, clamps, step shift resolved on the scalar unit)
+    // plus the lane index.  Loads are unconditional and nothing touches the loaded registers until stage_chunk (a
+    // guarded load becomes its own basic block behind a s_waitcnt; a select right after the load would wait for it).
+    auto g_item = [&](int i, int &strip, int &cb) { const int base = 512 * i + 64 * wv; strip = base / DW_MH; cb = base % DW_MH; };
+    auto x_item = [&](int i, int &strip, int &cb) { const int base = 512 * i + 64 * wv; strip = base >> 7; cb = base & (GRU_H - 1); };
+    auto load_chunk = [&](int64_t chunk, f4v (&gs)[3], f4v (&xs)[2]) {
+        const int64_t row0 = chunk * DW_KB;
+        const bool interior = row0 + DW_KB <= a.rows && row0 >= sh;          // no row clamps needed
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int strip, cb;
+            g_item(i, strip, cb);
+            const int m0 = half * DW_MH + cb;                                // 64 columns m0 .. m0+63 come from one matrix
+            const int64_t ld = m0 < 2 * GRU_H ? a.ldg01 : a.ldg2;
+            const float *src = m0 < 2 * GRU_H ? a.g01 + m0 : a.g2 + (m0 - 2 * GRU_H);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = row0 + 4 * strip + j;
+                gs[i][j] = (src + (interior ? r : min(r, a.rows - 1)) * ld)[lane];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int strip, cb;
+            x_item(i, strip, cb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t r = row0 + 4 * strip + j - sh;
+                xs[i][j] = (a.x + (interior ? r : max(min(r, a.rows - 1 - sh), (int64_t)0)) * a.ldx + cb)[lane];
+            }
+        }
+    };
+    auto split4 = [&](const f4v v, __bf16 *dst, int plane_elems) {
+        bf4v s0, s1, s2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __bf16 p, q, r;
+            bf16_split3(v[j], p, q, r);
+            s0[j] = p; s1[j] = q; s2[j] = r;
+        }
+        *(bf4v *)dst = s0;
+        *(bf4v *)(dst + plane_elems) = s1;
+        *(bf4v *)(dst + 2 * plane_elems) = s2;
+    };
+    // out-of-range rows and the t = 0 rows of the shifted operand are zeroed here (scalar conditions)
+    auto stage_chunk = [&](int buf, int64_t chunk, const f4v (&gs)[3], const f4v (&xs)[2]) {
+        const int64_t row0 = chunk * DW_KB;
+        const int tbase = a.shift ? (int)(row0 % a.steps) : 0;
+        const int valid = (int)min((int64_t)DW_KB, a.rows - row0);          // rows of this chunk that exist
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            int strip, cb;
+            g_item(i, strip, cb);
+            f4v v = gs[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = 4 * strip + j < valid ? v[j] : 0.f;
+            const int c = cb + lane;
+            split4(v, &Gt[buf][0][c][4 * (strip ^ dw_swz(c))], DW_MH * DW_PITCH);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int strip, cb;
+            x_item(i, strip, cb);
+            int t = a.shift ? (tbase + 4 * strip) % a.steps : 1;           // step index of the strip's first row
+            f4v v = xs[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = (4 * strip + j < valid && t != 0) ? v[j] : 0.f;
+                if (a.shift) t = (t + 1 == a.steps) ? 0 : t + 1;
+            }
+            const int c = cb + lane;
+            split4(v, &Xt[buf][0][c][4 * (strip ^ dw_swz(c))], GRU_H * DW_PITCH);
+        }
+    };
+
+    const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
+    f4v acc[3][4];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = zero4;
+
+    // one iteration: LDS buffer `buf` holds chunk `chunk`; `nxt` registers hold chunk+1; chunk+2 is loaded into `far`
+    // a fragment row is column tile*16 + col: its swizzle bits are (tile & 1, col >> 3)
+    const int rslot_even = 8 * (grp ^ (col >> 3)), rslot_odd = 8 * (grp ^ (2 | (col >> 3)));
+    auto iteration = [&](int64_t chunk, int buf, f4v (&far_g)[3], f4v (&far_x)[2], const f4v (&nxt_g)[3], const f4v (&nxt_x)[2]) {
+        if (chunk + 2 < c_hi) load_chunk(chunk + 2, far_g, far_x);
+        bf8v af[3][3];     // [m tile][split]: A[m = gate column][k = row 8*grp + j]
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) af[mt][sp] = *(const bf8v *)(&Gt[buf][sp][(3 * mg + mt) * 16 + col][((3 * mg + mt) & 1) ? rslot_odd : rslot_even]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            bf8v bfr[3];   // B[k = row][n = input column]
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) bfr[sp] = *(const bf8v *)(&Xt[buf][sp][(4 * ng + nt) * 16 + col][(nt & 1) ? rslot_odd : rslot_even]);
+#define CTGCN_X3_MFMA(I, J)                                                                                              \
+            _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                             \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][I], bfr[J], acc[mt][nt], 0, 0, 0);
+            CTGCN_X3_PAIRS(CTGCN_X3_MFMA)
+#undef CTGCN_X3_MFMA
+        }
+        if (chunk + 1 < c_hi) stage_chunk(buf ^ 1, chunk + 1, nxt_g, nxt_x);
+        __syncthreads();
+    };
+
+    f4v g_a[3], x_a[2], g_b[3], x_b[2];
+    if (c_lo < c_hi) {
+        load_chunk(c_lo, g_a, x_a);
+        if (c_lo + 1 < c_hi) load_chunk(c_lo + 1, g_b, x_b);
+        stage_chunk(0, c_lo, g_a, x_a);
+    }
+    __syncthreads();
+    for (int64_t chunk = c_lo; chunk < c_hi; chunk += 2) {
+        iteration(chunk, 0, g_a, x_a, g_b, x_b);                       // chunk+1 sits in set b, chunk+2 goes to set a
+        if (chunk + 1 < c_hi) iteration(chunk + 1, 1, g_b, x_b, g_a, x_a);
+    }
+    // D layout: lane (col, grp) holds D[m = 4*grp + i][n = col]
+    float *out = a.partial + (int64_t)pair * (3 * GRU_H) * GRU_H;
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = half * DW_MH + (3 * mg + mt) * 16 + 4 * grp + i, n = (4 * ng + nt) * 16 + col;
+                out[m * GRU_H + n] = a.accumulate ? out[m * GRU_H + n] + acc[mt][nt][i] : acc[mt][nt][i];
+            }
+}
+
 // final core numbers; with a level cap the unpeeled vertices (current degree >= cap) are reported as `cap`
 __global__ void kcore_copy_kernel(int n, int cap, const int32_t *__restrict__ deg, int32_t *__restrict__ core)
 {
@@ -1777,6 +2050,42 @@ int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const f
     const int64_t ntiles = (rows + PJ_BM - 1) / PJ_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;
     hipLaunchKernelGGL(gru_proj_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_input_grad_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *d_gi, const float *w_ih, float *d_x,
+                             int64_t ldx, void *stream)
+{
+    if (hidden != GRU_H || d_in != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_input_grad: only d_in = hidden = %d is built (got %d, %d)", GRU_H, d_in, hidden);
+    if (rows < 0 || ldx < d_in) return fail(CTGCN_E_INVALID, "gru_input_grad: bad sizes");
+    if (rows == 0) return CTGCN_OK;
+    if (!d_gi || !w_ih || !d_x) return fail(CTGCN_E_INVALID, "gru_input_grad: null pointer");
+    if (!aligned16(d_gi) || !aligned16(d_x) || (ldx % 4)) return fail(CTGCN_E_INVALID, "gru_input_grad: d_gi / d_x must be 16-byte aligned, ldx a multiple of 4");
+    DxArgs a{};
+    a.rows = rows; a.g = d_gi; a.w = w_ih; a.out = d_x; a.ldo = ldx;
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t ntiles = (rows + GBX_BM - 1) / GBX_BM;
+    const int64_t blocks = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL(gru_dx_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_weight_grad_f32(int64_t rows, int32_t steps, int32_t hidden, const float *g01, int64_t ldg01, const float *g2,
+                              int64_t ldg2, const float *x, int64_t ldx, int shift_steps, float *partial, int32_t n_pairs,
+                              int accumulate, void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_weight_grad: hidden=%d, only %d is built", hidden, GRU_H);
+    if (rows < 0 || steps < 1 || ldg01 < 2 * GRU_H || ldg2 < GRU_H || ldx < GRU_H) return fail(CTGCN_E_INVALID, "gru_weight_grad: bad sizes");
+    if (n_pairs < 8 || (n_pairs % 8)) return fail(CTGCN_E_INVALID, "gru_weight_grad: n_pairs=%d must be a positive multiple of 8", n_pairs);
+    if (!partial || (rows > 0 && (!g01 || !g2 || !x))) return fail(CTGCN_E_INVALID, "gru_weight_grad: null pointer");
+    DwArgs a{};
+    a.rows = rows; a.steps = steps; a.shift = shift_steps ? 1 : 0; a.g01 = g01; a.ldg01 = ldg01; a.g2 = g2; a.ldg2 = ldg2;
+    a.x = x; a.ldx = ldx; a.partial = partial; a.pairs = n_pairs; a.accumulate = accumulate ? 1 : 0;
+    hipLaunchKernelGGL(gru_dw_x3_kernel, dim3((unsigned)(2 * n_pairs)), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -260,6 +260,29 @@ def _project(x2d, w_ih, bias, out):
         torch.addmm(bias, x2d, w_ih.t(), out=out)
 
 
+def _project_grad(dgi, w_ih, out):
+    """out[rows, d_in] = dgi[rows, 3h] @ w_ih — gradient of the input projection w.r.t. its input."""
+    if split_mfma_enabled() and w_ih.shape == (384, 128) and w_ih.is_contiguous() and dgi.is_contiguous() \
+            and out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0:
+        lib = _lib.load()
+        check(lib.ctgcn_gru_input_grad_f32(dgi.shape[0], 128, 128, ptr(dgi), ptr(w_ih), ptr(out), out.stride(0), _stream()),
+              "ctgcn_gru_input_grad_f32")
+        return
+    torch.mm(dgi, w_ih, out=out)
+
+
+_DW_PAIRS = 128          # block pairs of ctgcn_gru_weight_grad_f32: 256 blocks = one per CU of an MI355X
+
+
+def _weight_grad(part, g01, g2, x2d, steps, shift, accumulate):
+    """part[p] (+)= block pair p's share of  sum_r [g01[r, :2h] | g2[r, :h]]^T x'[r]  (x' = x2d, or x2d shifted one step
+    inside each sequence); part.sum(0) is the weight gradient."""
+    lib = _lib.load()
+    check(lib.ctgcn_gru_weight_grad_f32(g01.shape[0], steps, 128, ptr(g01), g01.stride(0), ptr(g2), g2.stride(0), ptr(x2d),
+                                        x2d.stride(0), 1 if shift else 0, ptr(part), part.shape[0], 1 if accumulate else 0,
+                                        _stream()), "ctgcn_gru_weight_grad_f32")
+
+
 def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
     lib = _lib.load()
     rows, steps, d_in = seq.shape
@@ -344,7 +367,12 @@ class _GruSeq(torch.autograd.Function):
         gates_buf = torch.empty(cmax * steps, 4 * hid, dtype=torch.float32, device=dev)
         hseq_buf = torch.empty(cmax, steps, hid, dtype=torch.float32, device=dev)
         dghn_buf = torch.empty(cmax * steps, hid, dtype=torch.float32, device=dev)
-        hprev_buf = torch.zeros(cmax, steps, hid, dtype=torch.float32, device=dev)         # [:, 0] stays 0
+        split = split_mfma_enabled()
+        if split:
+            dw_part_ih = torch.empty(_DW_PAIRS, 3 * hid, hid, dtype=torch.float32, device=dev)    # summed once at the end
+            dw_part_hh = torch.empty(_DW_PAIRS, 3 * hid, hid, dtype=torch.float32, device=dev)
+        else:
+            hprev_buf = torch.zeros(cmax, steps, hid, dtype=torch.float32, device=dev)     # [:, 0] stays 0
         with torch.cuda.device(dev):
             for lo, n in chunks:
                 x2d = seq[lo:lo + n].reshape(n * steps, d_in)
@@ -371,14 +399,24 @@ class _GruSeq(torch.autograd.Function):
                                                 ptr(dpre) if reduce_sum else None, ptr(w_hh_d), ptr(dgi), ptr(dghn),
                                                 ptr(bias_part), bias_part.shape[0], 1 if split_mfma_enabled() else 0, _stream()),
                       "ctgcn_gru_seq_bwd_f32")
-                torch.mm(dgi, w_ih_d, out=dseq[lo:lo + n].view(n * steps, d_in))
-                _accumulate_tn(dw_ih, dgi, x2d)
+                _project_grad(dgi, w_ih_d, dseq[lo:lo + n].view(n * steps, d_in))
                 db_all += bias_part.sum(0)          # per-block column sums written by the kernel (no re-read of d_gi / d_ghn)
-                hprev = hprev_buf[:n]
-                hprev[:, 1:] = hseq[:, :-1]
-                hp2d = hprev.view(n * steps, hid)
-                _accumulate_tn(dw_hh[: 2 * hid], dgi[:, : 2 * hid], hp2d)
-                _accumulate_tn(dw_hh[2 * hid:], dghn, hp2d)
+                if split and d_in == hid:
+                    _weight_grad(dw_part_ih, dgi, dgi[:, 2 * hid:], x2d, steps, False, lo > 0)
+                else:
+                    _accumulate_tn(dw_ih, dgi, x2d)
+                if split:                            # h_{t-1} is read from the h sequence with the shift applied in the kernel
+                    _weight_grad(dw_part_hh, dgi, dghn, hseq.view(n * steps, hid), steps, True, lo > 0)
+                else:
+                    hprev = hprev_buf[:n]
+                    hprev[:, 1:] = hseq[:, :-1]
+                    hp2d = hprev.view(n * steps, hid)
+                    _accumulate_tn(dw_hh[: 2 * hid], dgi[:, : 2 * hid], hp2d)
+                    _accumulate_tn(dw_hh[2 * hid:], dghn, hp2d)
+        if split:
+            dw_hh += dw_part_hh.sum(0)
+            if d_in == hid:
+                dw_ih += dw_part_ih.sum(0)
         db_ih = db_hh = None
         if b_ih is not None:
             db_ih = db_all[: 3 * hid].clone()

@@ -201,6 +201,27 @@ int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
 int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *x, int64_t ldx,
                              const float *w_ih, const float *bias, float *gi, void *stream);
 
+/*
+ * Gradient of the projection w.r.t. its input: d_x[rows, 128] = d_gi[rows, 384] · W_ih  (autograd of the F.linear inside
+ * nn.GRU, reference layers.py:59), same split-bf16 arithmetic.  d_x rows are ldx floats apart.
+ */
+int ctgcn_gru_input_grad_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *d_gi, const float *w_ih, float *d_x,
+                             int64_t ldx, void *stream);
+
+/*
+ * Weight gradients of the GRU (autograd of nn.GRU's two F.linear, reference layers.py:59 / models.py:249):
+ *   partial[p] (p < n_pairs), each [384, 128], sum over p = sum over r < rows of G[r, :]^T · X'[r, :]
+ * G = gate columns [0,256) from g01 (row stride ldg01) and [256,384) from g2 (row stride ldg2): dW_ih takes both from
+ * d_gi; dW_hh takes g2 = d_ghn.  X' = x (row stride ldx), or with shift_steps != 0 the rows shifted by one step inside
+ * each `steps`-long sequence (X'[r] = r % steps ? x[r-1] : 0): h_{t-1} read straight from the h sequence.
+ * accumulate != 0 adds to `partial` instead of overwriting it (one host-side sum after many calls).
+ * rows = nodes * steps.  n_pairs: a positive multiple of 8 (half the CU count uses the whole device).  Split-bf16
+ * arithmetic, deterministic.
+ */
+int ctgcn_gru_weight_grad_f32(int64_t rows, int32_t steps, int32_t hidden, const float *g01, int64_t ldg01, const float *g2,
+                              int64_t ldg2, const float *x, int64_t ldx, int shift_steps, float *partial, int32_t n_pairs,
+                              int accumulate, void *stream);
+
 /* Rows one wave of persistent blocks covers (rows per block x compute units): callers that split `rows` into
  * chunks should use multiples of this so that every launch keeps all CUs equally busy. */
 int64_t ctgcn_gru_row_granule(void);

@@ -180,3 +180,50 @@ def test_split_bf16_projection_wide_dynamic_range():
     err_split = ((out.cpu().double() - ref).abs() / scale).max().item()
     err_fp32 = (((x @ w.t()).double() - ref).abs() / scale).max().item()
     assert err_split <= max(2.0 * err_fp32, 3e-7), (err_split, err_fp32)
+
+
+@pytest.mark.parametrize("rows", [1, 31, 32, 1000, 70001])
+def test_split_bf16_input_gradient_is_fp32_accurate(rows):
+    """ctgcn_gru_input_grad_f32: dX = dGI · W_ih against fp64; error no worse than a plain fp32 GEMM's."""
+    from ctgcn_amd import ops
+    torch.manual_seed(rows + 7)
+    g = torch.randn(rows, 384) * torch.rand(rows, 1) * 3.0
+    w = (torch.rand(384, 128) - 0.5) * 0.18
+    ref = g.double() @ w.double()
+    out = torch.full((rows, 128), float("nan"), device=DEV)
+    assert ops.split_mfma_enabled()
+    ops._project_grad(g.to(DEV), w.to(DEV), out)
+    err_split = (out.cpu().double() - ref).abs().max().item()
+    err_fp32 = ((g @ w).double() - ref).abs().max().item()
+    assert err_split <= max(2.0 * err_fp32, 2e-7 * ref.abs().max().item()), (err_split, err_fp32)
+
+
+@pytest.mark.parametrize("nodes,steps,shift", [(1, 1, False), (1, 1, True), (5, 3, True), (37, 8, False), (37, 8, True),
+                                               (4099, 8, True), (9000, 16, True), (20000, 6, False)])
+def test_split_bf16_weight_gradient_is_fp32_accurate(nodes, steps, shift):
+    """ctgcn_gru_weight_grad_f32: dW = sum_r [g01[:, :256] | g2]^T x' (x' optionally shifted one step inside each sequence,
+    i.e. h_{t-1} from the h sequence) against fp64; error no worse than a plain fp32 GEMM's.  Row counts that are not
+    multiples of the 32-row chunk, fewer chunks than block pairs, strided g01."""
+    from ctgcn_amd import ops
+    torch.manual_seed(nodes * 17 + steps)
+    R = nodes * steps
+    dgi = torch.randn(R, 384) * 0.5
+    dghn = torch.randn(R, 128) * 0.5
+    x = torch.tanh(torch.randn(nodes, steps, 128))
+    if shift:
+        xs = torch.zeros_like(x)
+        xs[:, 1:] = x[:, :-1]
+        G = torch.cat([dgi[:, :256], dghn], 1)
+    else:
+        xs = x
+        G = dgi
+    ref = G.double().t() @ xs.reshape(R, 128).double()
+    part = torch.full((ops._DW_PAIRS, 384, 128), float("nan"), device=DEV)
+    dgi_d = dgi.to(DEV)
+    ops._weight_grad(part, dgi_d, dghn.to(DEV) if shift else dgi_d[:, 256:], x.reshape(R, 128).to(DEV), steps, shift, False)
+    out = part.sum(0)
+    err_split = (out.cpu().double() - ref).abs().max().item()
+    err_fp32 = ((G.t() @ xs.reshape(R, 128)).double() - ref).abs().max().item()
+    assert err_split <= max(2.0 * err_fp32, 3e-7 * ref.abs().max().item()), (err_split, err_fp32)
+    ops._weight_grad(part, dgi_d, dghn.to(DEV) if shift else dgi_d[:, 256:], x.reshape(R, 128).to(DEV), steps, shift, True)
+    assert torch.allclose(part.sum(0).cpu().double(), 2 * ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item())   # accumulate flag

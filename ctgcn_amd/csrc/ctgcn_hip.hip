@@ -1582,9 +1582,12 @@ __global__ __launch_bounds__(512, 2) void gru_dx_x3_kernel(const DxArgs a)
 // b + 8 (same XCD, shared L2) walk the same rows with the two halves, so X is fetched from HBM once.  Every block pair
 // adds its partial sum to `partial[pair]` (its own slice, no atomics); the host adds the pairs (deterministic).
 // shift: X row r is taken as (r % steps ? X[r - 1] : 0) — h_{t-1} straight from the saved h sequence, no shifted copy.
-// Measured: 0.49 ms per 0.5 M row-steps = hipBLASLt's fp32 TN GEMM; load issue, staging (split + conflicting LDS
-// stores) and MFMA phases add up instead of overlapping (ablation: 0.13 + 0.18 + 0.11 ms + 0.07 fixed).  A
-// producer/consumer wave split was tried and is slower (the producers' instruction issue becomes the limit).
+// Measured 0.40 ms per 0.5 M row-steps (hipBLASLt fp32 split-K TN GEMM: 0.50 ms).  Ablation (remove one component, keep the
+// rest): no MFMA 0.28, no global loads 0.28, no staging 0.28, no barrier 0.37 — the three costs (~0.12 ms each) ADD even
+// with the loads three chunks ahead and the staging VALU interleaved between the MFMAs: on a SIMD the matrix pipe and
+// the VALU do not run concurrently for this instruction mix, and the 160 dword-per-lane buffer loads of a chunk keep the
+// CU's address unit busy for about as long as the MFMAs take.  Next: 16-byte loads + an in-register 4x4 transpose
+// (4x fewer address-unit cycles), fewer VALU ops per value in the split.
 constexpr int DW_KB = 32;          // rows per chunk = MFMA K
 constexpr int DW_MH = 192;         // gate columns per block
 constexpr int DW_PITCH = 40;       // bf16 per transposed plane row: 32 + 8 pad, 80-byte rows stay 16-byte aligned
@@ -1604,11 +1607,6 @@ struct DwArgs {
     int32_t accumulate;    // partial += instead of partial =
 };
 
-// 8-byte strips of a transposed plane row are stored at strip ^ swz(column): the 64 lanes of a staging store (consecutive
-// columns, same strip) would otherwise hit 8 bank pairs 8 times each (row pitch 20 dwords).  The swizzle keeps 16-byte
-// pairs of strips together, so a fragment read is still one aligned ds_read_b128 at 16-byte slot grp ^ (swz >> 1).
-__device__ __forceinline__ int dw_swz(int column) { return ((column >> 3) & 3) << 1; }
-
 __global__ __launch_bounds__(512, 2) void gru_dw_x3_kernel(const DwArgs a)
 {
     __shared__ __bf16 Gt[2][3][DW_MH][DW_PITCH];
@@ -1624,39 +1622,69 @@ __global__ __launch_bounds__(512, 2) void gru_dw_x3_kernel(const DwArgs a)
     const int64_t c_lo = min((int64_t)pair * per, nchunks), c_hi = min(c_lo + per, nchunks);
     const int sh = a.shift ? 1 : 0;
 
-    // Staging items: idx = 512*i + 64*wave + lane; G half = 8 strips (of 4 rows) x 192 columns = 3 items per thread,
-    // X = 8 x 128 = 2 items per thread.  192 and 128 are multiples of 64, so an item's strip and 64-column group are
-    // WAVE-UNIFORM: addresses are scalar bases (row, source matrix, clamps, step shift resolved on the scalar unit)
-    // plus the lane index.  Loads are unconditional and nothing touches the loaded registers until stage_chunk (a
-    // guarded load becomes its own basic block behind a s_waitcnt; a select right after the load would wait for it).
-    auto g_item = [&](int i, int &strip, int &cb) { const int base = 512 * i + 64 * wv; strip = base / DW_MH; cb = base % DW_MH; };
-    auto x_item = [&](int i, int &strip, int &cb) { const int base = 512 * i + 64 * wv; strip = base >> 7; cb = base & (GRU_H - 1); };
-    auto load_chunk = [&](int64_t chunk, f4v (&gs)[3], f4v (&xs)[2]) {
-        const int64_t row0 = chunk * DW_KB;
-        const bool interior = row0 + DW_KB <= a.rows && row0 >= sh;          // no row clamps needed
+    // Staging: a wave-item is 32 columns x 2 strips (of 4 rows): lane -> column lc = (lane & 7) + 8*(lane >> 4), strip parity
+    // par = bit 3 of the lane.  The 16 lanes that store in one LDS clock are then 8 columns x both strips of a 16-byte
+    // slot: with 80-byte plane rows (20 dwords: 8 consecutive columns start on the 8 different bank quads) the bf16x4
+    // stores are conflict-free.  [A lane -> 64 consecutive columns mapping puts lanes l and l+8 on the same bank pair:
+    // 8-way conflicts that made staging the most expensive phase of the kernel.]
+    // G half = 4 strip pairs x 6 column groups = 24 wave-items, X = 4 x 4 = 16: five per wave (3 of G, 2 of X).  Item
+    // geometry, source matrix, rows and the step shift are wave-uniform (scalar unit); the per-lane part of an address is a
+    // constant offset.  Loads are unconditional and nothing touches the loaded registers until stage_chunk (a guarded
+    // load becomes its own basic block behind a s_waitcnt; a select right after the load would wait for it).
+    // A wave issues at most one instruction every ~4 cycles, so the 72 MFMAs of a chunk (1152 cycles) leave room for
+    // only ~300 other instructions per wave and chunk.  The first versions spent ~2000 (64-bit scalar address products,
+    // a 64-bit modulo, clamps for every load) and ran at hipBLASLt's fp32 speed no matter what else was tuned.  Hence
+    // buffer loads: one descriptor per item (base = the item's first column at the block's first row, range = up to the
+    // item's columns in the last valid row), a per-lane byte offset that advances by one v_add per load and chunk, and
+    // the hardware range check returns 0 for rows past the end (and for row -1 of the shifted operand, whose offset
+    // wraps; that row is a t = 0 row) — no clamps, no tail masks.  Descriptor inputs go through readfirstlane so that the compiler can prove
+    // them wave-uniform (otherwise every load is wrapped in a waterfall loop).
+    const int lc = (lane & 7) + 8 * (lane >> 4), par = (lane >> 3) & 1;
+    const int64_t row_lo = c_lo * DW_KB;
+    __amdgpu_buffer_rsrc_t rs_[5];
+    int sp_[5], cb_[5];                 // item geometry (scalar): strip pair, first column
+    uint32_t voff_[5][4];               // per lane byte offset of row (8*sp + 4*par + j [- shift]) of the current chunk, column lc
+    uint32_t adv_[5];                   // bytes per chunk
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            int strip, cb;
-            g_item(i, strip, cb);
-            const int m0 = half * DW_MH + cb;                                // 64 columns m0 .. m0+63 come from one matrix
-            const int64_t ld = m0 < 2 * GRU_H ? a.ldg01 : a.ldg2;
-            const float *src = m0 < 2 * GRU_H ? a.g01 + m0 : a.g2 + (m0 - 2 * GRU_H);
+    for (int i = 0; i < 5; ++i) {
+        const int q = 8 * (i < 3 ? i : i - 3) + wv;
+        int64_t ld, last_row, first_row; // rows of the matrix this item's descriptor spans
+        int back = 0;                    // rows between the descriptor base and the block's first row
+        const float *src;
+        if (i < 3) {
+            sp_[i] = q / 6; cb_[i] = 32 * (q % 6);
+            const int m0 = half * DW_MH + cb_[i];                        // 32 columns m0 .. m0+31 come from one matrix
+            ld = m0 < 2 * GRU_H ? a.ldg01 : a.ldg2;
+            src = m0 < 2 * GRU_H ? a.g01 + m0 : a.g2 + (m0 - 2 * GRU_H);
+            last_row = a.rows - 1;
+        } else {
+            sp_[i] = q >> 2; cb_[i] = 32 * (q & 3);
+            ld = a.ldx;
+            src = a.x + cb_[i];
+            last_row = a.rows - 1 - sh;                                  // row r reads x[r - 1] ...
+            back = row_lo >= sh ? sh : 0;                                // ... so the span starts one row before the block's
+        }                                                                // (row -1 of the whole matrix: offset wraps -> 0)
+        first_row = row_lo - back;
+        const uint64_t base = (uint64_t)(src + first_row * ld);
+        const int64_t bytes = (last_row - first_row) * ld * 4 + 32 * 4;  // may be <= 0: nothing readable
+        const uint32_t b_lo = __builtin_amdgcn_readfirstlane((uint32_t)base), b_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        const uint32_t nrec = __builtin_amdgcn_readfirstlane((uint32_t)max(min(bytes, (int64_t)0x7fffffff), (int64_t)0));
+        rs_[i] = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)b_hi << 32) | b_lo), 0, nrec, 0x00020000);
+        adv_[i] = (uint32_t)(DW_KB * ld * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            voff_[i][j] = (uint32_t)(((8 * sp_[i] + 4 * par + j - (i < 3 ? 0 : sh) + back) * ld + lc) * 4);
+    }
+    // Loads must be issued for consecutive chunks (the offsets advance by one chunk per call); nothing touches the loaded
+    // registers until stage_chunk (a select right after a load would wait for it before the MFMAs instead of after).
+    auto load_chunk = [&](f4v (&v)[5]) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t r = row0 + 4 * strip + j;
-                gs[i][j] = (src + (interior ? r : min(r, a.rows - 1)) * ld)[lane];
+                v[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_[i], voff_[i][j], 0, 0));
+                voff_[i][j] += adv_[i];
             }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int strip, cb;
-            x_item(i, strip, cb);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t r = row0 + 4 * strip + j - sh;
-                xs[i][j] = (a.x + (interior ? r : max(min(r, a.rows - 1 - sh), (int64_t)0)) * a.ldx + cb)[lane];
-            }
-        }
     };
     auto split4 = [&](const f4v v, __bf16 *dst, int plane_elems) {
         bf4v s0, s1, s2;
@@ -1670,35 +1698,34 @@ __global__ __launch_bounds__(512, 2) void gru_dw_x3_kernel(const DwArgs a)
         *(bf4v *)(dst + plane_elems) = s1;
         *(bf4v *)(dst + 2 * plane_elems) = s2;
     };
-    // out-of-range rows and the t = 0 rows of the shifted operand are zeroed here (scalar conditions)
-    auto stage_chunk = [&](int buf, int64_t chunk, const f4v (&gs)[3], const f4v (&xs)[2]) {
-        const int64_t row0 = chunk * DW_KB;
-        const int tbase = a.shift ? (int)(row0 % a.steps) : 0;
-        const int valid = (int)min((int64_t)DW_KB, a.rows - row0);          // rows of this chunk that exist
+    // Step bookkeeping for the shifted operand, branch-free: t = step index (mod steps) of a row; rows with t == 0 are h_{-1} = 0.
+    // Without shift the same code runs with steps = INT_MAX and t starting at 1 (never 0), so that a whole loop iteration
+    // is ONE basic block and the scheduler can slot the split/store VALU work between the MFMAs (3 issue slots per MFMA).
+    const int steps_e = a.shift ? a.steps : 0x7fffffff;
+    int toff_[2][2];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            int strip, cb;
-            g_item(i, strip, cb);
-            f4v v = gs[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = 4 * strip + j < valid ? v[j] : 0.f;
-            const int c = cb + lane;
-            split4(v, &Gt[buf][0][c][4 * (strip ^ dw_swz(c))], DW_MH * DW_PITCH);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int strip, cb;
-            x_item(i, strip, cb);
-            int t = a.shift ? (tbase + 4 * strip) % a.steps : 1;           // step index of the strip's first row
-            f4v v = xs[i];
+    for (int i = 0; i < 2; ++i) {
+        toff_[i][0] = a.shift ? (8 * sp_[3 + i]) % a.steps : 0;
+        toff_[i][1] = a.shift ? (8 * sp_[3 + i] + 4) % a.steps : 0;
+    }
+    const int tadv = a.shift ? DW_KB % a.steps : 0;
+    auto wrap = [&](int t) { return t >= steps_e ? t - steps_e : t; };
+    // stage one of the five items of a chunk: split + three bf16x4 stores; the t = 0 rows of the shifted operand are zeroed
+    // here, rows past the end already arrived as 0
+    auto stage_item = [&](int i, int buf, int tbase, const f4v (&vv)[5]) {
+        f4v v = vv[i];
+        if (i >= 3) {
+            int t0 = wrap(tbase + toff_[i - 3][0]), t1 = wrap(tbase + toff_[i - 3][1]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = (4 * strip + j < valid && t != 0) ? v[j] : 0.f;
-                if (a.shift) t = (t + 1 == a.steps) ? 0 : t + 1;
+                const bool keep = par ? t1 != 0 : t0 != 0;
+                v[j] = keep ? v[j] : 0.f;
+                t0 = (t0 + 1 == steps_e) ? 0 : t0 + 1;
+                t1 = (t1 + 1 == steps_e) ? 0 : t1 + 1;
             }
-            const int c = cb + lane;
-            split4(v, &Xt[buf][0][c][4 * (strip ^ dw_swz(c))], GRU_H * DW_PITCH);
         }
+        if (i < 3) split4(v, &Gt[buf][0][cb_[i] + lc][8 * sp_[i] + 4 * par], DW_MH * DW_PITCH);
+        else split4(v, &Xt[buf][0][cb_[i] + lc][8 * sp_[i] + 4 * par], GRU_H * DW_PITCH);
     };
 
     const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
@@ -1708,53 +1735,74 @@ __global__ __launch_bounds__(512, 2) void gru_dw_x3_kernel(const DwArgs a)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = zero4;
 
-    // one iteration: LDS buffer `buf` holds chunk `chunk`; `nxt` registers hold chunk+1; chunk+2 is loaded into `far`
-    // a fragment row is column tile*16 + col: its swizzle bits are (tile & 1, col >> 3)
-    const int rslot_even = 8 * (grp ^ (col >> 3)), rslot_odd = 8 * (grp ^ (2 | (col >> 3)));
-    auto iteration = [&](int64_t chunk, int buf, f4v (&far_g)[3], f4v (&far_x)[2], const f4v (&nxt_g)[3], const f4v (&nxt_x)[2]) {
-        if (chunk + 2 < c_hi) load_chunk(chunk + 2, far_g, far_x);
+    // One iteration: LDS buffer `buf` holds chunk `chunk`; `nxt` registers hold chunk+1; chunk+3 is loaded into `far` (the
+    // set that held `chunk`, already staged).  No guards: loads past the block's range are out of range for the
+    // descriptors (no memory access, zeros), and staging a chunk nobody multiplies is harmless.
+    int tb = a.shift ? (int)((c_lo * DW_KB) % a.steps) : 1;              // step index of the first row of the chunk being staged
+    auto iteration = [&](int buf, f4v (&far)[5], const f4v (&nxt)[5]) {
+        load_chunk(far);
+        tb = wrap(tb + tadv);
         bf8v af[3][3];     // [m tile][split]: A[m = gate column][k = row 8*grp + j]
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) af[mt][sp] = *(const bf8v *)(&Gt[buf][sp][(3 * mg + mt) * 16 + col][((3 * mg + mt) & 1) ? rslot_odd : rslot_even]);
+            for (int sp = 0; sp < 3; ++sp) af[mt][sp] = *(const bf8v *)(&Gt[buf][sp][(3 * mg + mt) * 16 + col][8 * grp]);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             bf8v bfr[3];   // B[k = row][n = input column]
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) bfr[sp] = *(const bf8v *)(&Xt[buf][sp][(4 * ng + nt) * 16 + col][(nt & 1) ? rslot_odd : rslot_even]);
+            for (int sp = 0; sp < 3; ++sp) bfr[sp] = *(const bf8v *)(&Xt[buf][sp][(4 * ng + nt) * 16 + col][8 * grp]);
 #define CTGCN_X3_MFMA(I, J)                                                                                              \
             _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                             \
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][I], bfr[J], acc[mt][nt], 0, 0, 0);
             CTGCN_X3_PAIRS(CTGCN_X3_MFMA)
 #undef CTGCN_X3_MFMA
+            stage_item(nt, buf ^ 1, tb, nxt);                          // the next chunk's staging rides under these MFMAs
         }
-        if (chunk + 1 < c_hi) stage_chunk(buf ^ 1, chunk + 1, nxt_g, nxt_x);
+        stage_item(4, buf ^ 1, tb, nxt);
         __syncthreads();
     };
 
-    f4v g_a[3], x_a[2], g_b[3], x_b[2];
+    f4v va[5], vb[5], vc[5];           // three register sets: loads run three chunks ahead of their use
+    load_chunk(va);
+    load_chunk(vb);
+    load_chunk(vc);
     if (c_lo < c_hi) {
-        load_chunk(c_lo, g_a, x_a);
-        if (c_lo + 1 < c_hi) load_chunk(c_lo + 1, g_b, x_b);
-        stage_chunk(0, c_lo, g_a, x_a);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) stage_item(i, 0, tb, va);
     }
     __syncthreads();
-    for (int64_t chunk = c_lo; chunk < c_hi; chunk += 2) {
-        iteration(chunk, 0, g_a, x_a, g_b, x_b);                       // chunk+1 sits in set b, chunk+2 goes to set a
-        if (chunk + 1 < c_hi) iteration(chunk + 1, 1, g_b, x_b, g_a, x_a);
+    for (int64_t chunk = c_lo; chunk < c_hi; chunk += 6) {              // buffer parity and register set both repeat after 6
+        iteration(0, va, vb);                                          // chunk+1 sits in b, chunk+2 in c, chunk+3 goes to a
+        if (chunk + 1 < c_hi) iteration(1, vb, vc);
+        if (chunk + 2 < c_hi) iteration(0, vc, va);
+        if (chunk + 3 < c_hi) iteration(1, va, vb);
+        if (chunk + 4 < c_hi) iteration(0, vb, vc);
+        if (chunk + 5 < c_hi) iteration(1, vc, va);
     }
-    // D layout: lane (col, grp) holds D[m = 4*grp + i][n = col]
+    // D layout: lane (col, grp) holds D[m = 4*grp + i][n = col].  All 48 reads of the running partial sums are issued
+    // before the first add (one guarded read-modify-write per element serialises 48 memory latencies per call).
     float *out = a.partial + (int64_t)pair * (3 * GRU_H) * GRU_H;
+    auto oidx = [&](int mt, int nt, int i) { return (half * DW_MH + (3 * mg + mt) * 16 + 4 * grp + i) * GRU_H + (4 * ng + nt) * 16 + col; };
+    if (a.accumulate) {
+        f4v prev[3][4];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) prev[mt][nt][i] = out[oidx(mt, nt, i)];
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] += prev[mt][nt];
+    }
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = half * DW_MH + (3 * mg + mt) * 16 + 4 * grp + i, n = (4 * ng + nt) * 16 + col;
-                out[m * GRU_H + n] = a.accumulate ? out[m * GRU_H + n] + acc[mt][nt][i] : acc[mt][nt][i];
-            }
+            for (int i = 0; i < 4; ++i) out[oidx(mt, nt, i)] = acc[mt][nt][i];
 }
 
 // final core numbers; with a level cap the unpeeled vertices (current degree >= cap) are reported as `cap`

@@ -199,7 +199,8 @@ def test_split_bf16_input_gradient_is_fp32_accurate(rows):
 
 
 @pytest.mark.parametrize("nodes,steps,shift", [(1, 1, False), (1, 1, True), (5, 3, True), (37, 8, False), (37, 8, True),
-                                               (4099, 8, True), (9000, 16, True), (20000, 6, False)])
+                                               (4099, 8, True), (9000, 16, True), (20000, 6, False), (1000, 5, True), (1000, 5, False),
+                                               (333, 7, True), (6000, 3, True)])
 def test_split_bf16_weight_gradient_is_fp32_accurate(nodes, steps, shift):
     """ctgcn_gru_weight_grad_f32: dW = sum_r [g01[:, :256] | g2]^T x' (x' optionally shifted one step inside each sequence,
     i.e. h_{t-1} from the h sequence) against fp64; error no worse than a plain fp32 GEMM's.  Row counts that are not

@@ -214,22 +214,28 @@ def main():
     proj = [(s.elapsed_time(e), meta) for name, s, e, meta in launches if name == "gru_proj"]
     roof_mfma = None
     if gru:
-        split = ops.split_mfma_enabled()
-        # fp32-equivalent flops; step 0 (h = 0) issues no MFMA.  Split path: 6 bf16 products per fp32 product, so the
-        # matrix-core bound is the dense bf16 peak / 6; exact path: the fp32 MFMA peak.
-        peak = 2500.0 / 6.0 if split else 157.3
+        mode = ops.forward_split_mode()
+        # fp32-equivalent flops; step 0 (h = 0) issues no MFMA.  The matrix-core bound is the dense 16-bit peak divided by
+        # the number of 16-bit products per fp32 product (fp16x2: 3, bf16x3: 6), or the fp32 MFMA peak for the exact path.
+        peak = {2: 2500.0 / 3.0, 1: 2500.0 / 6.0, 0: 157.3}[mode]
+        name = {2: "gru_seq_h2_kernel (GRU recurrence + sum + LayerNorm; fp32 operands scaled per row and split into two fp16 "
+                   "terms, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)",
+                1: "gru_seq_x3_kernel (GRU recurrence + sum + LayerNorm; fp32 operands split 3-way into bf16, "
+                   "6 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate)",
+                0: "gru_seq_kernel (GRU recurrence + sum + LayerNorm, v_mfma_f32_16x16x4_f32)"}[mode]
+        pname = {2: "gru_proj_h2_kernel", 1: "gru_proj_x3_kernel", 0: "hipBLASLt fp32 GEMM"}[mode]
         flops = sum(m["rows"] * (m["steps"] - 1) * 2.0 * 128 * 384 for _, m in gru)
+        gi_bytes = sum(m["rows"] * m["steps"] * 1536.0 for _, m in gru)    # the projection's output read back, 1536 B per row-step
         ms = sum(t for t, _ in gru)
-        roof_mfma = {"kernel": ("gru_seq_x3_kernel (GRU recurrence + sum + LayerNorm; fp32 operands split 3-way into bf16, "
-                                "6 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate)") if split else
-                               "gru_seq_kernel (GRU recurrence + sum + LayerNorm, v_mfma_f32_16x16x4_f32)",
+        roof_mfma = {"kernel": name,
                      "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
                      "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
+                     "gi_read_GBps": round(gi_bytes / (ms * 1e-3) / 1e9, 1),
                      "launches_timed": len(gru), "ms_per_step_rank0": round(ms / args.steps, 3)}
         if proj:
             pms = sum(t for t, _ in proj)
             pbytes = sum(m["rows"] * 2048.0 for _, m in proj)          # 512 B read + 1536 B written per row
-            roof_mfma["input_projection"] = {"kernel": "gru_proj_x3_kernel", "bound": "hbm", "ms_per_step_rank0": round(pms / args.steps, 3),
+            roof_mfma["input_projection"] = {"kernel": pname, "bound": "hbm", "ms_per_step_rank0": round(pms / args.steps, 3),
                                              "achieved": round(pbytes / (pms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": round(pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if use_dist:

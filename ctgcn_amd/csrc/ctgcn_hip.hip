@@ -1152,6 +1152,297 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp16x2 split arithmetic (the default of the forward path).  Measured (tools/probes/mfma_f16x2_probe.hip): an fp32
+// operand x is written x = s·(x1 + x2·2^-11) with s a power of two chosen per ROW so that max|x/s| is in [2^14, 2^15),
+// x1 = fp16(x/s), x2 = fp16((x/s − x1)·2^11)  (22 mantissa bits, no subnormal loss: the residual is rescaled).  Then
+//     x·y  ≈  sx·sy·[ x1·y1 + 2^-11·(x1·y2 + x2·y1) ]           (dropped: x2·y2 ≈ 2^-22 x·y)
+// = THREE v_mfma_f32_16x16x32_f16 into two fp32 accumulators.  Max error / Σ|a·b| over K = 128 dot products:
+// 1.1e-7 (projection-like data), against 2.5e-7 for the 3-way bf16 split with six products and 2.0e-7 for an fp32 fmaf
+// chain — more accurate than both at HALF the matrix-core work of bf16x3, two operand planes instead of three in LDS
+// and 96 instead of 144 weight VGPRs.  On gfx950 VALU work does not overlap MFMA work on a SIMD (tools/probes/
+// mfma_valu_overlap_probe.hip: MFMA + k FMAs costs the SUM), so halving the MFMAs is a direct win.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+
+// power-of-two scale s with m/s in [2^14, 2^15) for m = max|row| (biased exponent arithmetic; m = 0 or tiny -> a harmless huge 1/s)
+__device__ __forceinline__ void h2_scale(float m, float &s, float &inv_s)
+{
+    int e = (int)(__float_as_uint(m) >> 23);          // m >= 0
+    e = e < 15 ? 15 : (e > 253 ? 253 : e);
+    s = __uint_as_float((uint32_t)(e - 14) << 23);
+    inv_s = __uint_as_float((uint32_t)(268 - e) << 23);
+}
+// RS = residual scale: 2048 (two accumulators, exact down to fp16's subnormals) or 1 (one accumulator: the residual of an
+// element below 2^-18 of its row's maximum loses bits — an absolute error of 2^-40 of that maximum; used by the recurrence,
+// whose operands are bounded, measured 1.2e-7 vs 3.0e-7 for an fp32 chain)
+template <int RS>
+__device__ __forceinline__ void h2_split(float xs, _Float16 &a, _Float16 &b)     // xs = x / s
+{
+    a = (_Float16)xs;
+    b = (_Float16)((xs - (float)a) * (float)RS);
+}
+// 8 consecutive fp32 weights, already multiplied by 1/s, -> two fp16x8 fragments
+template <int RS>
+__device__ __forceinline__ void h2_split_x8(const float *src, float inv_s, h8v &s0, h8v &s1)
+{
+    const f4v lo = *(const f4v *)src, hi = *(const f4v *)(src + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        _Float16 a, b;
+        h2_split<RS>(lo[j] * inv_s, a, b); s0[j] = a; s1[j] = b;
+        h2_split<RS>(hi[j] * inv_s, a, b); s0[4 + j] = a; s1[4 + j] = b;
+    }
+}
+// Weight slice of a wave for the transposed product (weights = MFMA A operand): lane (col, grp) holds, for gate g and k chunk c,
+// W[g*128 + 16w + col][c*32 + 8*grp .. +7].  Rows are scaled individually: the row max is reduced over the four lanes that
+// share a row (grp 0..3), the scale goes to wscale[g][16w + col] (LDS, read back per OUTPUT column by the caller).
+template <int RS>
+__device__ __forceinline__ void h2_load_weights(const float *w, int wave, int col, int grp, h8v (&Wf)[2][4][3], float (*wscale)[GRU_H])
+{
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float *row = w + (int64_t)(g * GRU_H + wave * 16 + col) * GRU_H;
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f4v lo = *(const f4v *)(row + c * 32 + 8 * grp), hi = *(const f4v *)(row + c * 32 + 8 * grp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m = fmaxf(m, fmaxf(fabsf(lo[j]), fabsf(hi[j])));
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sc, inv;
+        h2_scale(m, sc, inv);
+        if (grp == 0) wscale[g][wave * 16 + col] = sc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h2_split_x8<RS>(row + c * 32 + 8 * grp, inv, Wf[0][c][g], Wf[1][c][g]);
+    }
+}
+// the three products of one k chunk for the three gates: acc1 += W1·x2 + W2·x1 (weight 2^-11), acc0 += W1·x1
+#define CTGCN_H2_MFMA(WF, C, X1, X2, A0, A1)                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) A1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[0][C][g], X2, A1[g], 0, 0, 0); \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) A1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[1][C][g], X1, A1[g], 0, 0, 0); \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) A0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[0][C][g], X1, A0[g], 0, 0, 0);
+// one-accumulator form (residuals not rescaled), small terms first
+#define CTGCN_H2_MFMA1(WF, C, X1, X2, A)                                                                                 \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) A[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[0][C][g], X2, A[g], 0, 0, 0); \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) A[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[1][C][g], X1, A[g], 0, 0, 0); \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) A[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[0][C][g], X1, A[g], 0, 0, 0);
+
+// GRU input projection, fp16x2 arithmetic.  Same structure as gru_proj_x3_kernel; in addition every X row gets its own
+// power-of-two scale (row max reduced over the 32 lanes that stage the row), kept in LDS next to the planes.
+__global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
+{
+    __shared__ _Float16 As[2][2][PJ_BM][PJ_PITCH];
+    __shared__ float rscale[2][PJ_BM];
+    __shared__ float wscale[3][GRU_H];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int col = lane & 15, grp = lane >> 4;
+
+    h8v Wf[2][4][3];      // [split][k chunk][gate]
+    h2_load_weights<2048>(a.w, wave, col, grp, Wf, wscale);
+    __syncthreads();
+    // transposed product: D[m = out column][n = X row]; a lane ends up with output columns 16w + 4*grp .. +3 of X row (lane & 15)
+    const int oc = wave * 16 + 4 * grp;
+    f4v bias[3], wsc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        bias[g] = a.bias ? *(const f4v *)(a.bias + g * GRU_H + oc) : f4v{0.f, 0.f, 0.f, 0.f};
+        wsc[g] = *(const f4v *)(&wscale[g][oc]);
+    }
+    const int64_t ntiles = (a.rows + PJ_BM - 1) / PJ_BM;
+    // staging role: 64 rows x 32 float4; idx -> (row = idx >> 5, c4 = idx & 31): the 32 lanes of a half wave hold one row
+    auto load_tile = [&](int64_t tile, f4v (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
+            int64_t r = tile * PJ_BM + (idx >> 5);
+            r = r < a.rows ? r : a.rows - 1;
+            v[i] = *(const f4v *)(a.x + r * a.ldx + (idx & 31) * 4);
+        }
+    };
+    auto stage_tile = [&](int buf, const f4v (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
+            float m = fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+            float sc, inv;
+            h2_scale(m, sc, inv);
+            if ((idx & 31) == 0) rscale[buf][idx >> 5] = sc;
+            h4v s0, s1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 p, q;
+                h2_split<2048>(v[i][j] * inv, p, q);
+                s0[j] = p; s1[j] = q;
+            }
+            _Float16 *dst = &As[buf][0][idx >> 5][(idx & 31) * 4];
+            *(h4v *)dst = s0;
+            *(h4v *)(dst + PJ_BM * PJ_PITCH) = s1;
+        }
+    };
+
+    f4v stage[4];
+    int buf = 0;
+    if ((int64_t)blockIdx.x < ntiles) {
+        load_tile(blockIdx.x, stage);
+        stage_tile(0, stage);
+    }
+    __syncthreads();
+    const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int64_t next = tile + gridDim.x;
+        if (next < ntiles) load_tile(next, stage);               // in flight during the MFMAs
+        const int64_t row0 = tile * PJ_BM;
+#pragma unroll
+        for (int rt = 0; rt < PJ_BM / 16; ++rt) {
+            f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const h8v x1 = *(const h8v *)(&As[buf][0][rt * 16 + col][c * 32 + 8 * grp]);
+                const h8v x2 = *(const h8v *)(&As[buf][1][rt * 16 + col][c * 32 + 8 * grp]);
+                CTGCN_H2_MFMA(Wf, c, x1, x2, acc0, acc1)
+            }
+            const int64_t row = row0 + rt * 16 + col;
+            const float rs = rscale[buf][rt * 16 + col];
+            if (row < a.rows) {
+                float *o = a.out + row * (3 * GRU_H) + oc;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) *(f4v *)(o + g * GRU_H) = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (wsc[g] * rs) + bias[g];
+            }
+        }
+        if (next < ntiles) stage_tile(buf ^ 1, stage);
+        __syncthreads();
+    }
+}
+
+// GRU recurrence, fp16x2 arithmetic: gru_seq_x3_kernel with two fp16 planes of h·2^14 (|h| < 1) instead of three bf16
+// planes, W_hh rows scaled individually, 36 instead of 72 MFMAs per 16-row tile and step.  The scale of a product
+// (row scale of W_hh × 2^-14) is folded into the gate pre-activation FMA, so the gate math costs what it did.
+template <bool REDUCE, bool SAVE>
+__global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
+{
+    __shared__ _Float16 Hs[2][2][GRU_BM][PJ_PITCH];
+    __shared__ float sbuf[GRU_BM][GRU_PITCH];      // REDUCE: running sum over steps; otherwise: fp32 h_t staged for the row-wise LayerNorm / store
+    __shared__ float wscale[3][GRU_H];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int oc = wave * 16 + 4 * grp;       // first of the 4 consecutive hidden units this lane produces
+    const int steps = a.steps;
+
+    h8v Wf[2][4][3];      // [split][k chunk][gate]
+    h2_load_weights<1>(a.whh, wave, col, grp, Wf, wscale);
+    __syncthreads();
+    f4v csc[3];           // product scale per output column: row scale of W_hh x 2^-14 (the scale of h)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) csc[g] = *(const f4v *)(&wscale[g][oc]) * (1.f / 16384.f);
+    const f4v b_hn = a.bhn ? *(const f4v *)(a.bhn + oc) : f4v{0.f, 0.f, 0.f, 0.f};
+    const int64_t ntiles = (a.rows + GRU_BM - 1) / GRU_BM;
+    const int gstride = steps * 3 * GRU_H;
+
+    for (int64_t tile_ = blockIdx.x; tile_ < ntiles; tile_ += gridDim.x) {
+        const int64_t tile = ntiles - 1 - tile_;      // newest GI first: the projection kernel wrote the high tiles last
+        const int64_t row0 = tile * GRU_BM;
+        const float *gi_tile = a.gi + row0 * gstride + oc;
+        const int last = (int)min((int64_t)GRU_BM, a.rows - row0) - 1;
+        auto goff = [&](int rt) { return min(rt * 16 + col, last) * gstride; };
+        f4v hreg[GRU_RT];
+
+        auto publish = [&](int buf, int r_, const f4v h) {     // split h·2^14 and store the two fp16 planes
+            h4v p, q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 x, y;
+                h2_split<1>(h[j] * 16384.f, x, y);
+                p[j] = x; q[j] = y;
+            }
+            *(h4v *)(&Hs[buf][0][r_][oc]) = p;
+            *(h4v *)(&Hs[buf][1][r_][oc]) = q;
+        };
+        // gate math for the lane's 4 hidden units of one row; ac: the accumulators of h_{t-1}·W_hh^T, still to be multiplied by csc
+        auto gates = [&](const f4v gr, const f4v gz, const f4v gn, const f4v (&ac)[3], const f4v hold, int t, int r_) {
+            f4v h, rv, zv, nv, an;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rv[j] = gru_sigmoid(fmaf(ac[0][j], csc[0][j], gr[j]));
+                zv[j] = gru_sigmoid(fmaf(ac[1][j], csc[1][j], gz[j]));
+                an[j] = fmaf(ac[2][j], csc[2][j], b_hn[j]);
+                nv[j] = gru_tanh(fmaf(rv[j], an[j], gn[j]));
+                h[j] = nv[j] + zv[j] * (hold[j] - nv[j]);
+            }
+            if (!REDUCE) *(f4v *)(&sbuf[r_][oc]) = h;
+            if (SAVE && r_ <= last) {
+                float *gp = a.gates + ((row0 + r_) * steps + t) * (4 * GRU_H) + oc;
+                *(f4v *)gp = rv; *(f4v *)(gp + GRU_H) = zv; *(f4v *)(gp + 2 * GRU_H) = nv; *(f4v *)(gp + 3 * GRU_H) = an;
+            }
+            return h;
+        };
+        const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
+        const f4v zero3[3] = {zero4, zero4, zero4};
+
+        // ---- step 0: h_{-1} = 0, no MFMA
+#pragma unroll
+        for (int rt = 0; rt < GRU_RT; ++rt) {
+            const float *p = gi_tile + goff(rt);
+            const f4v h = gates(*(const f4v *)p, *(const f4v *)(p + GRU_H), *(const f4v *)(p + 2 * GRU_H), zero3, zero4, 0, rt * 16 + col);
+            hreg[rt] = h;
+            publish(0, rt * 16 + col, h);
+            if (REDUCE) *(f4v *)(&sbuf[rt * 16 + col][oc]) = h;
+        }
+        __syncthreads();
+        auto emit_step = [&](int t) {      // per-step output: LayerNorm (or plain copy) of the staged fp32 rows, 512 B per row
+            for (int r = wave; r <= last; r += 8)
+                gru_layernorm_row(sbuf[r], a.out + ((row0 + r) * steps + t) * GRU_H, lane, a.gamma, a.beta, a.eps);
+            __syncthreads();               // the next step's gate math overwrites sbuf
+        };
+        if (!REDUCE) emit_step(0);
+
+        // software pipeline over the row tiles of a step: the gate math of tile rt-1 is issued among tile rt's MFMAs
+        for (int t = 1; t < steps; ++t) {
+            const int pb = (t - 1) & 1, cb = t & 1;
+            const float *gi_t = gi_tile + t * 3 * GRU_H;
+            f4v acc[2][3], gq[2][3];
+#pragma unroll
+            for (int rt = 0; rt <= GRU_RT; ++rt) {
+                const int cur = rt & 1, prv = cur ^ 1;
+                if (rt < GRU_RT) {
+                    const float *p = gi_t + goff(rt);
+                    gq[cur][0] = *(const f4v *)p; gq[cur][1] = *(const f4v *)(p + GRU_H); gq[cur][2] = *(const f4v *)(p + 2 * GRU_H);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc[cur][g] = zero4;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        // MFMA B operand: B[k][n = row] = h_{t-1}[row rt*16 + col][k = c*32 + 8*grp + j]
+                        const h8v x1 = *(const h8v *)(&Hs[pb][0][rt * 16 + col][c * 32 + 8 * grp]);
+                        const h8v x2 = *(const h8v *)(&Hs[pb][1][rt * 16 + col][c * 32 + 8 * grp]);
+                        CTGCN_H2_MFMA1(Wf, c, x1, x2, acc[cur])
+                    }
+                }
+                if (rt > 0) {
+                    const int rp = rt - 1;
+                    const f4v h = gates(gq[prv][0], gq[prv][1], gq[prv][2], acc[prv], hreg[rp], t, rp * 16 + col);
+                    hreg[rp] = h;
+                    publish(cb, rp * 16 + col, h);
+                    if (REDUCE) {
+                        f4v *sp_ = (f4v *)(&sbuf[rp * 16 + col][oc]);
+                        *sp_ = *sp_ + h;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!REDUCE) emit_step(t);
+        }
+        if (REDUCE)
+            for (int r = wave; r <= last; r += 8)
+                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+        __syncthreads();       // LDS is reused by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LSTM recurrence (rnn_type = 'LSTM', reference layers.py:27-28 / models.py:234-235), same fusion as the GRU:
 //   gates = GI_t + h_{t-1}·W_hhᵀ (order i,f,g,o; both biases are already in GI);  c_t = σ(f)·c_{t-1} + σ(i)·tanh(g);
 //   h_t = σ(o)·tanh(c_t);   out = LayerNorm(Σ_t h_t)  or  LayerNorm(h_t) per step.
@@ -2036,7 +2327,13 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 8-wave block per CU
-    if (a.reduce_sum && split_bf16)
+    if (split_bf16 == 2 && a.reduce_sum)
+        hipLaunchKernelGGL((gru_seq_h2_kernel<true, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (split_bf16 == 2 && a.gates)
+        hipLaunchKernelGGL((gru_seq_h2_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (split_bf16 == 2)
+        hipLaunchKernelGGL((gru_seq_h2_kernel<false, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (a.reduce_sum && split_bf16)
         hipLaunchKernelGGL((gru_seq_x3_kernel<true, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else if (split_bf16 && a.gates)
         hipLaunchKernelGGL((gru_seq_x3_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
@@ -2083,7 +2380,7 @@ int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
 }
 
 int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *x, int64_t ldx,
-                             const float *w_ih, const float *bias, float *gi, void *stream)
+                             const float *w_ih, const float *bias, float *gi, int split_mode, void *stream)
 {
     if (hidden != GRU_H || d_in != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_input_proj: only d_in = hidden = %d is built (got %d, %d)", GRU_H, d_in, hidden);
     if (rows < 0 || ldx < d_in) return fail(CTGCN_E_INVALID, "gru_input_proj: bad sizes");
@@ -2097,7 +2394,10 @@ int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const f
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int64_t ntiles = (rows + PJ_BM - 1) / PJ_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;
-    hipLaunchKernelGGL(gru_proj_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    if (split_mode == 2)
+        hipLaunchKernelGGL(gru_proj_h2_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(gru_proj_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -211,7 +211,7 @@ def core_aggregate(x, adj, relu=True):
 
 # ------------------------------------------------------------- GRU over the core / time axis (+ sum, LayerNorm)
 import os as _os
-_GI_MAX_ELEMS = int(_os.environ.get("CTGCN_GI_MAX_ELEMS", 1 << 28))   # fp32 elements of the projection buffer per row chunk (1 GiB)
+_GI_MAX_ELEMS = int(_os.environ.get("CTGCN_GI_MAX_ELEMS", 1 << 29))   # fp32 elements of the projection buffer per row chunk (2 GiB)
 
 
 def gru_fused_ok(rnn, seq):
@@ -239,10 +239,20 @@ def _row_chunks(lib, rows, steps, hid):
 
 
 def split_mfma_enabled():
-    """fp32-accurate bf16x3 split arithmetic on the bf16 matrix cores (default).  CTGCN_FP32_MFMA_ONLY=1 forces the
+    """fp32-accurate split arithmetic on the 16-bit matrix cores (default).  CTGCN_FP32_MFMA_ONLY=1 forces the
     plain fp32 paths (hipBLASLt fp32 GEMM + v_mfma_f32_16x16x4_f32 recurrence) for A/B comparisons."""
     import os
     return os.environ.get("CTGCN_FP32_MFMA_ONLY", "0") != "1"
+
+
+def forward_split_mode():
+    """Arithmetic of the forward GRU products (include/ctgcn_hip.h CTGCN_SPLIT_*): 2 = fp16x2 (default: per-row scaled
+    two-term fp16 split, three products — half the matrix work of bf16x3 and measured more accurate), 1 = bf16x3
+    (CTGCN_GRU_SPLIT=bf16x3), 0 = fp32 MFMA (CTGCN_FP32_MFMA_ONLY=1)."""
+    import os
+    if not split_mfma_enabled():
+        return 0
+    return 1 if os.environ.get("CTGCN_GRU_SPLIT", "f16x2") == "bf16x3" else 2
 
 
 def _project(x2d, w_ih, bias, out):
@@ -252,7 +262,7 @@ def _project(x2d, w_ih, bias, out):
         lib = _lib.load()
         with _timed("gru_proj", rows=x2d.shape[0]):
             check(lib.ctgcn_gru_input_proj_f32(x2d.shape[0], 128, 128, ptr(x2d), x2d.stride(0), ptr(w_ih), ptr(bias), ptr(out),
-                                               _stream()), "ctgcn_gru_input_proj_f32")
+                                               forward_split_mode(), _stream()), "ctgcn_gru_input_proj_f32")
         return
     if bias is None:
         torch.mm(x2d, w_ih.t(), out=out)
@@ -292,7 +302,7 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
         return out
     chunks = _row_chunks(lib, rows, steps, hid)
     gi_buf = torch.empty(chunks[0][1] * steps, 3 * hid, dtype=torch.float32, device=seq.device)
-    split = 1 if split_mfma_enabled() else 0
+    split = forward_split_mode()
     with torch.cuda.device(seq.device):
         for lo, n in chunks:
             gi = gi_buf[: n * steps]
@@ -379,7 +389,7 @@ class _GruSeq(torch.autograd.Function):
                 gi, gates, hseq = gi_buf[: n * steps], gates_buf[: n * steps], hseq_buf[:n]
                 _project(x2d, w_ih_d, bias, gi)
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq),
-                                            ptr(gates), 1 if split_mfma_enabled() else 0, _stream()), "ctgcn_gru_seq_f32")
+                                            ptr(gates), forward_split_mode(), _stream()), "ctgcn_gru_seq_f32")
                 # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)
                 g_out = dout[lo:lo + n]
                 pre = hseq.sum(1) if reduce_sum else hseq

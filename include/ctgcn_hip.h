@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 3
+#define CTGCN_ABI_VERSION 4
 
 enum {
     CTGCN_OK = 0,
@@ -52,6 +52,11 @@ enum { /* `op` of ctgcn_workspace_bytes */
 };
 
 #define CTGCN_MAX_SLOTS 255
+
+/* arithmetic of the GRU matrix products (ctgcn_gru_seq_f32, ctgcn_gru_input_proj_f32) */
+#define CTGCN_SPLIT_NONE 0
+#define CTGCN_SPLIT_BF16X3 1
+#define CTGCN_SPLIT_F16X2 2
 
 int ctgcn_abi_version(void);
 const char *ctgcn_last_error(void);
@@ -158,9 +163,12 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  * gi [rows, steps, 384] is the input projection x·W_ih^T + b_ih (+ b_hh for the r and z gates) in PyTorch's
  * gate order r,z,n — a plain GEMM the caller runs with its BLAS; w_hh [384,128] and b_hn [128] (the n-gate's
  * hidden bias, NULL = 0) are the module's weight_hh_l0 and bias_hh_l0[256:384].  ln_weight == NULL skips the
- * LayerNorm.  h_0 = 0.  split_bf16 == 0: exact fp32 (f32-input MFMA, an fmaf chain).  split_bf16 != 0:
- * fp32-accurate split arithmetic on the bf16 matrix cores — operands split
- * exactly into three bf16 terms, six partial products, fp32 accumulation — about twice the matrix throughput.
+ * LayerNorm.  h_0 = 0.  split_bf16 selects the arithmetic of the product h_{t-1}·W_hh^T (all fp32-accurate, fp32 I/O):
+ *   CTGCN_SPLIT_NONE   (0)  f32-input MFMA (an fmaf chain)
+ *   CTGCN_SPLIT_BF16X3 (1)  operands split exactly into three bf16 terms, six partial products, fp32 accumulation
+ *   CTGCN_SPLIT_F16X2  (2)  operands scaled per row by a power of two and split into two fp16 terms (22 bits), three
+ *                           partial products, fp32 accumulation: half the matrix-core work of (1) and measured MORE
+ *                           accurate than (0) and (1) (tools/probes/mfma_f16x2_probe.hip)
  * gates_out (optional; requires reduce_sum == 0 and ln_weight == NULL): [rows, steps, 4, 128] receives r, z, n and
  * q = W_hn·h_{t-1} + b_hn for ctgcn_gru_seq_bwd_f32.
  */
@@ -194,12 +202,11 @@ int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
 
 /*
  * The GRU input projection  gi[rows, 384] = x[rows, 128]·w_ih^T + bias  (bias [384] may be NULL) for d_in = hidden = 128,
- * in fp32-accurate split arithmetic on the bf16 matrix cores: each fp32 operand is split exactly into three bf16
- * terms and the six significant partial products accumulate in fp32 (error vs fp64 no larger than an fp32 fmaf
- * chain's, measured).  Other widths: use a BLAS GEMM.
+ * in fp32-accurate split arithmetic on the matrix cores: split_mode = CTGCN_SPLIT_BF16X3 or CTGCN_SPLIT_F16X2 (see
+ * ctgcn_gru_seq_f32; error vs fp64 no larger than an fp32 fmaf chain's, measured).  Other widths: use a BLAS GEMM.
  */
 int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *x, int64_t ldx,
-                             const float *w_ih, const float *bias, float *gi, void *stream);
+                             const float *w_ih, const float *bias, float *gi, int split_mode, void *stream);
 
 /*
  * Gradient of the projection w.r.t. its input: d_x[rows, 128] = d_gi[rows, 384] · W_ih  (autograd of the F.linear inside

@@ -19,7 +19,7 @@ def _ref(rnn, norm, x, reduce_sum):
     (4097, 5, 128, False, True, True), (300, 16, 128, False, True, True), (64, 3, 24, True, False, True),
     (257, 22, 128, True, True, False), (100, 2, 128, False, False, False),
 ])
-def test_fused_gru_matches_torch(rows, steps, d_in, reduce_sum, bias, use_norm):
+def test_fused_gru_matches_torch(rows, steps, d_in, reduce_sum, bias, use_norm, split_mode):
     from ctgcn_amd import ops
     torch.manual_seed(rows + steps)
     rnn = torch.nn.GRU(d_in, 128, 1, bias=bias, batch_first=True)
@@ -119,10 +119,21 @@ def test_training_and_inference_paths_agree():
     assert torch.equal(y_inf, y_train.detach())
 
 
+@pytest.fixture(params=["f16x2", "bf16x3"])
+def split_mode(request, monkeypatch):
+    """both 16-bit split arithmetics of the forward kernels (default fp16x2; CTGCN_GRU_SPLIT=bf16x3)"""
+    from ctgcn_amd import ops
+    monkeypatch.setenv("CTGCN_GRU_SPLIT", request.param)
+    monkeypatch.setenv("CTGCN_FP32_MFMA_ONLY", "0")
+    assert ops.forward_split_mode() == (2 if request.param == "f16x2" else 1)
+    return request.param
+
+
 @pytest.mark.parametrize("rows", [1, 63, 64, 1000, 70000])
-def test_split_bf16_projection_is_fp32_accurate(rows):
-    """ctgcn_gru_input_proj_f32 (3-way bf16 split, six products) vs an fp64 reference: its error must not exceed the
-    error of a plain fp32 GEMM of the same operands by more than a small factor, and both are ~1e-6."""
+def test_split_bf16_projection_is_fp32_accurate(rows, split_mode):
+    """ctgcn_gru_input_proj_f32 (fp16x2: per-row scaled two-term fp16 split, three products; bf16x3: three-term bf16 split,
+    six products) vs an fp64 reference: its error must not exceed the error of a plain fp32 GEMM of the same operands by
+    more than a small factor, and both are ~1e-6."""
     from ctgcn_amd import ops
     torch.manual_seed(rows)
     x = (torch.relu(torch.randn(rows, 128)) * 4.0)
@@ -164,20 +175,33 @@ def test_fused_lstm_matches_torch(rows, steps, d_in, reduce_sum, bias):
     np.testing.assert_allclose(got_train.detach().cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
 
 
-def test_split_bf16_projection_wide_dynamic_range():
-    """operands spanning 10 orders of magnitude (and exact zeros / negatives): the 3-way split keeps fp32 accuracy."""
+def test_split_bf16_projection_wide_dynamic_range(split_mode):
+    """operands spanning 10 orders of magnitude inside a row (and exact zeros / negatives), all-zero rows, rows of huge
+    (1e30) and of tiny (1e-30) entries, weight rows of very different magnitude: the split keeps fp32 accuracy."""
     from ctgcn_amd import ops
     torch.manual_seed(5)
     rows = 4096
     mag = 10.0 ** torch.empty(rows, 128).uniform_(-6, 4)
     x = mag * torch.sign(torch.randn(rows, 128)) * (torch.rand(rows, 128) > 0.1)
+    x[7] = 0.0
+    x[8] *= 1e26
+    x[9] *= 1e-20
+    x[10, 1:] = 0.0
     w = (10.0 ** torch.empty(384, 128).uniform_(-4, 0)) * torch.sign(torch.randn(384, 128))
+    w[5] *= 1e-12
+    w[6] *= 1e6
+    w[300] = 0.0
     ref = x.double() @ w.double().t()
     out = torch.empty(rows, 384, device=DEV)
     ops._project(x.to(DEV), w.to(DEV), None, out)
     # error measured against the magnitude of the terms that were summed (cancellation-aware bound)
     scale = (x.abs().double() @ w.abs().double().t())
-    err_split = ((out.cpu().double() - ref).abs() / scale).max().item()
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    zero = scale == 0                                   # all-zero row of x or of w: the result is exactly 0
+    assert bool((got[zero] == 0).all()) and int(zero.sum()) >= 128 + 4096
+    scale = torch.where(zero, torch.ones_like(scale), scale)
+    err_split = ((got - ref).abs() / scale).max().item()
     err_fp32 = (((x @ w.t()).double() - ref).abs() / scale).max().item()
     assert err_split <= max(2.0 * err_fp32, 3e-7), (err_split, err_fp32)
 

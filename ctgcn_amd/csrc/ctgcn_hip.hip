@@ -733,6 +733,7 @@ struct GruArgs {
     int32_t reduce_sum;     // 1: out[rows,128] = LN(sum_t h_t)   0: out[rows,steps,128] = LN(h_t)
     float *out;
     float *gates;           // optional [rows, steps, 4, 128]: r, z, n, q = W_hn h + b_hn, saved for the backward kernel
+    int32_t gi_blocked;     // gi is in the blocked tile layout (gi_blocked_offset); fp16x2 kernel only
 };
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each): far inside the fp32 tolerance of the layer, a fraction of an IEEE divide's cost
@@ -926,8 +927,18 @@ struct ProjArgs {
     int64_t ldx;
     const float *w;       // [384, 128]
     const float *bias;    // [384] or null
-    float *out;           // [rows, 384]
+    float *out;           // [rows, 384], or the blocked layout below
+    int32_t steps_blocked; // > 0: rows = nodes*steps sequences; out is written in the recurrence's tile layout (gi_blocked_offset)
 };
+
+// Blocked GI layout (fp16x2 path): [node tile of 64][step][gate][wave = 16-column group][node in tile][16 columns] floats.
+// The recurrence kernel's wave-load for (step, gate, 16-row tile) is then ONE contiguous KB instead of sixteen 64-byte
+// pieces 12 KB apart (measured: recurrence 3.32 -> 3.01 ms per 1 M x 8 call).  Same size as [nodes, steps, 384] when the
+// node count is a multiple of 64; the buffer must cover whole tiles.
+__device__ __forceinline__ int64_t gi_blocked_offset(int64_t node, int t, int steps, int gate, int column)
+{
+    return ((((node >> 6) * steps + t) * 3 + gate) * 8 + (column >> 4)) * 1024 + (node & 63) * 16 + (column & 15);
+}
 
 __global__ __launch_bounds__(512, 2) void gru_proj_x3_kernel(const ProjArgs a)
 {
@@ -1251,15 +1262,25 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
         bias[g] = a.bias ? *(const f4v *)(a.bias + g * GRU_H + oc) : f4v{0.f, 0.f, 0.f, 0.f};
         wsc[g] = *(const f4v *)(&wscale[g][oc]);
     }
-    const int64_t ntiles = (a.rows + PJ_BM - 1) / PJ_BM;
+    // Tiles: 64 consecutive rows, or — blocked output — 64 consecutive NODES at one step (rows S apart), so that a wave's
+    // 16 rows x 64 bytes of output are one contiguous KB of the blocked layout.
+    const int S = a.steps_blocked;
+    const int64_t nodes = S > 0 ? a.rows / S : 0;
+    const int64_t ntiles = S > 0 ? ((nodes + PJ_BM - 1) / PJ_BM) * S : (a.rows + PJ_BM - 1) / PJ_BM;
+    auto tile_row = [&](int64_t tile, int r_) -> int64_t {      // flat row of tile row r_, clamped to the last valid one
+        if (S > 0) {
+            const int64_t nt = tile / S;
+            const int64_t node = min(nt * PJ_BM + r_, nodes - 1);
+            return node * S + (tile - nt * S);
+        }
+        return min(tile * PJ_BM + r_, a.rows - 1);
+    };
     // staging role: 64 rows x 32 float4; idx -> (row = idx >> 5, c4 = idx & 31): the 32 lanes of a half wave hold one row
     auto load_tile = [&](int64_t tile, f4v (&v)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 512 * i;
-            int64_t r = tile * PJ_BM + (idx >> 5);
-            r = r < a.rows ? r : a.rows - 1;
-            v[i] = *(const f4v *)(a.x + r * a.ldx + (idx & 31) * 4);
+            v[i] = *(const f4v *)(a.x + tile_row(tile, idx >> 5) * a.ldx + (idx & 31) * 4);
         }
     };
     auto stage_tile = [&](int buf, const f4v (&v)[4]) {
@@ -1296,7 +1317,8 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const int64_t next = tile + gridDim.x;
         if (next < ntiles) load_tile(next, stage);               // in flight during the MFMAs
-        const int64_t row0 = tile * PJ_BM;
+        const int64_t nt = S > 0 ? tile / S : 0;
+        const int tstep = S > 0 ? (int)(tile - nt * S) : 0;
 #pragma unroll
         for (int rt = 0; rt < PJ_BM / 16; ++rt) {
             f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4};
@@ -1306,12 +1328,24 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
                 const h8v x2 = *(const h8v *)(&As[buf][1][rt * 16 + col][c * 32 + 8 * grp]);
                 CTGCN_H2_MFMA(Wf, c, x1, x2, acc0, acc1)
             }
-            const int64_t row = row0 + rt * 16 + col;
-            const float rs = rscale[buf][rt * 16 + col];
-            if (row < a.rows) {
-                float *o = a.out + row * (3 * GRU_H) + oc;
+            const int r_ = rt * 16 + col;
+            const float rs = rscale[buf][r_];
+            float *o;
+            int64_t gstep;
+            bool valid;
+            if (S > 0) {
+                valid = nt * PJ_BM + r_ < nodes;
+                o = a.out + ((nt * S + tstep) * 3 * 8 + wave) * 1024 + r_ * 16 + 4 * grp;      // gi_blocked_offset(node, tstep, S, 0, oc)
+                gstep = 8 * 1024;
+            } else {
+                const int64_t row = tile * PJ_BM + r_;
+                valid = row < a.rows;
+                o = a.out + row * (3 * GRU_H) + oc;
+                gstep = GRU_H;
+            }
+            if (valid) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g) *(f4v *)(o + g * GRU_H) = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (wsc[g] * rs) + bias[g];
+                for (int g = 0; g < 3; ++g) *(f4v *)(o + g * gstep) = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (wsc[g] * rs) + bias[g];
             }
         }
         if (next < ntiles) stage_tile(buf ^ 1, stage);
@@ -1327,7 +1361,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
 {
     __shared__ _Float16 Hs[2][2][GRU_BM][PJ_PITCH];
     __shared__ float sbuf[GRU_BM][GRU_PITCH];      // REDUCE: running sum over steps; otherwise: fp32 h_t staged for the row-wise LayerNorm / store
-    __shared__ float wscale[3][GRU_H];
+    __shared__ float wscale[4][GRU_H];             // rows 0-2: product scales of the three gates, row 3: b_hn
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 15, grp = lane >> 4;
     const int oc = wave * 16 + 4 * grp;       // first of the 4 consecutive hidden units this lane produces
@@ -1336,19 +1370,28 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
     h8v Wf[2][4][3];      // [split][k chunk][gate]
     h2_load_weights<1>(a.whh, wave, col, grp, Wf, wscale);
     __syncthreads();
-    f4v csc[3];           // product scale per output column: row scale of W_hh x 2^-14 (the scale of h)
+    // product scale per output column = row scale of W_hh x 2^-14 (the scale of h); kept in LDS together with b_hn and
+    // re-read by every gate block (4 ds_read_b128) — the 16 VGPRs go to the deeper GI prefetch below
+    if (grp == 0) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) csc[g] = *(const f4v *)(&wscale[g][oc]) * (1.f / 16384.f);
-    const f4v b_hn = a.bhn ? *(const f4v *)(a.bhn + oc) : f4v{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 3; ++g) wscale[g][wave * 16 + col] *= (1.f / 16384.f);
+        wscale[3][wave * 16 + col] = a.bhn ? a.bhn[wave * 16 + col] : 0.f;
+    }
+    __syncthreads();
     const int64_t ntiles = (a.rows + GRU_BM - 1) / GRU_BM;
     const int gstride = steps * 3 * GRU_H;
 
     for (int64_t tile_ = blockIdx.x; tile_ < ntiles; tile_ += gridDim.x) {
         const int64_t tile = ntiles - 1 - tile_;      // newest GI first: the projection kernel wrote the high tiles last
         const int64_t row0 = tile * GRU_BM;
-        const float *gi_tile = a.gi + row0 * gstride + oc;
         const int last = (int)min((int64_t)GRU_BM, a.rows - row0) - 1;
-        auto goff = [&](int rt) { return min(rt * 16 + col, last) * gstride; };
+        // address of the lane's float4 of gate 0 for (step t, row tile rt); gates are gi_gs floats apart
+        const float *gi_tile = a.gi_blocked ? a.gi + tile * (int64_t)gstride * GRU_BM + wave * 1024 + col * 16 + 4 * grp
+                                            : a.gi + row0 * gstride + oc;
+        const int gi_gs = a.gi_blocked ? 8 * 1024 : GRU_H;
+        auto gaddr = [&](int t, int rt) {
+            return a.gi_blocked ? gi_tile + t * (3 * 8 * 1024) + rt * 256 : gi_tile + t * 3 * GRU_H + min(rt * 16 + col, last) * gstride;
+        };
         f4v hreg[GRU_RT];
 
         auto publish = [&](int buf, int r_, const f4v h) {     // split h·2^14 and store the two fp16 planes
@@ -1364,6 +1407,8 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
         };
         // gate math for the lane's 4 hidden units of one row; ac: the accumulators of h_{t-1}·W_hh^T, still to be multiplied by csc
         auto gates = [&](const f4v gr, const f4v gz, const f4v gn, const f4v (&ac)[3], const f4v hold, int t, int r_) {
+            const f4v csc[3] = {*(const f4v *)(&wscale[0][oc]), *(const f4v *)(&wscale[1][oc]), *(const f4v *)(&wscale[2][oc])};
+            const f4v b_hn = *(const f4v *)(&wscale[3][oc]);
             f4v h, rv, zv, nv, an;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1386,8 +1431,8 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
         // ---- step 0: h_{-1} = 0, no MFMA
 #pragma unroll
         for (int rt = 0; rt < GRU_RT; ++rt) {
-            const float *p = gi_tile + goff(rt);
-            const f4v h = gates(*(const f4v *)p, *(const f4v *)(p + GRU_H), *(const f4v *)(p + 2 * GRU_H), zero3, zero4, 0, rt * 16 + col);
+            const float *p = gaddr(0, rt);
+            const f4v h = gates(*(const f4v *)p, *(const f4v *)(p + gi_gs), *(const f4v *)(p + 2 * gi_gs), zero3, zero4, 0, rt * 16 + col);
             hreg[rt] = h;
             publish(0, rt * 16 + col, h);
             if (REDUCE) *(f4v *)(&sbuf[rt * 16 + col][oc]) = h;
@@ -1400,17 +1445,24 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
         };
         if (!REDUCE) emit_step(0);
 
-        // software pipeline over the row tiles of a step: the gate math of tile rt-1 is issued among tile rt's MFMAs
+        // Software pipeline over the row tiles of a step: the gate math of tile rt-1 is issued among tile rt's MFMAs, and
+        // the GI operands of a row tile are requested TWO units (row tile x step) before its MFMAs start — a full step
+        // before its gate math — into four statically indexed buffers (the loaded HBM latency exceeds one step's MFMAs).
+        f4v gq[4][3];
+        auto load_gi = [&](int t, int rt) {
+            const float *p = gaddr(t, rt);
+            gq[rt][0] = *(const f4v *)p; gq[rt][1] = *(const f4v *)(p + gi_gs); gq[rt][2] = *(const f4v *)(p + 2 * gi_gs);
+        };
+        if (steps > 1) { load_gi(1, 0); load_gi(1, 1); }
         for (int t = 1; t < steps; ++t) {
             const int pb = (t - 1) & 1, cb = t & 1;
-            const float *gi_t = gi_tile + t * 3 * GRU_H;
-            f4v acc[2][3], gq[2][3];
+            f4v acc[2][3];
 #pragma unroll
             for (int rt = 0; rt <= GRU_RT; ++rt) {
                 const int cur = rt & 1, prv = cur ^ 1;
                 if (rt < GRU_RT) {
-                    const float *p = gi_t + goff(rt);
-                    gq[cur][0] = *(const f4v *)p; gq[cur][1] = *(const f4v *)(p + GRU_H); gq[cur][2] = *(const f4v *)(p + 2 * GRU_H);
+                    if (rt + 2 < GRU_RT) load_gi(t, rt + 2);
+                    else if (t + 1 < steps) load_gi(t + 1, rt + 2 - GRU_RT);
 #pragma unroll
                     for (int g = 0; g < 3; ++g) acc[cur][g] = zero4;
 #pragma unroll
@@ -1423,7 +1475,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
                 }
                 if (rt > 0) {
                     const int rp = rt - 1;
-                    const f4v h = gates(gq[prv][0], gq[prv][1], gq[prv][2], acc[prv], hreg[rp], t, rp * 16 + col);
+                    const f4v h = gates(gq[rp][0], gq[rp][1], gq[rp][2], acc[prv], hreg[rp], t, rp * 16 + col);
                     hreg[rp] = h;
                     publish(cb, rp * 16 + col, h);
                     if (REDUCE) {
@@ -2310,7 +2362,7 @@ int64_t ctgcn_gru_row_granule(void)
 
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, float *gates_out, int split_bf16, void *stream)
+                      int reduce_sum, float *out, float *gates_out, int split_bf16, int gi_blocked, void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq: hidden=%d, only %d is built", hidden, GRU_H);
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq: bad sizes rows=%lld steps=%d", (long long)rows, steps);
@@ -2320,7 +2372,8 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
         return fail(CTGCN_E_INVALID, "gru_seq: w_hh must be 16-byte aligned, out / ln_weight 8-byte aligned");
     GruArgs a{};
     a.rows = rows; a.steps = steps; a.gi = gi; a.whh = w_hh; a.bhn = b_hn; a.gamma = ln_weight; a.beta = ln_bias;
-    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = gates_out;
+    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = gates_out; a.gi_blocked = gi_blocked ? 1 : 0;
+    if (gi_blocked && split_bf16 != CTGCN_SPLIT_F16X2) return fail(CTGCN_E_INVALID, "gru_seq: the blocked gi layout belongs to CTGCN_SPLIT_F16X2");
     if (gates_out && (reduce_sum || ln_weight)) return fail(CTGCN_E_INVALID, "gru_seq: gates_out needs reduce_sum == 0 and no LayerNorm (raw h sequence)");
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
@@ -2380,7 +2433,7 @@ int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
 }
 
 int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *x, int64_t ldx,
-                             const float *w_ih, const float *bias, float *gi, int split_mode, void *stream)
+                             const float *w_ih, const float *bias, float *gi, int split_mode, int32_t steps_blocked, void *stream)
 {
     if (hidden != GRU_H || d_in != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_input_proj: only d_in = hidden = %d is built (got %d, %d)", GRU_H, d_in, hidden);
     if (rows < 0 || ldx < d_in) return fail(CTGCN_E_INVALID, "gru_input_proj: bad sizes");
@@ -2389,6 +2442,10 @@ int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const f
     if (!aligned16(x) || !aligned16(w_ih) || (ldx % 4)) return fail(CTGCN_E_INVALID, "gru_input_proj: x / w_ih must be 16-byte aligned, ldx a multiple of 4");
     ProjArgs a{};
     a.rows = rows; a.x = x; a.ldx = ldx; a.w = w_ih; a.bias = bias; a.out = gi;
+    if (steps_blocked < 0 || (steps_blocked > 0 && (split_mode != CTGCN_SPLIT_F16X2 || rows % steps_blocked)))
+        return fail(CTGCN_E_INVALID, "gru_input_proj: steps_blocked=%d needs CTGCN_SPLIT_F16X2 and rows a multiple of it", steps_blocked);
+    a.steps_blocked = steps_blocked;
+
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

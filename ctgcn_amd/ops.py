@@ -255,19 +255,29 @@ def forward_split_mode():
     return 1 if os.environ.get("CTGCN_GRU_SPLIT", "f16x2") == "bf16x3" else 2
 
 
-def _project(x2d, w_ih, bias, out):
-    """out[rows, 3h] = x2d @ w_ih^T + bias — the GRU input projection."""
-    if split_mfma_enabled() and x2d.shape[1] == 128 and w_ih.shape[0] == 384 and x2d.stride(1) == 1 \
+def _project(x2d, w_ih, bias, out, steps_blocked=0):
+    """out = x2d @ w_ih^T + bias — the GRU input projection.  Returns True when `out` was written in the recurrence
+    kernel's blocked tile layout (only asked for with steps_blocked > 0, only done by the fp16x2 kernel), else [rows, 3h]."""
+    mode = forward_split_mode()
+    if mode and x2d.shape[1] == 128 and w_ih.shape[0] == 384 and x2d.stride(1) == 1 \
             and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0 and w_ih.is_contiguous():
         lib = _lib.load()
+        blocked = steps_blocked if mode == 2 else 0
         with _timed("gru_proj", rows=x2d.shape[0]):
             check(lib.ctgcn_gru_input_proj_f32(x2d.shape[0], 128, 128, ptr(x2d), x2d.stride(0), ptr(w_ih), ptr(bias), ptr(out),
-                                               forward_split_mode(), _stream()), "ctgcn_gru_input_proj_f32")
-        return
+                                               mode, blocked, _stream()), "ctgcn_gru_input_proj_f32")
+        return blocked > 0
+    out = out[: x2d.shape[0] * w_ih.shape[0]].view(x2d.shape[0], w_ih.shape[0])
     if bias is None:
         torch.mm(x2d, w_ih.t(), out=out)
     else:
         torch.addmm(bias, x2d, w_ih.t(), out=out)
+    return False
+
+
+def _gi_buffer(rows, steps, hid, device):
+    """flat fp32 buffer for the projection of `rows` sequences; whole 64-row tiles (the blocked layout writes by tile)"""
+    return torch.empty(-(-rows // 64) * 64 * steps * 3 * hid, dtype=torch.float32, device=device)
 
 
 def _project_grad(dgi, w_ih, out):
@@ -301,15 +311,15 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
     if rows == 0:
         return out
     chunks = _row_chunks(lib, rows, steps, hid)
-    gi_buf = torch.empty(chunks[0][1] * steps, 3 * hid, dtype=torch.float32, device=seq.device)
+    gi_buf = _gi_buffer(chunks[0][1], steps, hid, seq.device)
     split = forward_split_mode()
     with torch.cuda.device(seq.device):
         for lo, n in chunks:
-            gi = gi_buf[: n * steps]
-            _project(seq[lo:lo + n].reshape(n * steps, d_in), w_ih, bias, gi)
+            blocked = _project(seq[lo:lo + n].reshape(n * steps, d_in), w_ih, bias, gi_buf, steps_blocked=steps)
             with _timed("gru_seq", rows=n, steps=steps):
-                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
-                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), None, split, _stream()), "ctgcn_gru_seq_f32")
+                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_buf), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
+                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), None, split, 1 if blocked else 0,
+                                            _stream()), "ctgcn_gru_seq_f32")
     return out
 
 
@@ -373,7 +383,7 @@ class _GruSeq(torch.autograd.Function):
         dln_b = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
         chunks = _row_chunks(lib, rows, steps, hid)
         cmax = chunks[0][1]
-        gi_buf = torch.empty(cmax * steps, 3 * hid, dtype=torch.float32, device=dev)       # reused as d_gi
+        gi_flat = _gi_buffer(cmax, steps, hid, dev)                                          # reused as d_gi
         gates_buf = torch.empty(cmax * steps, 4 * hid, dtype=torch.float32, device=dev)
         hseq_buf = torch.empty(cmax, steps, hid, dtype=torch.float32, device=dev)
         dghn_buf = torch.empty(cmax * steps, hid, dtype=torch.float32, device=dev)
@@ -386,10 +396,11 @@ class _GruSeq(torch.autograd.Function):
         with torch.cuda.device(dev):
             for lo, n in chunks:
                 x2d = seq[lo:lo + n].reshape(n * steps, d_in)
-                gi, gates, hseq = gi_buf[: n * steps], gates_buf[: n * steps], hseq_buf[:n]
-                _project(x2d, w_ih_d, bias, gi)
-                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq),
-                                            ptr(gates), forward_split_mode(), _stream()), "ctgcn_gru_seq_f32")
+                gates, hseq = gates_buf[: n * steps], hseq_buf[:n]
+                gi = gi_flat[: n * steps * 3 * hid].view(n * steps, 3 * hid)                 # the [rows, 3h] view (d_gi later)
+                blocked = _project(x2d, w_ih_d, bias, gi_flat, steps_blocked=steps)
+                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_flat), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq),
+                                            ptr(gates), forward_split_mode(), 1 if blocked else 0, _stream()), "ctgcn_gru_seq_f32")
                 # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)
                 g_out = dout[lo:lo + n]
                 pre = hseq.sum(1) if reduce_sum else hseq

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 4
+#define CTGCN_ABI_VERSION 5
 
 enum {
     CTGCN_OK = 0,
@@ -169,12 +169,14 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  *   CTGCN_SPLIT_F16X2  (2)  operands scaled per row by a power of two and split into two fp16 terms (22 bits), three
  *                           partial products, fp32 accumulation: half the matrix-core work of (1) and measured MORE
  *                           accurate than (0) and (1) (tools/probes/mfma_f16x2_probe.hip)
+ * gi_blocked != 0 (CTGCN_SPLIT_F16X2 only): gi is in the tile layout ctgcn_gru_input_proj_f32 writes for steps_blocked = steps
+ *   ([node tile of 64][step][gate][16-column group][node in tile][16]; the buffer must cover ceil(rows/64)*64 rows).
  * gates_out (optional; requires reduce_sum == 0 and ln_weight == NULL): [rows, steps, 4, 128] receives r, z, n and
  * q = W_hn·h_{t-1} + b_hn for ctgcn_gru_seq_bwd_f32.
  */
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, float *gates_out, int split_bf16, void *stream);
+                      int reduce_sum, float *out, float *gates_out, int split_bf16, int gi_blocked, void *stream);
 
 /*
  * The same for nn.LSTM (rnn_type = 'LSTM'; layers.py:27-28, models.py:234-235): gi [rows, steps, 512] = x·W_ih^T + b_ih
@@ -204,9 +206,11 @@ int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
  * The GRU input projection  gi[rows, 384] = x[rows, 128]·w_ih^T + bias  (bias [384] may be NULL) for d_in = hidden = 128,
  * in fp32-accurate split arithmetic on the matrix cores: split_mode = CTGCN_SPLIT_BF16X3 or CTGCN_SPLIT_F16X2 (see
  * ctgcn_gru_seq_f32; error vs fp64 no larger than an fp32 fmaf chain's, measured).  Other widths: use a BLAS GEMM.
+ * steps_blocked > 0 (CTGCN_SPLIT_F16X2 only): rows = nodes*steps_blocked rows of [nodes, steps, 128] sequences; gi is written
+ * in the recurrence kernel's tile layout (see ctgcn_gru_seq_f32, gi_blocked) instead of [rows, 384].
  */
 int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const float *x, int64_t ldx,
-                             const float *w_ih, const float *bias, float *gi, int split_mode, void *stream);
+                             const float *w_ih, const float *bias, float *gi, int split_mode, int32_t steps_blocked, void *stream);
 
 /*
  * Gradient of the projection w.r.t. its input: d_x[rows, 128] = d_gi[rows, 384] · W_ih  (autograd of the F.linear inside

@@ -23,6 +23,7 @@ SIGNATURES = {
     "ctgcn_abi_version": (_int, []),
     "ctgcn_last_error": (_c.c_char_p, []),
     "ctgcn_device_info": (_int, [_c.c_char_p, _sz, _c.POINTER(_int)]),
+    "ctgcn_transpose_bias_f32": (_int, [_i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "ctgcn_spmm_csr_f32": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp]),
     "ctgcn_core_aggregate_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _u32, _vp, _i32, _i32, _vp]),
     "ctgcn_core_aggregate_bwd_prep_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),

@@ -2148,6 +2148,42 @@ __global__ __launch_bounds__(512, 2) void gru_dw_x3_kernel(const DwArgs a)
             for (int i = 0; i < 4; ++i) out[oidx(mt, nt, i)] = acc[mt][nt][i];
 }
 
+// transpose_bias_kernel: out[i][j] = w[j][i] + bias[j] — Linear applied to one-hot (identity) node features is just Wᵀ + b
+// (reference helper.py:161-172 builds the identity, layers.py:95-106 multiplies by it).  32 x 128 tiles through LDS:
+// 128-byte reads along i, 512-byte rows written.  HBM-bound: 4 B read + 4 B written per element.
+__global__ __launch_bounds__(256) void transpose_bias_kernel(int64_t n, int d, const float *__restrict__ w, int64_t ldw,
+                                                             const float *__restrict__ bias, float *__restrict__ out, int64_t ldo)
+{
+    __shared__ float tile[128][33];
+    const int tid = threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * 32;
+    for (int j0 = 0; j0 < d; j0 += 128) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = (tid >> 3) + 32 * k, i4 = (tid & 7) * 4;
+            f4v v = f4v{0.f, 0.f, 0.f, 0.f};
+            if (j0 + j < d) {
+                const float *src = w + (int64_t)(j0 + j) * ldw + i0 + i4;
+                if (i0 + i4 + 3 < n && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) v = *(const f4v *)src;
+                else
+                    for (int q = 0; q < 4; ++q) if (i0 + i4 + q < n) v[q] = src[q];
+            }
+            tile[j][i4] = v[0]; tile[j][i4 + 1] = v[1]; tile[j][i4 + 2] = v[2]; tile[j][i4 + 3] = v[3];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = (tid >> 5) + 8 * k, j = (tid & 31) * 4;
+            if (i0 + i < n) {
+                float *dst = out + (i0 + i) * ldo + j0 + j;
+                for (int q = 0; q < 4; ++q)
+                    if (j0 + j + q < d) dst[q] = tile[j + q][i] + (bias ? bias[j0 + j + q] : 0.f);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // final core numbers; with a level cap the unpeeled vertices (current degree >= cap) are reported as `cap`
 __global__ void kcore_copy_kernel(int n, int cap, const int32_t *__restrict__ deg, int32_t *__restrict__ core)
 {
@@ -2179,6 +2215,17 @@ int ctgcn_device_info(char *name_host, size_t name_len, int *cu_count_host)
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     if (name_host && name_len) snprintf(name_host, name_len, "%s (%s)", prop.name, prop.gcnArchName);
     if (cu_count_host) *cu_count_host = prop.multiProcessorCount;
+    return CTGCN_OK;
+}
+
+int ctgcn_transpose_bias_f32(int64_t n, int32_t d, const float *w, int64_t ldw, const float *bias, float *out, int64_t ldo,
+                             void *stream)
+{
+    if (n < 0 || d < 1 || ldw < n || ldo < d) return fail(CTGCN_E_INVALID, "transpose_bias: bad sizes n=%lld d=%d", (long long)n, d);
+    if (n == 0) return CTGCN_OK;
+    if (!w || !out) return fail(CTGCN_E_INVALID, "transpose_bias: null pointer");
+    hipLaunchKernelGGL(transpose_bias_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, n, d, w, ldw, bias, out, ldo);
+    HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }
 

@@ -147,6 +147,20 @@ def spmm_csr(row_ptr, col, val, x, out=None, accumulate=False):
     return out
 
 
+def linear_of_identity(weight, bias):
+    """nn.Linear(weight, bias) applied to the N x N identity (one-hot node features): [N, out] = weight^T + bias, written
+    row-major in one pass (weight.t() + bias in torch yields a column-major tensor that the next layer has to copy)."""
+    _need_cuda(weight)
+    lib = _lib.load()
+    d, n = weight.shape
+    w = weight.detach() if weight.stride(1) == 1 else weight.detach().contiguous()
+    out = torch.empty(n, d, dtype=torch.float32, device=weight.device)
+    with torch.cuda.device(weight.device):
+        check(lib.ctgcn_transpose_bias_f32(n, d, ptr(w), w.stride(0), ptr(bias.detach().contiguous() if bias is not None else None),
+                                           ptr(out), out.stride(0), _stream()), "ctgcn_transpose_bias_f32")
+    return out
+
+
 # -------------------------------------------------------------------- CoreDiffusion aggregation
 def _aggregate_fwd(adj, x, relu):
     lib = _lib.load()
@@ -211,7 +225,7 @@ def core_aggregate(x, adj, relu=True):
 
 # ------------------------------------------------------------- GRU over the core / time axis (+ sum, LayerNorm)
 import os as _os
-_GI_MAX_ELEMS = int(_os.environ.get("CTGCN_GI_MAX_ELEMS", 1 << 29))   # fp32 elements of the projection buffer per row chunk (2 GiB)
+_GI_MAX_ELEMS = int(_os.environ.get("CTGCN_GI_MAX_ELEMS", 1 << 30))   # row-chunk bound: rows * steps * 4 * hidden elements (4 GiB of saved gates)
 
 
 def gru_fused_ok(rnn, seq):

@@ -65,6 +65,14 @@ const char *ctgcn_last_error(void);
 int ctgcn_device_info(char *name_host, size_t name_len, int *cu_count_host);
 
 /*
+ * out[n, d] = w[d, n]^T + bias[d]  — nn.Linear applied to one-hot node features (the sparse identity of reference
+ * helper.py:161-172 fed to layers.py:95-106 MLP): X·W^T + b with X = I is a transpose of the weight.  w rows are ldw
+ * floats apart, out rows ldo; bias may be NULL.
+ */
+int ctgcn_transpose_bias_f32(int64_t n, int32_t d, const float *w, int64_t ldw, const float *bias, float *out, int64_t ldo,
+                             void *stream);
+
+/*
  * Y = A·X  (accumulate == 0)   or   Y += A·X  (accumulate != 0).
  * Replaces one torch.sparse.mm(adj, x), layers.py:43 / layers.py:45.
  */

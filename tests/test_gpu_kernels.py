@@ -341,3 +341,15 @@ def test_hub_rows_general_lists():
         assert adj.long_rows(transposed=True) is None or adj.long_rows(transposed=True).numel() >= 0
     finally:
         CoreAdj.LONG_ROW = old
+
+
+@pytest.mark.parametrize("n,d,bias", [(1, 1, True), (31, 128, True), (1899, 128, True), (70001, 128, False), (4097, 50, True), (1000, 300, True)])
+def test_linear_of_identity_is_transposed_weight_plus_bias(n, d, bias):
+    """ctgcn_transpose_bias_f32: Linear applied to one-hot features (helper.py:161-172 identity through layers.py:95-106)
+    equals W^T + b exactly (pure data movement + one add)."""
+    from ctgcn_amd import ops
+    lin = torch.nn.Linear(n, d, bias=bias).to(_dev())
+    got = ops.linear_of_identity(lin.weight, lin.bias)
+    want = lin.weight.detach().t() + (lin.bias.detach() if bias else 0.0)
+    assert got.is_contiguous() and got.shape == (n, d)
+    assert torch.equal(got, want.contiguous())

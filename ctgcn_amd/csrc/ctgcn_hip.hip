@@ -734,6 +734,7 @@ struct GruArgs {
     float *out;
     float *gates;           // optional [rows, steps, 4, 128]: r, z, n, q = W_hn h + b_hn, saved for the backward kernel
     int32_t gi_blocked;     // gi is in the blocked tile layout (gi_blocked_offset); fp16x2 kernel only
+    int64_t ldo;            // reduce_sum: floats between output rows (128 = dense; larger: rows of a [rows, T, 128] tensor)
 };
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each): far inside the fp32 tolerance of the layer, a fraction of an IEEE divide's cost
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
         }
         if (REDUCE)
             for (int r = wave; r <= last; r += 8)
-                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
         __syncthreads();       // LDS is reused by the next tile
     }
 }
@@ -1157,7 +1158,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_x3_kernel(const GruArgs a)
         }
         if (REDUCE)
             for (int r = wave; r <= last; r += 8)
-                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
         __syncthreads();       // LDS is reused by the next tile
     }
 }
@@ -1489,7 +1490,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
         }
         if (REDUCE)
             for (int r = wave; r <= last; r += 8)
-                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
         __syncthreads();       // LDS is reused by the next tile
     }
 }
@@ -1591,7 +1592,7 @@ __global__ __launch_bounds__(512, 2) void lstm_seq_kernel(const GruArgs a)
                 for (int i = 0; i < 4; ++i) sbuf[rt * 16 + grp * 4 + i][hid] = hsum[rt][i];
             __syncthreads();
             for (int r = wave; r <= last; r += 8)
-                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * GRU_H, lane, a.gamma, a.beta, a.eps);
+                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
         }
         __syncthreads();
     }
@@ -2409,7 +2410,7 @@ int64_t ctgcn_gru_row_granule(void)
 
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, float *gates_out, int split_bf16, int gi_blocked, void *stream)
+                      int reduce_sum, float *out, int64_t ld_out, float *gates_out, int split_bf16, int gi_blocked, void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq: hidden=%d, only %d is built", hidden, GRU_H);
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq: bad sizes rows=%lld steps=%d", (long long)rows, steps);
@@ -2420,6 +2421,8 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     GruArgs a{};
     a.rows = rows; a.steps = steps; a.gi = gi; a.whh = w_hh; a.bhn = b_hn; a.gamma = ln_weight; a.beta = ln_bias;
     a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = gates_out; a.gi_blocked = gi_blocked ? 1 : 0;
+    a.ldo = ld_out > 0 ? ld_out : GRU_H;
+    if (ld_out > 0 && (!reduce_sum || ld_out < GRU_H || (ld_out & 1))) return fail(CTGCN_E_INVALID, "gru_seq: ld_out=%lld needs reduce_sum and an even value >= %d", (long long)ld_out, GRU_H);
     if (gi_blocked && split_bf16 != CTGCN_SPLIT_F16X2) return fail(CTGCN_E_INVALID, "gru_seq: the blocked gi layout belongs to CTGCN_SPLIT_F16X2");
     if (gates_out && (reduce_sum || ln_weight)) return fail(CTGCN_E_INVALID, "gru_seq: gates_out needs reduce_sum == 0 and no LayerNorm (raw h sequence)");
     int dev = 0, cus = 256;
@@ -2553,7 +2556,7 @@ int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float 
     if (!aligned16(w_hh) || (reinterpret_cast<uintptr_t>(out) & 7u)) return fail(CTGCN_E_INVALID, "lstm_seq: w_hh must be 16-byte aligned, out 8-byte aligned");
     GruArgs a{};
     a.rows = rows; a.steps = steps; a.gi = gi; a.whh = w_hh; a.bhn = nullptr; a.gamma = ln_weight; a.beta = ln_bias;
-    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = nullptr;
+    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = nullptr; a.ldo = GRU_H;
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));

@@ -16,15 +16,24 @@ _RNN = {"GRU": nn.GRU, "LSTM": nn.LSTM}
 _RNN_MAX_ELEMS = 1 << 29     # MIOpen's RNN indexes its gate workspace with 32-bit ints: keep batch*seq*4*hidden below 2^31
 
 
-def rnn_reduce_norm(rnn, norm, seq, reduce_sum):
+def rnn_reduce_norm(rnn, norm, seq, reduce_sum, out=None):
     """norm(rnn(seq).sum(1)) or norm(rnn(seq)).  GRU(hidden=128): fused HIP kernels, forward and backward.
     LSTM(hidden=128): fused HIP recurrence for inference.  Everything else (other widths, LSTM training) goes through
-    the PyTorch-ROCm modules."""
+    the PyTorch-ROCm modules.  out (inference only, reduce_sum): a [rows, hidden] strided view that receives the result."""
+    if out is not None and torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in rnn.parameters())):
+        out = None                                   # training: autograd needs its own tensors
     if ops.gru_fused_ok(rnn, seq):
-        return ops.gru_sequence(rnn, seq, norm, reduce_sum)
-    if ops.lstm_fused_ok(rnn, seq):
-        return ops.lstm_sequence(rnn, seq, norm, reduce_sum)
-    return norm(rnn_over_rows(rnn, seq, reduce_sum))
+        if out is not None and reduce_sum:
+            return ops.gru_sequence(rnn, seq, norm, reduce_sum, out=out)
+        res = ops.gru_sequence(rnn, seq, norm, reduce_sum)
+    elif ops.lstm_fused_ok(rnn, seq):
+        res = ops.lstm_sequence(rnn, seq, norm, reduce_sum)
+    else:
+        res = norm(rnn_over_rows(rnn, seq, reduce_sum))
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def rnn_over_rows(rnn, seq, reduce_sum):
@@ -99,9 +108,10 @@ class CoreDiffusion(nn.Module):
         """[N, K, input_dim] = all K rectified cumulative aggregations, one kernel launch."""
         return ops.core_aggregate(x, as_core_adj(adj_list, x.device), relu=True)
 
-    def forward(self, x, adj_list):
+    def forward(self, x, adj_list, out=None):
+        """out (optional, inference): a [N, output_dim] view (unit column stride) that receives the result."""
         seq = self.aggregate(x, adj_list)            # [batch = N, seq = K, feat]
-        return rnn_reduce_norm(self.rnn, self.norm, seq, reduce_sum=True)
+        return rnn_reduce_norm(self.rnn, self.norm, seq, reduce_sum=True, out=out)
 
 
 class MLP(nn.Module):

@@ -25,9 +25,11 @@ class CDN(nn.Module):
         self.diffusion_list = nn.ModuleList(
             CoreDiffusion(a, b, bias=bias, rnn_type=rnn_type) for a, b in zip(dims[:-1], dims[1:]))
 
-    def forward(self, x, adj_list):
-        for layer in self.diffusion_list:
-            x = layer(x, adj_list)
+    def forward(self, x, adj_list, out=None):
+        """out (optional, inference): where the LAST layer writes its [N, output_dim] result (see CoreDiffusion.forward)."""
+        last = len(self.diffusion_list) - 1
+        for i, layer in enumerate(self.diffusion_list):
+            x = layer(x, adj_list, out=out if i == last else None)
         return x
 
 
@@ -97,10 +99,10 @@ class CTGCN(nn.Module):
         self.norm = nn.LayerNorm(output_dim)
         self.process_group = None      # set by snapshot_parallel.shard_ctgcn()
 
-    def snapshot_branch(self, t, x, adj):
+    def snapshot_branch(self, t, x, adj, out=None):
         """Everything that is independent per snapshot: reference models.py:244-246."""
         trans = self.mlp_list[t](x)
-        return self.duffision_list[t](trans, adj), trans
+        return self.duffision_list[t](trans, adj, out=out), trans
 
     def temporal_head(self, hx):
         """hx [N, T, d] -> [T, N, d]: reference models.py:249-250."""
@@ -110,9 +112,17 @@ class CTGCN(nn.Module):
         if self.process_group is not None:
             return sp_par.ctgcn_forward_sharded(self, x_list, adj_list)
         hx, trans = [], []
-        for t in range(len(x_list)):
-            h, tr = self.snapshot_branch(t, x_list[t], adj_list[t])
+        T = len(x_list)
+        seq = None
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())) and T > 0:
+            # inference: every snapshot's embeddings are written straight into column t of the temporal GRU's [N, T, d]
+            # input (models.py:248 stack + transpose without the two copies)
+            n = adj_list[0].n if hasattr(adj_list[0], "n") else adj_list[0][0].shape[0]
+            p0 = next(self.parameters())
+            seq = torch.empty(n, T, self.output_dim, dtype=p0.dtype, device=p0.device)
+        for t in range(T):
+            h, tr = self.snapshot_branch(t, x_list[t], adj_list[t], out=None if seq is None else seq[:, t])
             hx.append(h)
             trans.append(tr)
-        out = self.temporal_head(torch.stack(hx).transpose(0, 1))
+        out = self.temporal_head(seq if seq is not None else torch.stack(hx).transpose(0, 1))
         return out if self.model_type == 'C' else (out, trans)

@@ -317,11 +317,16 @@ def _weight_grad(part, g01, g2, x2d, steps, shift, accumulate):
                                         _stream()), "ctgcn_gru_weight_grad_f32")
 
 
-def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
+def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=None):
     lib = _lib.load()
     rows, steps, d_in = seq.shape
     hid = w_hh.shape[1]
-    out = torch.empty((rows, hid) if reduce_sum else (rows, steps, hid), dtype=torch.float32, device=seq.device)
+    if out is None:
+        out = torch.empty((rows, hid) if reduce_sum else (rows, steps, hid), dtype=torch.float32, device=seq.device)
+    elif not (reduce_sum and out.shape == (rows, hid) and out.dtype == torch.float32 and out.stride(1) == 1
+              and out.stride(0) % 2 == 0 and out.stride(0) >= hid and out.device == seq.device):
+        raise ValueError("gru: out must be a [rows, %d] fp32 view with unit column stride (reduce_sum only)" % hid)
+    ldo = out.stride(0) if reduce_sum else 0
     if rows == 0:
         return out
     chunks = _row_chunks(lib, rows, steps, hid)
@@ -332,7 +337,7 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum):
             blocked = _project(seq[lo:lo + n].reshape(n * steps, d_in), w_ih, bias, gi_buf, steps_blocked=steps)
             with _timed("gru_seq", rows=n, steps=steps):
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_buf), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
-                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), None, split, 1 if blocked else 0,
+                                            1 if reduce_sum else 0, ptr(out[lo:lo + n]), ldo, None, split, 1 if blocked else 0,
                                             _stream()), "ctgcn_gru_seq_f32")
     return out
 
@@ -413,7 +418,7 @@ class _GruSeq(torch.autograd.Function):
                 gates, hseq = gates_buf[: n * steps], hseq_buf[:n]
                 gi = gi_flat[: n * steps * 3 * hid].view(n * steps, 3 * hid)                 # the [rows, 3h] view (d_gi later)
                 blocked = _project(x2d, w_ih_d, bias, gi_flat, steps_blocked=steps)
-                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_flat), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq),
+                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_flat), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq), 0,
                                             ptr(gates), forward_split_mode(), 1 if blocked else 0, _stream()), "ctgcn_gru_seq_f32")
                 # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)
                 g_out = dout[lo:lo + n]
@@ -497,14 +502,21 @@ def lstm_sequence(rnn, seq, norm, reduce_sum):
     return out
 
 
-def gru_sequence(rnn, seq, norm, reduce_sum):
+def gru_sequence(rnn, seq, norm, reduce_sum, out=None):
     """LayerNorm(sum_t GRU(seq)_t) (reduce_sum) or LayerNorm(GRU(seq)) — layers.py:59-62 / models.py:249-250.
-    seq [rows, steps, d_in].  The input projection is a hipBLASLt GEMM; the recurrence, the sum over steps and the
-    LayerNorm run in ONE HIP kernel (ctgcn_gru_seq_f32); with autograd enabled the backward runs
-    ctgcn_gru_seq_bwd_f32 (see _GruSeq)."""
+    seq [rows, steps, d_in].  Input projection (ctgcn_gru_input_proj_f32), then the recurrence, the sum over steps and the
+    LayerNorm in ONE HIP kernel (ctgcn_gru_seq_f32); with autograd enabled the backward runs ctgcn_gru_seq_bwd_f32 (see
+    _GruSeq).  out (inference, reduce_sum): a [rows, hidden] view with unit column stride that receives the result,
+    e.g. column t of the temporal GRU's [rows, T, hidden] input."""
     b_ih = rnn.bias_ih_l0 if rnn.bias else None
     b_hh = rnn.bias_hh_l0 if rnn.bias else None
     ln_w = None if norm is None else norm.weight
     ln_b = None if norm is None else norm.bias
     eps = 0.0 if norm is None else float(norm.eps)
+    if out is not None:
+        if torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in rnn.parameters())):
+            raise RuntimeError("gru_sequence(out=...) is an inference path")
+        bias, b_hn = _gru_bias(rnn, rnn.hidden_size)
+        return _gru_forward(seq.contiguous(), rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous(), bias, b_hn,
+                            ln_w, ln_b, eps, bool(reduce_sum), out=out)
     return _GruSeq.apply(seq, rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, ln_w, ln_b, eps, bool(reduce_sum))

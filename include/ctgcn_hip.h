@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 5
+#define CTGCN_ABI_VERSION 6
 
 enum {
     CTGCN_OK = 0,
@@ -177,6 +177,8 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  *   CTGCN_SPLIT_F16X2  (2)  operands scaled per row by a power of two and split into two fp16 terms (22 bits), three
  *                           partial products, fp32 accumulation: half the matrix-core work of (1) and measured MORE
  *                           accurate than (0) and (1) (tools/probes/mfma_f16x2_probe.hip)
+ * ld_out (reduce_sum only; 0 = dense 128): floats between output rows — lets a snapshot's embeddings land directly in
+ *   column t of the [nodes, T, 128] input of the temporal GRU (models.py:248 stack + transpose without the copies).
  * gi_blocked != 0 (CTGCN_SPLIT_F16X2 only): gi is in the tile layout ctgcn_gru_input_proj_f32 writes for steps_blocked = steps
  *   ([node tile of 64][step][gate][16-column group][node in tile][16]; the buffer must cover ceil(rows/64)*64 rows).
  * gates_out (optional; requires reduce_sum == 0 and ln_weight == NULL): [rows, steps, 4, 128] receives r, z, n and
@@ -184,7 +186,7 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  */
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, float *gates_out, int split_bf16, int gi_blocked, void *stream);
+                      int reduce_sum, float *out, int64_t ld_out, float *gates_out, int split_bf16, int gi_blocked, void *stream);
 
 /*
  * The same for nn.LSTM (rnn_type = 'LSTM'; layers.py:27-28, models.py:234-235): gi [rows, steps, 512] = x·W_ih^T + b_ih

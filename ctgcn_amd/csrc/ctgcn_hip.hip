@@ -738,8 +738,10 @@ struct GruArgs {
 };
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each): far inside the fp32 tolerance of the layer, a fraction of an IEEE divide's cost
-__device__ __forceinline__ float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+// raw v_exp_f32 (2^x): __expf wraps it in range clamps (v_max ...) that these forms do not need — 2^(+big) = inf -> rcp = 0,
+// 2^(-big) = 0 -> rcp(1) = 1 are exactly the saturated values
+__device__ __forceinline__ float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+__device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008f)); }
 
 __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src, float *__restrict__ dst, int lane,
                                                   const float *gamma, const float *beta, float eps)

@@ -259,6 +259,15 @@ def split_mfma_enabled():
     return os.environ.get("CTGCN_FP32_MFMA_ONLY", "0") != "1"
 
 
+def fused_gru_enabled():
+    """CTGCN_GRU_FUSED=1: ctgcn_gru_fused_f32 for the CoreDiffusion GRU (reduce_sum, d_in = hidden = 128, fp16x2) instead of the
+    projection + recurrence kernel pair.  Same arithmetic (bit-identical results), 0.2 GB of scratch instead of a 4 GB gi
+    buffer, one launch — but measured 15 % SLOWER on config 5 (308 vs 263 ms per window): the gi round trip costs
+    Infinity-Fabric bandwidth whether it ends in HBM or in the memory-side cache.  Off by default."""
+    import os
+    return os.environ.get("CTGCN_GRU_FUSED", "0") == "1"
+
+
 def forward_split_mode():
     """Arithmetic of the forward GRU products (include/ctgcn_hip.h CTGCN_SPLIT_*): 2 = fp16x2 (default: per-row scaled
     two-term fp16 split, three products — half the matrix work of bf16x3 and measured more accurate), 1 = bf16x3
@@ -329,9 +338,18 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
     ldo = out.stride(0) if reduce_sum else 0
     if rows == 0:
         return out
+    split = forward_split_mode()
+    if reduce_sum and split == 2 and d_in == hid and fused_gru_enabled() and seq.stride(2) == 1 and seq.stride(1) % 4 == 0 \
+            and seq.stride(0) == steps * seq.stride(1) and seq.data_ptr() % 16 == 0 and w_ih.is_contiguous():
+        # projection + recurrence of a 64-row tile in one block, gi through a cache-resident per-block scratch: one launch, no chunks
+        ws_bytes = int(lib.ctgcn_workspace_bytes(_lib.OP_GRU_FUSED, rows, 0, 0, steps))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=seq.device)
+        with torch.cuda.device(seq.device), _timed("gru_fused", rows=rows, steps=steps):
+            check(lib.ctgcn_gru_fused_f32(rows, steps, d_in, hid, ptr(seq), seq.stride(1), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn),
+                                          ptr(ln_w), ptr(ln_b), eps, ptr(out), ldo, ptr(ws), ws_bytes, _stream()), "ctgcn_gru_fused_f32")
+        return out
     chunks = _row_chunks(lib, rows, steps, hid)
     gi_buf = _gi_buffer(chunks[0][1], steps, hid, seq.device)
-    split = forward_split_mode()
     with torch.cuda.device(seq.device):
         for lo, n in chunks:
             blocked = _project(seq[lo:lo + n].reshape(n * steps, d_in), w_ih, bias, gi_buf, steps_blocked=steps)

@@ -159,6 +159,10 @@ def ctgcn_forward_sharded(model, x_list, adj_list):
     mine = plan.assignment[rank]
     assert len(x_list) == plan.T, "window length %d != plan %d" % (len(x_list), plan.T)
 
+    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    if model.shard_exchange == "all_to_all" and not needs_grad and plan.per > 0:
+        return _forward_sharded_pipelined(model, x_list, adj_list)
+
     states, trans_local = [], {}
     for t in mine:
         h, tr = model.snapshot_branch(t, x_list[t], adj_list[t])
@@ -190,6 +194,46 @@ def ctgcn_forward_sharded(model, x_list, adj_list):
     if not model.shard_replicate_head and model.shard_gather_output:
         padded = torch.nn.functional.pad(out, (0, 0, 0, plan.n_slice - (hi - lo))) if hi - lo < plan.n_slice else out
         full = _AllGather.apply(padded.transpose(0, 1).contiguous(), group)  # [world, n_slice, T, d]
+        out = full.reshape(plan.n_pad, plan.T, d)[: plan.n].transpose(0, 1)
+    if model.model_type == 'C':
+        return out
+    return out, [trans_local.get(t) for t in range(plan.T)]
+
+
+def _forward_sharded_pipelined(model, x_list, adj_list):
+    """Inference form of the all-to-all exchange, overlapped with compute: slot s of every rank (its s-th snapshot) is
+    exchanged by its own asynchronous all-to-all as soon as it is computed, on the collective's stream, while the next
+    snapshot runs on the compute stream.  The last CoreDiffusion of a snapshot writes its embeddings straight into the send
+    buffer.  At G = 2 the whole exchange is N/2 x T/2 x d x 4 B over ONE xGMI link (2 GB for config 5, ~40 ms if done at the
+    end); per slot it is 1/per of that and hides behind a snapshot's ~16 ms of compute.  Same numbers as the autograd path."""
+    group, plan = model.process_group, model.shard_plan
+    rank = dist.get_rank(group)
+    mine = plan.assignment[rank]
+    p0 = next(model.rnn.parameters())
+    d = model.output_dim
+    send = torch.zeros(plan.per, plan.n_pad, d, dtype=p0.dtype, device=p0.device)        # pad rows / empty slots stay 0
+    recv = torch.empty(plan.per, plan.world, plan.n_slice, d, dtype=p0.dtype, device=p0.device)
+    works, trans_local = [], {}
+    for s_ in range(plan.per):
+        if s_ < len(mine):
+            t = mine[s_]
+            h, tr = model.snapshot_branch(t, x_list[t], adj_list[t], out=send[s_, : plan.n])
+            if h.data_ptr() != send[s_].data_ptr():
+                send[s_, : plan.n].copy_(h)
+            trans_local[t] = tr
+        works.append(dist.all_to_all_single(recv[s_].view(plan.world * plan.n_slice, d), send[s_], group=group, async_op=True))
+    for w in works:
+        w.wait()
+    lo, hi = plan.node_range(rank)
+    # recv[s][w] = snapshot assignment[w][s] on my node slice -> [nodes, T, d] in time order (the temporal GRU's input layout)
+    seq = torch.empty(hi - lo, plan.T, d, dtype=p0.dtype, device=p0.device)
+    for t in range(plan.T):
+        w_, s_ = divmod(plan.slot_of[t], plan.per)
+        seq[:, t] = recv[s_, w_, : hi - lo]
+    out = model.temporal_head(seq)                                                          # [T, my nodes, d]
+    if model.shard_gather_output:
+        padded = torch.nn.functional.pad(out, (0, 0, 0, plan.n_slice - (hi - lo))) if hi - lo < plan.n_slice else out
+        full = _AllGather.apply(padded.transpose(0, 1).contiguous(), group)                 # [world, n_slice, T, d]
         out = full.reshape(plan.n_pad, plan.T, d)[: plan.n].transpose(0, 1)
     if model.model_type == 'C':
         return out

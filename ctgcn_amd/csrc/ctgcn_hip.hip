@@ -1457,6 +1457,52 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
             gq[rt][0] = *(const f4v *)p; gq[rt][1] = *(const f4v *)(p + gi_gs); gq[rt][2] = *(const f4v *)(p + 2 * gi_gs);
         };
         if (steps > 1) { load_gi(1, 0); load_gi(1, 1); }
+        auto mfma_unit = [&](int pb, int rt, f4v (&ac)[3]) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ac[g] = zero4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // MFMA B operand: B[k][n = row] = h_{t-1}[row rt*16 + col][k = c*32 + 8*grp + j]
+                const h8v x1 = *(const h8v *)(&Hs[pb][0][rt * 16 + col][c * 32 + 8 * grp]);
+                const h8v x2 = *(const h8v *)(&Hs[pb][1][rt * 16 + col][c * 32 + 8 * grp]);
+                CTGCN_H2_MFMA1(Wf, c, x1, x2, ac)
+            }
+        };
+        if constexpr (REDUCE) {
+            // Rolling pipeline ACROSS steps: unit (t, rt) issues its MFMAs together with the gate math of the previous unit —
+            // for rt = 0 that is row tile 3 of step t-1, so the matrix pipe does not drain at step boundaries.  Row tiles
+            // are independent sequences: h_{t-1}[rows of rt] is complete three units before MFMA(t, rt) needs it, and
+            // two barriers per step (after rt = 1 and rt = 3) always fall in between.  The publish of (t-1, 3) goes to the
+            // buffer step t reads, rows 3 — not yet read by anyone in step t.
+            f4v acc[2][3];
+            for (int t = 1; t < steps; ++t) {
+                const int pb = (t - 1) & 1, cb = t & 1;
+#pragma unroll
+                for (int rt = 0; rt < GRU_RT; ++rt) {
+                    const int cur = rt & 1, prv = cur ^ 1;
+                    if (rt + 2 < GRU_RT) load_gi(t, rt + 2);
+                    else if (t + 1 < steps) load_gi(t + 1, rt + 2 - GRU_RT);
+                    mfma_unit(pb, rt, acc[cur]);
+                    if (rt > 0 || t > 1) {
+                        const int rp = rt > 0 ? rt - 1 : GRU_RT - 1;          // the previous unit's row tile ...
+                        const int wb = rt > 0 ? cb : pb;                      // ... and the plane buffer of ITS step
+                        const f4v h = gates(gq[rp][0], gq[rp][1], gq[rp][2], acc[prv], hreg[rp], t, rp * 16 + col);
+                        hreg[rp] = h;
+                        publish(wb, rp * 16 + col, h);
+                        f4v *sp_ = (f4v *)(&sbuf[rp * 16 + col][oc]);
+                        *sp_ = *sp_ + h;
+                    }
+                    if (rt & 1) __syncthreads();
+                }
+            }
+            if (steps > 1) {                                                  // drain: row tile 3 of the last step
+                const int rp = GRU_RT - 1;
+                const f4v h = gates(gq[rp][0], gq[rp][1], gq[rp][2], acc[1], hreg[rp], steps - 1, rp * 16 + col);
+                f4v *sp_ = (f4v *)(&sbuf[rp * 16 + col][oc]);
+                *sp_ = *sp_ + h;
+            }
+            __syncthreads();
+        } else {
         for (int t = 1; t < steps; ++t) {
             const int pb = (t - 1) & 1, cb = t & 1;
             f4v acc[2][3];
@@ -1466,29 +1512,18 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
                 if (rt < GRU_RT) {
                     if (rt + 2 < GRU_RT) load_gi(t, rt + 2);
                     else if (t + 1 < steps) load_gi(t + 1, rt + 2 - GRU_RT);
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[cur][g] = zero4;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        // MFMA B operand: B[k][n = row] = h_{t-1}[row rt*16 + col][k = c*32 + 8*grp + j]
-                        const h8v x1 = *(const h8v *)(&Hs[pb][0][rt * 16 + col][c * 32 + 8 * grp]);
-                        const h8v x2 = *(const h8v *)(&Hs[pb][1][rt * 16 + col][c * 32 + 8 * grp]);
-                        CTGCN_H2_MFMA1(Wf, c, x1, x2, acc[cur])
-                    }
+                    mfma_unit(pb, rt, acc[cur]);
                 }
                 if (rt > 0) {
                     const int rp = rt - 1;
                     const f4v h = gates(gq[rp][0], gq[rp][1], gq[rp][2], acc[prv], hreg[rp], t, rp * 16 + col);
                     hreg[rp] = h;
                     publish(cb, rp * 16 + col, h);
-                    if (REDUCE) {
-                        f4v *sp_ = (f4v *)(&sbuf[rp * 16 + col][oc]);
-                        *sp_ = *sp_ + h;
-                    }
                 }
             }
             __syncthreads();
-            if (!REDUCE) emit_step(t);
+            emit_step(t);
+        }
         }
         if (REDUCE)
             for (int r = wave; r <= last; r += 8)

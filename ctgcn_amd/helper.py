@@ -39,6 +39,9 @@ class DataLoader(object):
         largest k down; the first gets + I; a later matrix equal in sum to its predecessor is dropped."""
         date_dirs = sorted(os.listdir(core_base_path))
         assert start_idx < len(date_dirs)
+        from .preprocessing.structure_generation import CACHE_SUFFIX
+        if date_dirs and all(d.endswith(CACHE_SUFFIX) for d in date_dirs):
+            return self.get_core_adj_list_from_cache(core_base_path, start_idx, duration, max_core)
         window = []
         for i in self._window(start_idx, duration):
             folder = os.path.join(core_base_path, date_dirs[i])
@@ -77,6 +80,28 @@ class DataLoader(object):
                 max_core = file_count
             window.append(adj if adj is not None else [])
             cores.append(core)
+        return (window, cores) if return_core_numbers else window
+
+    def get_core_adj_list_from_cache(self, cache_base_path, start_idx, duration, max_core=-1, return_core_numbers=False):
+        """Same result as get_core_adj_list on the per-k files, read from one <snapshot>.coreadj.npz per snapshot (written by
+        StructureInfoGenerator(..., cache_folder=...)): the CSR and the stored core numbers go to the GPU, the k-core
+        matrices become a level -> slot table — no peel, no per-k files, any max_core from the same file."""
+        if not self.has_cuda:
+            raise RuntimeError("the cache route builds the tagged CSR on the GPU: construct DataLoader(has_cuda=True)")
+        from .preprocessing.structure_generation import read_core_cache
+        files = sorted(os.listdir(cache_base_path))
+        assert start_idx < len(files)
+        window, cores = [], []
+        for i in self._window(start_idx, duration):
+            indptr, indices, data, core = read_core_cache(os.path.join(cache_base_path, files[i]))
+            row_ptr = torch.from_numpy(indptr).to(self.device)
+            col = torch.from_numpy(indices).to(self.device)
+            val = torch.from_numpy(data.astype(np.float32)).to(self.device)
+            adj, core_t, file_count = CoreAdj.from_graph(row_ptr, col, val, max_core=max_core, core=torch.from_numpy(core).to(self.device))
+            if max_core == -1:
+                max_core = file_count
+            window.append(adj if adj is not None else [])
+            cores.append(core_t)
         return (window, cores) if return_core_numbers else window
 
     # ------------------------------------------------------------ negative-sampling inputs (helper.py:26-49)

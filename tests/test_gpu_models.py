@@ -303,3 +303,29 @@ def test_hip_graph_replay_equals_eager_forward(features):
         assert torch.equal(runner(xs2), want3)
         with pytest.raises(ValueError):
             runner([x[:, :3] for x in xs2])
+
+
+def test_binary_core_cache_route_matches_reference_loader(tmp_path):
+    """one <snapshot>.coreadj.npz per snapshot (CSR + core numbers) instead of K per-core .npz files.
+    The generator writes both; the loader must return, from the cache alone, exactly what the reference's loader returns
+    from the per-k files for every max_core setting (goldens), and get_core_adj_list must recognise a cache folder."""
+    import ctgcn_amd
+    from ctgcn_amd.preprocessing import StructureInfoGenerator
+    names = _write_uci(tmp_path)
+    gen = StructureInfoGenerator(str(tmp_path), "1.format", "2.core", "nodes_set/nodes.csv")
+    gen.get_kcore_graph_all_time(sep="\t", cache_folder="2.corecache", per_k_files=False)
+    assert not os.listdir(tmp_path / "2.core")                       # no per-k files were asked for
+    ca, kc = load_golden("uci_core_adj.npz"), load_golden("uci_kcore.npz")
+    assert sorted(os.listdir(tmp_path / "2.corecache")) == [str(s) + ".coreadj.npz" for s in kc["snapshots"]]
+    dl = ctgcn_amd.DataLoader(names, 7, has_cuda=True)
+    for tag, start, dur, mc in (("mcm1_", 0, 7, -1), ("mc5_", 0, 7, 5), ("w4_", 4, 3, -1)):
+        got, cores = dl.get_core_adj_list_from_cache(str(tmp_path / "2.corecache"), start, dur, max_core=mc, return_core_numbers=True)
+        assert [len(g) for g in got] == ca[tag + "K"].tolist()
+        for i, (adj, core) in enumerate(zip(got, cores)):
+            assert np.array_equal(core.cpu().numpy(), kc["core_t%d" % (start + i)])      # stored, uncapped core numbers
+            for j, m in enumerate(adj.to_scipy_list()):
+                want = csr_from(ca, tag + "t%d_j%d" % (i, j), 1899, np.float32)
+                assert np.array_equal(m.indptr, want.indptr) and np.array_equal(m.indices, want.indices)
+                assert np.array_equal(m.data, want.data)
+    auto = dl.get_core_adj_list(str(tmp_path / "2.corecache"), 0, 7, max_core=5)         # same entry point as the reference
+    assert [len(g) for g in auto] == ca["mc5_K"].tolist()

@@ -37,6 +37,7 @@ class CoreAdj(object):
         self.nnz_per_slot = [int(v) for v in nnz_per_slot]      # reference-semantics nnz(A_j), incl. the +I of slot 0
         self.levels = None if levels is None else [int(v) for v in levels]   # k value of each slot (k-core route)
         self._t = None                                           # transposed arrays, built on demand when not symmetric
+        self._moved = {}                                         # copies on other devices (as_core_adj: moved once, not per call)
         self._long = {}                                          # cached hub-row lists (forward / transposed)
         assert 0 <= self.K <= _lib.MAX_SLOTS
 
@@ -66,8 +67,17 @@ class CoreAdj(object):
 
     def to(self, device):
         device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         if device == self.device:
             return self
+        hit = self._moved.get(str(device))
+        if hit is not None:
+            return hit
+        out = self._moved[str(device)] = self._copy_to(device)
+        return out
+
+    def _copy_to(self, device):
         out = CoreAdj(self.n, self.K, self.row_ptr.to(device), self.col.to(device), self.val.to(device),
                       self.slot.to(device), self.self_loop, self.nested, self.symmetric, self.nnz_per_slot, self.levels)
         if self._t is not None:
@@ -240,6 +250,14 @@ class CoreAdj(object):
         """
         from . import ops
         n = row_ptr.numel() - 1
+        if max_core == 0:
+            # an edgeless first snapshot under max_core=-1 makes the sticky value 0: the reference then keeps f_list[:0] = []
+            # for every later snapshot (helper.py:61-64)
+            if core is None:
+                core, max_k = ops.kcore(row_ptr, col)
+            else:
+                max_k = int(core.max().item()) if n else 0
+            return None, core, max_k
         if core is None:
             core, max_k = ops.kcore(row_ptr, col, level_cap=max_core if max_core >= 1 else -1)
         else:

@@ -145,16 +145,84 @@ class DataLoader(object):
             out.append(_coo_tensor(mat, self.device) if data_type == 'tensor' else mat)
         return out
 
+    def get_degree_feature_list(self, origin_base_path, start_idx, duration, sep='\t', init_type='gaussian', std=1e-4):
+        """Degree-based node features for the structural models CGCN-S / CTGCN-S (reference helper.py:109-158, called at
+        train.py:72-74).  Returns (x_list, input_dim) with the reference's shapes, dtypes and layouts:
+
+          degree   = int(weighted degree) of the snapshot's simple undirected graph (adj.sum(axis=1).astype(int), :121);
+          D        = 1 + the largest degree over the WHOLE window (:122, :127-...);
+          gaussian   dense float32 [N, D], row i ~ Normal(degree_i, std)                                   (:128-135)
+          adj        sparse COO float32 [N, N] = the snapshot adjacency                                    (:136-139)
+          combine    sparse COO float32 [N, D + N] = [gaussian | adj]                                      (:140-148)
+          one-hot    sparse COO float32 [N, D], a single 1 in column degree_i                              (:149-156)
+
+        Randomness: the reference draws from numpy's global RandomState row by row.  Without CUDA this loader draws the
+        same stream in one vectorised call (same values bit for bit under np.random.seed).  With has_cuda the normals are
+        generated on the GPU (torch Generator seeded from numpy's global state, so np.random.seed still makes a run
+        reproducible): at config-3 scale the reference's host loop is 60 730 x 27 numpy calls and a 6.6 GB upload."""
+        assert init_type in ['gaussian', 'adj', 'combine', 'one-hot']
+        files = sorted(os.listdir(origin_base_path))
+        adjs, degrees, max_degree = [], [], 0
+        for i in self._window(start_idx, duration):
+            adj = get_sp_adj_mat(os.path.join(origin_base_path, files[i]), self.full_node_list, sep=sep)
+            deg = np.asarray(adj.sum(axis=1)).reshape(-1).astype(int)       # truncation toward zero, as astype(np.int)
+            max_degree = max(max_degree, int(deg.max(initial=0)))
+            adjs.append(adj)
+            degrees.append(deg)
+        x_list, input_dim = [], 0
+        width = max_degree + 1
+        for adj, deg in zip(adjs, degrees):
+            if init_type == 'gaussian':
+                x_list.append(self._gaussian_degree_features(deg, std, width))
+                input_dim = width
+            elif init_type == 'adj':
+                x_list.append(_coo_tensor(adj, self.device))
+                input_dim = self.node_num
+            elif init_type == 'combine':
+                # sp.coo_matrix(dense) keeps the non-zero entries in row-major order (exact zeros, probability ~0, dropped)
+                gauss = np.random.normal(deg.reshape(-1, 1), std, (len(deg), width))
+                feat = sp.hstack((sp.coo_matrix(gauss), adj)).astype(np.float32)
+                x_list.append(_coo_tensor(feat, self.device))
+                input_dim = feat.shape[1]
+            else:
+                idx = torch.from_numpy(np.vstack((np.arange(len(deg)), deg)).astype(np.int64))
+                x_list.append(torch.sparse_coo_tensor(idx, torch.ones(len(deg), dtype=torch.float32),
+                                                      torch.Size((len(deg), width))).to(self.device))
+                input_dim = width
+        return x_list, input_dim
+
+    def _gaussian_degree_features(self, deg, std, width):
+        if not self.has_cuda:
+            return torch.from_numpy(np.random.normal(deg.reshape(-1, 1), std, (len(deg), width)).astype(np.float32))
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
+        x = torch.randn(len(deg), width, generator=gen, device=self.device, dtype=torch.float32)
+        loc = torch.from_numpy(deg.astype(np.float32)).to(self.device)
+        return x.mul_(float(std)).add_(loc.unsqueeze(1))
+
     def get_feature_list(self, feature_base_path, start_idx, duration, sep='\t', shuffle=False):
-        """One-hot (sparse identity) node features when no feature files exist (reference helper.py:161-172)."""
-        if feature_base_path is not None:
-            raise NotImplementedError("feature files are outside the CTGCN hot path; pass dense tensors directly")
+        """One-hot (sparse identity) node features when no feature files exist, else one dense float32 [rows, F] tensor per
+        snapshot read from `<feature_base_path>/<sorted file i>` (header line, numeric columns), zero-padded on the right to
+        the widest file of the window (reference helper.py:161-192)."""
         x_list = []
-        for _ in self._window(start_idx, duration):
-            cols = np.random.permutation(self.node_num) if shuffle else np.arange(self.node_num)
-            mat = sp.coo_matrix((np.ones(self.node_num), (np.arange(self.node_num), cols)), shape=(self.node_num,) * 2)
-            x_list.append(_coo_tensor(mat, self.device))
-        return x_list, self.node_num
+        if feature_base_path is None:
+            for _ in self._window(start_idx, duration):
+                cols = np.random.permutation(self.node_num) if shuffle else np.arange(self.node_num)
+                mat = sp.coo_matrix((np.ones(self.node_num), (np.arange(self.node_num), cols)), shape=(self.node_num,) * 2)
+                x_list.append(_coo_tensor(mat, self.device))
+            return x_list, self.node_num
+        import pandas as pd
+        files = sorted(os.listdir(feature_base_path))
+        arrays, width = [], 0
+        for i in self._window(start_idx, duration):
+            arr = pd.read_csv(os.path.join(feature_base_path, files[i]), sep=sep, header=0).values
+            width = max(width, arr.shape[1])
+            arrays.append(arr)
+        for arr in arrays:
+            full = np.zeros((arr.shape[0], width), dtype=np.float32)
+            full[:, : arr.shape[1]] = arr
+            x_list.append(torch.from_numpy(full).to(self.device))
+        return x_list, width
 
 
 def _coo_tensor(mat, device):

@@ -59,7 +59,7 @@ def as_core_adj(adj_list, device):
     """Accept what the reference's callers pass: a CoreAdj (our loader) or a python list of torch sparse
     matrices (reference loader, helper.py:51-82).  Lists are fused once and cached by identity."""
     if isinstance(adj_list, CoreAdj):
-        return adj_list if adj_list.device == device else adj_list.to(device)
+        return adj_list if adj_list.device == device else adj_list.to(device)    # .to() keeps the moved copy on the source object
     key = tuple((id(a), a._values().data_ptr() if a.is_sparse else a.data_ptr()) for a in adj_list) + (str(device),)
     hit = _adj_cache.get(key)
     if hit is None:

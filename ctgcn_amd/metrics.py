@@ -6,6 +6,7 @@ the bottleneck of real training once the model is fast.  Here the draws are one 
 """
 import ctypes
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -15,6 +16,9 @@ from . import _lib, ops
 from ._lib import check, ptr
 from .walks import WalkPairs
 
+# seed=None streams: a per-process base drawn from OS entropy (the reference calls random.seed() — OS entropy — on every
+# forward, metrics.py:69) advanced by a counter, so runs, and the ranks of one job, draw different samples
+_seed_base = int.from_bytes(os.urandom(8), "little")
 _seed_counter = itertools.count(1)
 
 
@@ -58,7 +62,7 @@ class NegativeSamplingLoss(nn.Module):
         pos_idx = torch.empty(sample_num, dtype=torch.int64, device=device)
         neg_idx = torch.empty(num, dtype=torch.int64, device=device)
         scratch = torch.empty(num, dtype=torch.int64, device=device)
-        seed = next(_seed_counter) * 0x9E3779B1 if self.seed is None else (self.seed * 1000003 + i)
+        seed = (_seed_base + next(_seed_counter) * 0x9E3779B97F4A7C15) if self.seed is None else (self.seed * 1000003 + i)
         with torch.cuda.device(device):
             check(_lib.load().ctgcn_neg_sampling_indices(batch.numel(), ptr(batch), ptr(pairs.row_ptr), ptr(pairs.col), num, table.numel(),
                                                          ptr(table), ctypes.c_uint64(seed & (2 ** 64 - 1)), ptr(offsets), ptr(node_idx),

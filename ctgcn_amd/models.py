@@ -108,13 +108,22 @@ class CTGCN(nn.Module):
         """hx [N, T, d] -> [T, N, d]: reference models.py:249-250."""
         return rnn_reduce_norm(self.rnn, self.norm, hx, reduce_sum=False).transpose(0, 1)
 
+    def _needs_autograd(self, x_list):
+        """True when the forward has to build an autograd graph: grad mode on and a parameter OR an input requires grad
+        (frozen weights with x.requires_grad_() — saliency runs, a trainable upstream encoder — must not take the
+        write-in-place inference path)."""
+        if not torch.is_grad_enabled():
+            return False
+        return any(p.requires_grad for p in self.parameters()) or any(
+            isinstance(x, torch.Tensor) and x.requires_grad for x in x_list)
+
     def forward(self, x_list, adj_list):
         if self.process_group is not None:
             return sp_par.ctgcn_forward_sharded(self, x_list, adj_list)
         hx, trans = [], []
         T = len(x_list)
         seq = None
-        if not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())) and T > 0:
+        if T > 0 and not self._needs_autograd(x_list):
             # inference: every snapshot's embeddings are written straight into column t of the temporal GRU's [N, T, d]
             # input (models.py:248 stack + transpose without the two copies)
             n = adj_list[0].n if hasattr(adj_list[0], "n") else adj_list[0][0].shape[0]
@@ -122,6 +131,8 @@ class CTGCN(nn.Module):
             seq = torch.empty(n, T, self.output_dim, dtype=p0.dtype, device=p0.device)
         for t in range(T):
             h, tr = self.snapshot_branch(t, x_list[t], adj_list[t], out=None if seq is None else seq[:, t])
+            if seq is not None and h.data_ptr() != seq[:, t].data_ptr():
+                seq[:, t].copy_(h)           # a layer that could not write in place (other rnn type/width) returned its own tensor
             hx.append(h)
             trans.append(tr)
         out = self.temporal_head(seq if seq is not None else torch.stack(hx).transpose(0, 1))

@@ -14,7 +14,10 @@ the reference stacks the per-snapshot states (models.py:248):
 
 Backward is the transposed collective (all-to-all / reduce-scatter).  The temporal rnn/norm weights are
 replicated; sum their grads with allreduce_replicated_grads() after backward.  With gather_output=True the
-output node slices are all-gathered so every rank returns the reference's full [T, N, d].
+output node slices are all-gathered so every rank returns the reference's full [T, N, d]; training on that output
+follows the replicated-loss convention — every rank computes the SAME loss on the full tensor (as the reference's
+single process does) and the gather's backward keeps the rank's own block of the gradient, so parameter gradients equal
+the reference's.  With gather_output=False (bench.py, large graphs) the loss is computed on the rank's node slice.
 
 The backend is whatever the process group was created with: "nccl" (= RCCL) on MI355X, "gloo" in CPU tests.
 """
@@ -143,11 +146,32 @@ class _AllGather(torch.autograd.Function):
         grad = grad.contiguous()
         out = torch.empty(grad.shape[1:], dtype=grad.dtype, device=grad.device)
         if dist.get_backend(ctx.group) == "gloo":      # gloo has no reduce_scatter
+            grad = grad.clone()                            # autograd may hand the same buffer to other consumers
             dist.all_reduce(grad, group=ctx.group)
             out.copy_(grad[dist.get_rank(ctx.group)])
         else:
             dist.reduce_scatter_tensor(out, grad.view((-1,) + tuple(grad.shape[2:])), group=ctx.group)
         return out, None
+
+
+class _GatherReplicatedOutput(torch.autograd.Function):
+    """x [..] -> [world, ..] for an output that every rank then feeds to the SAME loss (gather_output=True: each rank
+    returns the reference's full [T, N, d]).  Every rank's incoming gradient is then the same full tensor, so the
+    gradient of this rank's contribution is simply its own block of it — no communication, and no world-fold
+    over-count as a reduce-scatter of identical gradients would give."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        world = dist.get_world_size(group)
+        x = x.contiguous()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=group)
+        return out.view((world,) + tuple(x.shape))
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad[dist.get_rank(ctx.group)].contiguous(), None
 
 
 # ------------------------------------------------------------------------------------ sharded forward
@@ -159,7 +183,7 @@ def ctgcn_forward_sharded(model, x_list, adj_list):
     mine = plan.assignment[rank]
     assert len(x_list) == plan.T, "window length %d != plan %d" % (len(x_list), plan.T)
 
-    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters())
+    needs_grad = model._needs_autograd(x_list)
     if model.shard_exchange == "all_to_all" and not needs_grad and plan.per > 0:
         return _forward_sharded_pipelined(model, x_list, adj_list)
 
@@ -193,7 +217,7 @@ def ctgcn_forward_sharded(model, x_list, adj_list):
     out = model.temporal_head(seq.transpose(0, 1))                          # [T, nodes, d]
     if not model.shard_replicate_head and model.shard_gather_output:
         padded = torch.nn.functional.pad(out, (0, 0, 0, plan.n_slice - (hi - lo))) if hi - lo < plan.n_slice else out
-        full = _AllGather.apply(padded.transpose(0, 1).contiguous(), group)  # [world, n_slice, T, d]
+        full = _GatherReplicatedOutput.apply(padded.transpose(0, 1).contiguous(), group)  # [world, n_slice, T, d]
         out = full.reshape(plan.n_pad, plan.T, d)[: plan.n].transpose(0, 1)
     if model.model_type == 'C':
         return out
@@ -233,7 +257,7 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
     out = model.temporal_head(seq)                                                          # [T, my nodes, d]
     if model.shard_gather_output:
         padded = torch.nn.functional.pad(out, (0, 0, 0, plan.n_slice - (hi - lo))) if hi - lo < plan.n_slice else out
-        full = _AllGather.apply(padded.transpose(0, 1).contiguous(), group)                 # [world, n_slice, T, d]
+        full = _GatherReplicatedOutput.apply(padded.transpose(0, 1).contiguous(), group)    # [world, n_slice, T, d]
         out = full.reshape(plan.n_pad, plan.T, d)[: plan.n].transpose(0, 1)
     if model.model_type == 'C':
         return out

@@ -73,7 +73,19 @@ def run(rank, world, port, T, n, exchange, results):
         with torch.no_grad():
             full, _ = model(x_list, adj_list)
         err_full = (full - ref_out).abs().max().item()
-        results[rank] = (err_fwd, err_bwd, err_full, plan.assignment)
+        # training on the gathered output (replicated-loss convention: every rank computes the SAME loss on the full
+        # [T, N, d]): parameter gradients must equal the reference's, not world x them
+        model.zero_grad()
+        full, _ = model(x_list, adj_list)
+        (full * gsel).sum().backward()
+        spp.allreduce_replicated_grads(model)
+        err_bwd_full = 0.0
+        for name, p in model.named_parameters():
+            ref_g = sd[name].grad
+            if id(p) not in owned or ref_g is None:
+                continue
+            err_bwd_full = max(err_bwd_full, (p.grad - ref_g).abs().max().item() / (1e-6 + ref_g.abs().max().item()))
+        results[rank] = (err_fwd, max(err_bwd, err_bwd_full), err_full, plan.assignment)
     finally:
         dist.destroy_process_group()
 

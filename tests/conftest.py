@@ -79,3 +79,38 @@ def close_scaled(got, ref, rtol=1e-5, atol_scale=2e-6):
     bad = np.abs(got - ref) > tol
     assert not bad.any(), "max abs err %.3e (tol at worst %.3e), %d/%d out of tolerance" % (
         np.abs(got - ref).max(), tol[bad].min() if bad.any() else 0, bad.sum(), bad.size)
+
+
+def seeded_parameters(module, seed):
+    """Same helper as tests/golden/make_golden.py: parameters from numpy's PCG64 stream, visited in sorted-name order
+    (the width-128 fixtures store expected outputs only)."""
+    import torch
+    with torch.no_grad():
+        for k, (name, p) in enumerate(sorted(module.named_parameters())):
+            rng = np.random.default_rng(seed * 1000 + k)
+            bound = 1.0 / np.sqrt(p.shape[-1]) if p.dim() > 1 else 0.1
+            v = rng.uniform(-bound, bound, size=tuple(p.shape)).astype(np.float32)
+            if name.endswith("norm.weight"):
+                v = v * 5.0 + 1.0
+            p.copy_(torch.from_numpy(v).to(p.device))
+
+
+def check_sampled_tensor(g, key, got, rtol, atol_scale):
+    """Compare a tensor with its golden record written by make_golden.put_tensor: the full tensor when stored, else 256
+    sampled entries plus the sum / abs-sum checksums.  Tolerance: rtol*|ref| + atol_scale*max|ref| per entry."""
+    got = np.asarray(got, dtype=np.float64)
+    if key in g.files:
+        ref = g[key].astype(np.float64)
+        scale = max(1e-30, float(np.abs(ref).max(initial=0.0)))
+        err = np.abs(got - ref)
+        assert (err <= rtol * np.abs(ref) + atol_scale * scale).all(), (key, float(err.max()), scale)
+    else:
+        ref = g[key + "__vals"].astype(np.float64)
+        vals = got.reshape(-1)[g[key + "__pick"]]
+        scale = max(1e-30, float(np.abs(ref).max(initial=0.0)))
+        err = np.abs(vals - ref)
+        assert (err <= rtol * np.abs(ref) + atol_scale * scale).all(), (key, float(err.max()), scale)
+    abssum = float(g[key + "__abssum"])
+    # checksums: the sum of N entries each within the tolerance above
+    assert abs(np.abs(got).sum() - abssum) <= 10 * rtol * abssum + 1e-12, (key, "abssum", np.abs(got).sum(), abssum)
+    assert abs(got.sum() - float(g[key + "__sum"])) <= 10 * rtol * abssum + 1e-12, (key, "sum")

@@ -10,6 +10,8 @@ stored.  Re-run:  python tests/golden/make_golden.py
 Run-time shims (reference files untouched):
   * np.int = int                          (numpy 2 removed the alias)
   * nx.to_scipy_sparse_matrix             (removed in networkx 3)
+  * np.random.normal(loc=1x1 np.matrix)   (gen_degree_features only: helper.py:131 passes a 1x1 matrix as loc, which
+                                           numpy rejects together with size=; the shim hands numpy float(loc))
 
 Outputs
   uci_snapshots.npz      the bundled UCI snapshot edge lists as index arrays
@@ -20,6 +22,11 @@ Outputs
   models_uci.npz         CGCN-C/S and CTGCN-C/S forward (+ input grads) on UCI
   toy_kcore.npz          hand-sized k-core known answers
   export_tsv.npz         bytes of the file the reference's save_embedding writes for a crafted embedding
+  degree_features.npz    DataLoader.get_degree_feature_list (one-hot / adj on UCI; all four init types on a small weighted
+                         graph under np.random.seed) and get_feature_list on feature files
+  models_w128.npz        hidden = embed = 128 (the width of every shipped config and of the fused HIP GRU kernels):
+                         CoreDiffusion(128,128) forward + all gradients, CTGCN-C(24,128,128,1,2,3) and
+                         CTGCN-S(24,128,128,3,1,3) forward + gradient checksums on a UCI window
   negloss.npz            reference random_walk outputs (deterministic matching graph; seeded UCI statistics) and a
                          NegativeSamplingLoss value + gradients on a draw-independent configuration
 """
@@ -420,13 +427,166 @@ def gen_negloss():
     np.savez_compressed(os.path.join(OUT, "negloss.npz"), **d)
 
 
+
+# ------------------------------------------------- degree features / feature files (CTGCN-S input path, helper.py:109-192)
+def put_coo_tensor(d, key, t):
+    """a torch sparse COO tensor exactly as the loader returned it (entry order kept, not coalesced)"""
+    d[key + "_idx"] = t._indices().numpy().astype(np.int32)
+    d[key + "_val"] = t._values().numpy()
+    d[key + "_shape"] = np.array(t.shape, dtype=np.int64)
+    assert t._values().dtype == torch.float32
+
+
+def gen_degree_features():
+    d = {}
+    src_dir = os.path.join(REF, "data", "uci")
+    names = [l.strip() for l in open(os.path.join(src_dir, "nodes_set", "nodes.csv")) if l.strip()]
+    dl = DataLoader(names, 7)
+    for it, tag in (("one-hot", "uci_onehot_"), ("adj", "uci_adj_")):
+        xs, dim = dl.get_degree_feature_list(os.path.join(src_dir, "1.format"), 4, 3, init_type=it)
+        d[tag + "dim"] = np.int64(dim)
+        for t, x in enumerate(xs):
+            put_coo_tensor(d, tag + "t%d" % t, x)
+    # all four init types on weighted_small case 1 (n = 64; fractional weights -> astype(int) truncation), seeded numpy stream
+    ws = np.load(os.path.join(OUT, "weighted_small.npz"))
+    n = int(ws["c1_n"])
+    wnames = ["V%03d" % i for i in range(n)]
+    tmp = tempfile.mkdtemp(prefix="golden_deg_")
+    orig_normal = np.random.normal
+    try:
+        os.makedirs(os.path.join(tmp, "1.format"))
+        for si in range(2):
+            with open(os.path.join(tmp, "1.format", "s%d.csv" % si), "w") as fp:
+                fp.write("from_id\tto_id\tweight\n")
+                for a, b, w in zip(ws["c1_s%d_src" % si], ws["c1_s%d_dst" % si], ws["c1_s%d_w" % si]):
+                    fp.write("%s\t%s\t%s\n" % (wnames[a], wnames[b], repr(float(w)) if w != int(w) else str(int(w))))
+        np.random.normal = lambda loc=0.0, scale=1.0, size=None: orig_normal(float(loc), scale, size)   # shim 3
+        dl2 = DataLoader(wnames, 2)
+        d["small_seed"], d["small_std"] = np.int64(77), np.float64(0.05)
+        for it, tag in (("gaussian", "small_gaussian_"), ("combine", "small_combine_"), ("one-hot", "small_onehot_"), ("adj", "small_adj_")):
+            np.random.seed(77)
+            xs, dim = dl2.get_degree_feature_list(os.path.join(tmp, "1.format"), 0, 2, init_type=it, std=0.05)
+            d[tag + "dim"] = np.int64(dim)
+            for t, x in enumerate(xs):
+                if x.is_sparse:
+                    put_coo_tensor(d, tag + "t%d" % t, x)
+                else:
+                    assert x.dtype == torch.float32
+                    d[tag + "t%d" % t] = x.numpy()
+        # feature files of different widths (helper.py:173-191)
+        os.makedirs(os.path.join(tmp, "feat"))
+        for i, width in enumerate((3, 5)):
+            arr = formula_tensor((n, width), 0.29 + i, 0.7)
+            with open(os.path.join(tmp, "feat", "f%d.csv" % i), "w") as fp:
+                fp.write("\t".join("c%d" % c for c in range(width)) + "\n")
+                for row in arr:
+                    fp.write("\t".join(repr(float(v)) for v in row) + "\n")
+        xs, dim = dl2.get_feature_list(os.path.join(tmp, "feat"), 0, 2)
+        d["feat_dim"] = np.int64(dim)
+        for t, x in enumerate(xs):
+            d["feat_t%d" % t] = x.numpy()
+    finally:
+        np.random.normal = orig_normal
+        shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(OUT, "degree_features.npz"), **d)
+
+
+# --------------------------------------------- hidden = embed = 128: the width the fused HIP GRU kernels cover
+def seeded_parameters(module, seed):
+    """Overwrite every parameter with values from numpy's PCG64 stream (same helper in tests/conftest.py), so the fixture
+    stores expected OUTPUTS only: uniform(-b, b), b = 1/sqrt(last dim) for matrices, 0.1 for vectors; LayerNorm weight
+    around 1."""
+    with torch.no_grad():
+        for k, (name, p) in enumerate(sorted(module.named_parameters())):
+            rng = np.random.default_rng(seed * 1000 + k)
+            bound = 1.0 / np.sqrt(p.shape[-1]) if p.dim() > 1 else 0.1
+            v = rng.uniform(-bound, bound, size=tuple(p.shape)).astype(np.float32)
+            if name.endswith("norm.weight"):
+                v = v * 5.0 + 1.0
+            p.copy_(torch.from_numpy(v))
+
+
+def gen_models_w128():
+    """Reference outputs at the width of every shipped config (embed_dim 128).  Weights and inputs are closed-form /
+    seeded-numpy (regenerated by the tests); stored: a row sample + checksums of the outputs, gradients in full when
+    small, else as (sum, abs-sum, 256 sampled entries)."""
+    d = {}
+    ca = np.load(os.path.join(OUT, "uci_core_adj.npz"))
+    n, dur = 1899, 3
+    adj = []
+    for t in range(dur):
+        mats = []
+        for j in range(int(ca["w4_K"][t])):
+            m = sp.csr_matrix((ca["w4_t%d_j%d_data" % (t, j)].astype(np.float32), ca["w4_t%d_j%d_indices" % (t, j)],
+                               ca["w4_t%d_j%d_indptr" % (t, j)]), shape=(n, n))
+            mats.append(ref_utils.sparse_mx_to_torch_sparse_tensor(m))
+        adj.append(mats)
+    rows = np.arange(0, n, 7)                        # 272 sampled node rows
+    d["rows"] = rows.astype(np.int32)
+
+    def put_tensor(key, g, full_below=6000):
+        g = g.detach().numpy()
+        d[key + "__sum"] = np.float64(g.astype(np.float64).sum())
+        d[key + "__abssum"] = np.float64(np.abs(g.astype(np.float64)).sum())
+        if g.size <= full_below:
+            d[key] = g
+        else:
+            flat = g.reshape(-1)
+            pick = np.linspace(0, flat.size - 1, 256).astype(np.int64)
+            d[key + "__pick"] = pick
+            d[key + "__vals"] = flat[pick]
+
+    # (1) one CoreDiffusion(128, 128) layer on snapshot 0 of the window (K = 4)
+    layer = ref_layers.CoreDiffusion(128, 128, rnn_type="GRU")
+    seeded_parameters(layer, 11)
+    x = torch.from_numpy(formula_tensor((n, 128), 0.19, 0.2)).requires_grad_(True)
+    gout = torch.from_numpy(formula_tensor((n, 128), 0.41, 0.9))
+    out = layer(x, adj[0])
+    (out * gout).sum().backward()
+    d["cd_out_rows"] = out.detach().numpy()[rows]
+    d["cd_dx_rows"] = x.grad.numpy()[rows]
+    put_tensor("cd_out", out)
+    put_tensor("cd_dx", x.grad)
+    for k, v in layer.named_parameters():
+        if v.grad is not None:
+            put_tensor("cd_grad_" + k, v.grad)
+
+    # (2) models
+    x_dense = list(torch.from_numpy(formula_tensor((dur, n, 24), 0.11, 0.3)))
+
+    def record(tag, model, seed, xs):
+        seeded_parameters(model, seed)
+        gsel = torch.from_numpy(formula_tensor((dur, n, model.output_dim), 0.37, 1.1))
+        out = model(xs, adj)
+        if model.model_type == "S":
+            out, trans = out
+            d[tag + "trans_rows"] = torch.stack(list(trans)).detach().numpy()[:, rows]
+        d[tag + "out_rows"] = out.detach().numpy()[:, rows]
+        put_tensor(tag + "out", out)
+        model.zero_grad()
+        (out * gsel).sum().backward()
+        for k, v in model.named_parameters():
+            put_tensor(tag + "grad_" + k, v.grad if v.grad is not None else torch.zeros_like(v))
+
+    record("ctgcn_c_", ref_models.CTGCN(24, 128, 128, 1, 2, dur, rnn_type="GRU", model_type="C", trans_activate_type="L"), 21, x_dense)
+    record("ctgcn_s_", ref_models.CTGCN(24, 128, 128, 3, 1, dur, rnn_type="GRU", model_type="S", trans_activate_type="N"), 22, x_dense)
+    np.savez_compressed(os.path.join(OUT, "models_w128.npz"), **d)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)
+    if len(sys.argv) > 1:                 # regenerate selected fixtures only:  make_golden.py degree w128
+        for what in sys.argv[1:]:
+            {"degree": gen_degree_features, "w128": gen_models_w128, "negloss": gen_negloss, "export": gen_export,
+             "toy": gen_toy, "small": gen_weighted_small, "uci": gen_uci}[what]()
+        sys.exit(0)
     gen_negloss()
     gen_export()
     gen_toy()
     gen_weighted_small()
     gen_uci()
+    gen_degree_features()
+    gen_models_w128()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print("%-24s %8.1f KiB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))

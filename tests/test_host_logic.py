@@ -259,3 +259,122 @@ def test_negative_table_matches_reference_formula():
         f = rng.integers(0, 5000, 400) * (rng.random(400) < 0.8)
         assert np.array_equal(negative_table(f), O.negative_table(f))
     assert len(negative_table(np.zeros(7, dtype=np.int64))) == 0
+
+
+# ------------------------------------------- CTGCN-S input path: degree features / feature files (helper.py:109-192)
+def _coo_equal(t, g, key):
+    assert t.is_sparse and t.dtype == torch.float32 and tuple(t.shape) == tuple(g[key + "_shape"])
+    assert np.array_equal(t._indices().numpy().astype(np.int32), g[key + "_idx"])
+    assert np.array_equal(t._values().numpy(), g[key + "_val"])
+
+
+def _write_snapshot_files(folder, names, rows):
+    os.makedirs(folder)
+    for fname, (src, dst, w) in rows.items():
+        with open(os.path.join(folder, fname), "w") as fp:
+            fp.write("from_id\tto_id\tweight\n")
+            for a, b, ww in zip(src, dst, w):
+                fp.write("%s\t%s\t%s\n" % (names[a], names[b], repr(float(ww)) if ww != int(ww) else str(int(ww))))
+
+
+def test_degree_feature_list_matches_reference_loader(tmp_path):
+    """one-hot / adj on the UCI window and all four init types on a weighted graph (fractional weighted degrees, seeded
+    numpy stream): same tensors, entry order, dtypes and input_dim as the reference's get_degree_feature_list."""
+    g = load_golden("degree_features.npz")
+    snaps = load_golden("uci_snapshots.npz")
+    names = [str(x) for x in snaps["node_names"]]
+    _write_snapshot_files(str(tmp_path / "uci"), names,
+                          {str(f): (snaps["t%d_src" % t], snaps["t%d_dst" % t], snaps["t%d_w" % t]) for t, f in enumerate(snaps["files"])})
+    dl = ctgcn_amd.DataLoader(names, 7)
+    for it, tag in (("one-hot", "uci_onehot_"), ("adj", "uci_adj_")):
+        xs, dim = dl.get_degree_feature_list(str(tmp_path / "uci"), 4, 3, init_type=it)
+        assert dim == int(g[tag + "dim"]) and len(xs) == 3
+        for t, x in enumerate(xs):
+            _coo_equal(x, g, tag + "t%d" % t)
+    ws = load_golden("weighted_small.npz")
+    n = int(ws["c1_n"])
+    wnames = ["V%03d" % i for i in range(n)]
+    _write_snapshot_files(str(tmp_path / "small"), wnames,
+                          {"s%d.csv" % si: (ws["c1_s%d_src" % si], ws["c1_s%d_dst" % si], ws["c1_s%d_w" % si]) for si in range(2)})
+    dl2 = ctgcn_amd.DataLoader(wnames, 2)
+    for it, tag in (("gaussian", "small_gaussian_"), ("combine", "small_combine_"), ("one-hot", "small_onehot_"), ("adj", "small_adj_")):
+        np.random.seed(int(g["small_seed"]))
+        xs, dim = dl2.get_degree_feature_list(str(tmp_path / "small"), 0, 2, init_type=it, std=float(g["small_std"]))
+        assert dim == int(g[tag + "dim"])
+        for t, x in enumerate(xs):
+            if it == "gaussian":
+                assert not x.is_sparse and x.dtype == torch.float32
+                assert np.array_equal(x.numpy(), g[tag + "t%d" % t])       # same numpy stream, bit for bit
+            else:
+                _coo_equal(x, g, tag + "t%d" % t)
+    with pytest.raises(AssertionError):
+        dl2.get_degree_feature_list(str(tmp_path / "small"), 0, 2, init_type="degree")
+
+
+def test_feature_file_loader_matches_reference(tmp_path):
+    g = load_golden("degree_features.npz")
+    from conftest import formula_tensor
+    n = 64
+    os.makedirs(tmp_path / "feat")
+    for i, width in enumerate((3, 5)):
+        arr = formula_tensor((n, width), 0.29 + i, 0.7)
+        with open(tmp_path / "feat" / ("f%d.csv" % i), "w") as fp:
+            fp.write("\t".join("c%d" % c for c in range(width)) + "\n")
+            for row in arr:
+                fp.write("\t".join(repr(float(v)) for v in row) + "\n")
+    dl = ctgcn_amd.DataLoader(["V%03d" % i for i in range(n)], 2)
+    xs, dim = dl.get_feature_list(str(tmp_path / "feat"), 0, 2)
+    assert dim == int(g["feat_dim"]) == 5
+    for t, x in enumerate(xs):
+        assert x.dtype == torch.float32 and np.array_equal(x.numpy(), g["feat_t%d" % t])
+    eye, dim = dl.get_feature_list(None, 0, 2)
+    assert dim == n and eye[0].is_sparse and eye[0]._nnz() == n
+
+
+# ------------------------------------------------------------------ forward-path selection (advisor finding, round 1)
+def test_frozen_weights_with_input_gradients_take_the_autograd_path(monkeypatch):
+    """All parameters frozen, inputs require grad, grad mode on: the write-in-place inference path must NOT be taken (it
+    would feed an uninitialised buffer to the temporal head and drop the input gradients).  The HIP aggregation cannot
+    run here; the CPU oracle is injected at the product's dispatch point as the checker."""
+    from oracle import torch_path as TP, oracle as O
+    from ctgcn_amd import ops
+    from ctgcn_amd.synth import dynamic_graph
+
+    def oracle_aggregate(x, adj, relu=True):
+        mats = [TP.coo_like_reference(m) for m in adj.to_scipy_list()]
+        return torch.stack(TP.aggregate_loop(mats, x), 0).transpose(0, 1)
+
+    monkeypatch.setattr(ops, "core_aggregate", oracle_aggregate)
+    monkeypatch.setattr(ops, "_need_cuda", lambda *a: None)
+    n, T = 120, 3
+    graphs = dynamic_graph(n, 6, T, seed=2)
+    lists = [O.core_adj_list([O.kcore_matrices(g)], 0, 1, 1, max_core=3)[0] for g in graphs]
+    adj = [CoreAdj.from_matrices(l) for l in lists]
+    torch.manual_seed(0)
+    model = ctgcn_amd.CTGCN(10, 12, 8, 1, 2, T)
+    xs = [torch.randn(n, 10) for _ in range(T)]
+    with torch.no_grad():
+        want = model(xs, adj)                              # inference path
+    for p in model.parameters():
+        p.requires_grad_(False)
+    xg = [x.clone().requires_grad_(True) for x in xs]
+    assert model._needs_autograd(xg) and not model._needs_autograd(xs)
+    out = model(xg, adj)
+    assert out.requires_grad
+    np.testing.assert_allclose(out.detach().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    gsel = torch.randn_like(want)              # (not out.square().sum(): LayerNorm makes that constant, its gradient is rounding noise)
+    (out * gsel).sum().backward()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    ref = TP.ctgcn_with_grad(sd, xr, [[TP.coo_like_reference(m) for m in l] for l in lists])
+    (ref * gsel).sum().backward()
+    for a, b in zip(xg, xr):
+        np.testing.assert_allclose(a.grad.numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-5 * float(b.grad.abs().max()))
+
+
+def test_core_adj_device_copies_are_cached():
+    adj = CoreAdj.from_matrices([sp.eye(5, format="csr") + sp.csr_matrix(np.ones((5, 5)) - np.eye(5))])
+    assert adj.to("cpu") is adj
+    fake = adj._copy_to(torch.device("cpu"))
+    adj._moved["meta"] = fake                              # what .to() stores after the first move to another device
+    assert adj.to("meta") is fake

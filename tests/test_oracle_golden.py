@@ -157,6 +157,85 @@ def test_models_match_reference_outputs():
     np.testing.assert_allclose(out.numpy(), g["cgcn_c_single_out"], **tol)
 
 
+def test_width_128_models_match_reference_outputs():
+    """hidden = embed = 128 (the width of every shipped config): reference CoreDiffusion / CTGCN-C / CTGCN-S outputs and
+    gradients (tests/golden/models_w128.npz) vs the torch restatement, weights regenerated from the seeded-numpy helper."""
+    from conftest import seeded_parameters, check_sampled_tensor
+    g = load_golden("models_w128.npz")
+    rows = g["rows"]
+    adj, n = _uci_window(4, 3)
+    dur = 3
+
+    class _Bag(torch.nn.Module):          # named parameters in a module the helper can visit; names = reference state_dict keys
+        def __init__(self, shapes):
+            super().__init__()
+            self.names = sorted(shapes)
+            self.ps = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(shapes[k])) for k in self.names])
+
+        def named_parameters(self, *a, **k):
+            return iter(zip(self.names, self.ps))
+
+    def shapes_cd(prefix, din, dout):
+        return {prefix + "linear.weight": (dout, din), prefix + "linear.bias": (dout,),
+                prefix + "rnn.weight_ih_l0": (3 * dout, din), prefix + "rnn.weight_hh_l0": (3 * dout, dout),
+                prefix + "rnn.bias_ih_l0": (3 * dout,), prefix + "rnn.bias_hh_l0": (3 * dout,),
+                prefix + "norm.weight": (dout,), prefix + "norm.bias": (dout,)}
+
+    # (1) the layer
+    bag = _Bag(shapes_cd("", 128, 128))
+    seeded_parameters(bag, 11)
+    sd = dict(bag.named_parameters())
+    x = torch.from_numpy(formula_tensor((n, 128), 0.19, 0.2)).requires_grad_(True)
+    gout = torch.from_numpy(formula_tensor((n, 128), 0.41, 0.9))
+    saved = TP._rnn
+    TP._rnn = TP._rnn_grad
+    try:
+        out = TP.core_diffusion(sd, "", x, adj[0], "GRU")
+    finally:
+        TP._rnn = saved
+    np.testing.assert_allclose(out.detach().numpy()[rows], g["cd_out_rows"], rtol=1e-4, atol=1e-5)
+    (out * gout).sum().backward()
+    check_sampled_tensor(g, "cd_out", out.detach().numpy(), 1e-4, 1e-5)
+    np.testing.assert_allclose(x.grad.numpy()[rows], g["cd_dx_rows"], rtol=1e-4, atol=1e-5 * float(np.abs(g["cd_dx_rows"]).max()))
+    for name, p in sd.items():
+        if "linear" in name:
+            continue
+        check_sampled_tensor(g, "cd_grad_" + name, p.grad.numpy(), 2e-4, 2e-5)
+
+    # (2) CTGCN-C and CTGCN-S
+    xd = [torch.from_numpy(a) for a in formula_tensor((dur, n, 24), 0.11, 0.3)]
+    gsel = torch.from_numpy(formula_tensor((dur, n, 128), 0.37, 1.1))
+    for tag, seed, mtype, act, trans_num, diff_num in (("ctgcn_c_", 21, "C", "L", 1, 2), ("ctgcn_s_", 22, "S", "N", 3, 1)):
+        shapes = {}
+        for t in range(dur):
+            if trans_num == 1:
+                shapes["mlp_list.%d.linear.weight" % t] = (128, 24)
+                shapes["mlp_list.%d.linear.bias" % t] = (128,)
+            else:
+                widths = [24] + [128] * trans_num
+                for i in range(trans_num):
+                    shapes["mlp_list.%d.linears.%d.weight" % (t, i)] = (widths[i + 1], widths[i])
+                    shapes["mlp_list.%d.linears.%d.bias" % (t, i)] = (widths[i + 1],)
+            for l in range(diff_num):
+                shapes.update(shapes_cd("duffision_list.%d.diffusion_list.%d." % (t, l), 128, 128))
+        shapes.update({"rnn.weight_ih_l0": (384, 128), "rnn.weight_hh_l0": (384, 128), "rnn.bias_ih_l0": (384,),
+                       "rnn.bias_hh_l0": (384,), "norm.weight": (128,), "norm.bias": (128,)})
+        bag = _Bag(shapes)
+        seeded_parameters(bag, seed)
+        sd = dict(bag.named_parameters())
+        res = TP.ctgcn_with_grad(sd, xd, adj, "GRU", mtype, act)
+        if mtype == "S":
+            res, trans = res
+            np.testing.assert_allclose(torch.stack(trans).detach().numpy()[:, rows], g[tag + "trans_rows"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(res.detach().numpy()[:, rows], g[tag + "out_rows"], rtol=1e-4, atol=1e-5)
+        check_sampled_tensor(g, tag + "out", res.detach().numpy(), 1e-4, 1e-5)
+        (res * gsel).sum().backward()
+        for name, p in sd.items():
+            if ".linear." in name and "mlp_list" not in name:
+                continue                       # CoreDiffusion.linear is unused (layers.py:24): zero gradient on both sides
+            check_sampled_tensor(g, tag + "grad_" + name, p.grad.numpy(), 5e-4, 5e-5)
+
+
 # ------------------------------------------------------------------ random walks / negative sampling (§8f rank 3)
 def test_walk_corpus_oracle_matches_reference_on_deterministic_graph():
     g = load_golden("negloss.npz")

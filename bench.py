@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py — CTGCN hot-path benchmark on MI355X (driver contract: one JSON line on rank 0).
+"""bench.py — CTGCN hot-path benchmark on MI355X (driver contract: ONE JSON line on rank 0's stdout).
 
-step     = one embedding (forward) pass of CTGCN-C over the whole T-snapshot window: per-snapshot
-           one-hot MLP -> 2 x CoreDiffusion (HIP aggregation + core-axis GRU + LayerNorm) -> exchange ->
-           temporal GRU + LayerNorm.  Inputs (graphs, features, weights) are resident in HBM before timing.
-metric   = aggregated edges/s over the window = sum_t sum_layers sum_k nnz(A(t,k)) / step time  (BASELINE.json)
-workload = BASELINE config 5: synthetic power-law dynamic graph, 1M nodes x 16 cumulative snapshots,
-           avg-deg 16, max_core capped at 8, hid = embed = 128.  Fits one GPU; with --gpus N the
-           SAME window is sharded snapshot-parallel over N ranks (strong scaling).
+step     = one embedding (forward) pass of CTGCN over the whole T-snapshot window: per-snapshot MLP -> CoreDiffusion
+           layers (HIP nested-k-core aggregation + core-axis GRU + LayerNorm) -> exchange -> temporal GRU + LayerNorm.
+           Graphs, features and weights are resident in HBM before the timed region.
+metric   = aggregated edges/s over the window = sum_t sum_layers sum_k nnz(A(t,k)) / step time        (BASELINE.json)
+workload = default `synthetic-1m` = BASELINE config 5 (1M nodes x 16 cumulative snapshots, avg-deg 16, max_core capped at 8,
+           hid = embed = 128): fits one GPU; with --gpus N the SAME window is sharded snapshot-parallel over
+           N ranks (strong scaling).  --workload picks the other BASELINE configs' shapes (enron-like = config 2,
+           facebook-like = config 3 (CTGCN-S), math-like / as-like = config 4); their lines are committed under profiles/.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel (agg_fwd_kernel): algorithmic bytes per launch / HIP-event-measured duration
-  cpu_baseline  the reference's torch.sparse.mm CPU loop (oracle/torch_path.py) on a bounded sample, rank 0, N=1 only
+`python bench.py --gpus N` with N > 1 and no launcher environment re-launches itself under torch.distributed.run
+(one process per GPU, RCCL, 127.0.0.1 rendezvous); under a launcher (RANK/WORLD_SIZE set) it runs as that rank.
+
+Extra objects on the JSON line (SURVEY.md §8d):
+  roofline            dominant kernel (agg_fwd_kernel): algorithmic bytes per launch / HIP-event duration on the launch stream
+  roofline_by_width   the same per feature width when the model aggregates at more than one (hid=500: d=500 and d=128)
+  roofline_gru        matrix-core kernels (recurrence / input projection)
+  roofline_kcore      k-core peel of the window's largest snapshot: 2(4(N+1)+4nnz)+8N bytes / measured peel time
+  cpu_baseline        the reference's torch.sparse.mm loop on the host cores (warm-up 2, 5 repeats, median; uncoalesced COO
+                      as the reference builds it + a coalesced-CSR variant), bounded sample, rank 0, N=1 only
+  cpu_baseline_kcore  Batagelj-Zaversnik (the algorithm of networkx.core_number) single thread, oracle C restatement
+  exact_fp32          the same forward with CTGCN_FP32_MFMA_ONLY=1 (no fp16x2 operand split in the GRU products)
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,11 +38,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 WORKLOADS = {
-    # name: (nodes, snapshots, avg_deg, max_core, hid, embed, description)
-    "synthetic-1m": (1_000_000, 16, 16, 8, 128, 128, "BASELINE config 5: synthetic 1M nodes x 16 snapshots, avg-deg 16"),
-    "facebook-like": (60_730, 27, 20, 9, 128, 128, "BASELINE config 3 shape: 60 730 nodes x 27 snapshots (synthetic stand-in)"),
-    "enron-like": (87_036, 12, 12, 5, 500, 128, "BASELINE config 2 shape: 87 036 nodes x 12 snapshots, max_core 5 (synthetic stand-in)"),
-    "tiny": (20_000, 4, 8, 4, 64, 64, "debug"),
+    "synthetic-1m": dict(nodes=1_000_000, T=16, edges=8_000_000, cumulative=True, max_core=8, hid=128, emb=128, model="C", trans=1,
+                         diff=2, act="L", features="one-hot",
+                         desc="BASELINE config 5: synthetic 1M nodes x 16 cumulative snapshots, avg-deg 16"),
+    "enron-like": dict(nodes=87_036, T=12, edges=530_284, cumulative=True, max_core=5, hid=500, emb=128, model="C", trans=1, diff=2,
+                       act="L", features="one-hot",
+                       desc="BASELINE config 2 shape: Enron statistics (87 036 nodes, 530 284 edges), 12-snapshot window, max_core 5 "
+                            "(synthetic stand-in, the dataset is not available offline)"),
+    "facebook-like": dict(nodes=60_730, T=27, edges=607_487, cumulative=True, max_core=-1, hid=500, emb=128, model="S", trans=3, diff=1,
+                          act="N", features="gaussian-degree",
+                          desc="BASELINE config 3 shape: Facebook statistics (60 730 nodes, 607 487 edges), full 27-snapshot window, "
+                               "CTGCN-S (3 transform layers, 1 diffusion layer at d=128, gaussian degree features; synthetic stand-in)"),
+    "math-like": dict(nodes=24_740, T=8, edges=323_357, cumulative=True, max_core=-1, hid=500, emb=128, model="C", trans=1, diff=2, act="L",
+                      features="one-hot",
+                      desc="BASELINE config 4 shape (math): 24 740 nodes, 323 357 edges, 8-snapshot window (synthetic stand-in)"),
+    "as-like": dict(nodes=6_828, T=8, edges=19_500, cumulative=False, max_core=-1, hid=500, emb=128, model="C", trans=1, diff=2, act="L",
+                    features="one-hot",
+                    desc="BASELINE config 4 shape (AS): 6 828 nodes, ~19.5k edges per snapshot, NON-cumulative 8-snapshot window "
+                         "(synthetic stand-in)"),
+    "tiny": dict(nodes=20_000, T=4, edges=80_000, cumulative=True, max_core=4, hid=64, emb=64, model="C", trans=1, diff=2, act="L",
+                 features="one-hot", desc="debug"),
 }
 
 
@@ -50,7 +75,8 @@ def parse():
                     help="replay the window from one captured hipGraph (ctgcn_amd.graph_capture; single GPU, inference): "
                          "removes launch/Python overhead on small graphs; per-launch HIP-event timing (roofline) is off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=30.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 forward and the k-core roofline legs")
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     return ap.parse_args()
 
 
@@ -60,8 +86,38 @@ def algorithmic_bytes(n, nnz, K, d):
     return nnz * (4 * d + 9) + n * K * 4 * d + 4 * (n + 1)
 
 
+def kcore_bytes(n, nnz):
+    """SURVEY.md §8d k-core minimum traffic: one read of the CSR for the degrees, one for the decrements, core array r/w."""
+    return 2 * (4 * (n + 1) + 4 * nnz) + 8 * n
+
+
+def agg_kernel_name(d):
+    chunks = (d + 3) // 4
+    lpr = 8
+    while lpr < 64 and lpr < chunks:
+        lpr <<= 1
+    return "agg_fwd_kernel<4,%d,4> (CoreDiffusion fused nested-core SpMM, d=%d%s)" % (lpr, d, ", %d passes" % (-(-chunks // lpr)) if chunks > lpr else "")
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: re-run this script under torch.distributed.run, one rank per GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    import torch
+    import torch.distributed as dist
     # stdout carries exactly ONE JSON line: anything libraries print on fd 1 meanwhile (RCCL's version banner ...)
     # is routed to stderr until the result is ready.
     sys.stdout.flush()
@@ -71,43 +127,51 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # CTGCN_FORCE_DIST=1 runs the RCCL/sharded code path even with one rank (1-GPU boxes can exercise it)
-    force_dist = os.environ.get("CTGCN_FORCE_DIST") == "1" and "RANK" in os.environ
+    force_dist = os.environ.get("CTGCN_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ctgcn_amd import CTGCN, CoreAdj, ops, _lib
     from ctgcn_amd import snapshot_parallel as spp
-    from ctgcn_amd.synth import dynamic_graph_device, prefix_sizes, DEFAULT_SEED
+    from ctgcn_amd.synth import window_graph_device, prefix_sizes, DEFAULT_SEED
     _lib.load()
 
-    n, T, avg_deg, max_core, hid, emb, desc = WORKLOADS[args.workload]
+    W = WORKLOADS[args.workload]
+    n, T, hid, emb = W["nodes"], W["T"], W["hid"], W["emb"]
     log = (lambda *a: print(*a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
 
     # ---------------------------------------------------------------- plan + graphs (owned snapshots only)
-    sizes = prefix_sizes(int(n * avg_deg / 2), T)
+    sizes = prefix_sizes(W["edges"], T) if W["cumulative"] else [W["edges"]] * T
     assignment = spp.plan_assignment(sizes, world)
     mine = assignment[rank]
     t0 = time.time()
-    graphs = dynamic_graph_device(n, avg_deg, T, dev, seed=DEFAULT_SEED, which=mine)
+    need = sorted(set(mine) | ({0} if W["max_core"] == -1 else set()))    # sticky max_core: snapshot 0's file count caps the window
+    graphs = window_graph_device(n, W["edges"], T, dev, seed=DEFAULT_SEED, cumulative=W["cumulative"], which=need)
     log("generated %d/%d snapshots in %.1fs" % (len(mine), T, time.time() - t0))
     t0 = time.time()
-    adj_list, local_stats = [None] * T, {}
+    max_core = W["max_core"]
+    if max_core == -1:      # helper.py:61-62: -1 becomes the FIRST snapshot's k-core file count and stays that
+        _, max_core = ops.kcore(graphs[0][0], graphs[0][1])
+    adj_list, local_stats, degrees = [None] * T, {}, {}
     for t in mine:
         rp, col, val = graphs[t]
         adj, core, files = CoreAdj.from_graph(rp, col, val, max_core=max_core)
         adj_list[t] = adj
         local_stats[t] = dict(K=adj.K, nnz=adj.nnz, agg=adj.aggregated_edges, max_core=files)
+        if W["features"] == "gaussian-degree":
+            degrees[t] = (rp[1:] - rp[:-1]).to(torch.float32)          # unit weights: weighted degree = neighbour count
     torch.cuda.synchronize()
-    log("k-core + slot tagging of %d snapshots in %.2fs" % (len(mine), time.time() - t0))
+    log("k-core + slot tagging of %d snapshots in %.2fs (max_core %d)" % (len(mine), time.time() - t0, max_core))
+    kc_t = max(mine, key=lambda t: local_stats[t]["nnz"]) if mine else None
+    kc_graph = graphs[kc_t][:2] if kc_t is not None else None
     del graphs
 
     # every rank needs the window totals (metric numerator)
@@ -119,18 +183,29 @@ def main():
             stats.update(g)
     else:
         stats = local_stats
-    layers = 2
+    layers = W["diff"]
     agg_edges_step = layers * sum(stats[t]["agg"] for t in range(T))
 
-    # ------------------------------------------------------------------------------- model + features
+    # ------------------------------------------------------------------------------- features + model
+    x_list = [None] * T
+    if W["features"] == "one-hot":           # sparse identity (reference helper.py:161-172)
+        input_dim = n
+        eye_idx = torch.arange(n, device=dev).repeat(2, 1)
+        for t in mine:
+            x_list[t] = torch.sparse_coo_tensor(eye_idx, torch.ones(n, device=dev), (n, n))
+    else:                                    # Normal(degree, 1e-4) rows of width max-degree + 1 (reference helper.py:128-135)
+        md = torch.tensor([max([int(d.max().item()) for d in degrees.values()] + [0])], device=dev)
+        if use_dist:
+            dist.all_reduce(md, op=dist.ReduceOp.MAX)
+        input_dim = int(md.item()) + 1
+        gen = torch.Generator(device=dev)
+        for t in mine:
+            gen.manual_seed(DEFAULT_SEED + t)
+            x_list[t] = torch.randn(n, input_dim, generator=gen, device=dev).mul_(1e-4).add_(degrees[t].unsqueeze(1))
     torch.manual_seed(0)
     with torch.device(dev):
-        model = CTGCN(n, hid, emb, 1, layers, T, rnn_type="GRU", model_type="C", trans_activate_type="L")
+        model = CTGCN(input_dim, hid, emb, W["trans"], layers, T, rnn_type="GRU", model_type=W["model"], trans_activate_type=W["act"])
     model.eval()
-    eye_idx = torch.arange(n, device=dev).repeat(2, 1)
-    x_list = [None] * T
-    for t in mine:   # one-hot node features = sparse identity (reference helper.py:161-172)
-        x_list[t] = torch.sparse_coo_tensor(eye_idx, torch.ones(n, device=dev), (n, n))
     if use_dist:
         spp.shard_ctgcn(model, n, assignment=assignment, exchange=args.exchange, gather_output=False)
 
@@ -149,14 +224,17 @@ def main():
         params = list(spp.owned_parameters(model)) if use_dist else list(model.parameters())
         opt = torch.optim.Adam(params, lr=1e-3)
 
+    def first(res):
+        return res[0] if isinstance(res, tuple) else res     # 'S' models also return the transform outputs
+
     def step():
         if args.graph:
-            return runner()
+            return first(runner())
         if not args.train:
             with torch.no_grad():
-                return model(x_list, adj_list)
+                return first(model(x_list, adj_list))
         opt.zero_grad(set_to_none=True)
-        out = model(x_list, adj_list)
+        out = first(model(x_list, adj_list))
         out.square().mean().backward()
         if use_dist:
             spp.allreduce_replicated_grads(model)
@@ -169,55 +247,69 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    launches.clear()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t_start
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    ms_per_step = 1000.0 * elapsed / args.steps
+    def timed(steps, warmup):
+        for _ in range(warmup):
+            step()
+        fence()
+        launches.clear()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        fence()
+        elapsed = time.perf_counter() - t_start
+        if use_dist:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return 1000.0 * elapsed / steps, out
+
+    ms_per_step, out = timed(args.steps, args.warmup)
     assert torch.isfinite(out).all()
+    recorded = list(launches)
 
     # ------------------------------------------------------------------------- roofline of the dominant kernel
     ops.set_launch_timer(None)
-    fwd = [(s.elapsed_time(e), meta) for name, s, e, meta in launches if name == "agg_fwd"]
-    kern_ms = [ms for ms, _ in fwd]
-    kern_bytes = [algorithmic_bytes(m["n"], m["nnz"], m["K"], m["d"]) for _, m in fwd]
-    roof = None
-    if fwd:
-        avg_ms = sum(kern_ms) / len(kern_ms)
-        avg_bytes = sum(kern_bytes) / len(kern_bytes)
+    fwd = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "agg_fwd"]
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc = {}
+    if os.path.exists(pmc_file):
+        try:
+            pmc = json.load(open(pmc_file))
+        except Exception:
+            pmc = {}
+
+    def roofline_of(group, d):
+        avg_ms = sum(ms for ms, _ in group) / len(group)
+        avg_bytes = sum(algorithmic_bytes(m["n"], m["nnz"], m["K"], m["d"]) for _, m in group) / len(group)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file):
-            try:
-                rec = json.load(open(pmc_file)).get(args.workload, {}).get(str(world))
-                traffic = rec["hbm_bytes_per_launch"] if rec else None
-            except Exception:
-                traffic = None
-        roof = {"kernel": "agg_fwd_kernel<4,32,4> (CoreDiffusion fused nested-core SpMM, d=128)", "bound": "hbm",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "launches_timed": len(fwd), "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_launch": int(avg_bytes),
+        rec = pmc.get(args.workload, {}).get(str(world)) if d == 128 else None
+        return {"kernel": agg_kernel_name(d), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec["hbm_bytes_per_launch"] if rec else None,
+                "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/agg_bench.py on the same "
+                                   "workload (separate run, not this one)") if rec else None,
+                "launches_timed": len(group), "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(avg_bytes),
+                "ms_per_step_rank0": round(sum(ms for ms, _ in group) / args.steps, 3),
                 "frac_of_measured_copy_bw_6300": round(achieved / 6300.0, 4)}
+
+    by_width = {}
+    for ms, m in fwd:
+        by_width.setdefault(m["d"], []).append((ms, m))
+    roofs = {d: roofline_of(g, d) for d, g in by_width.items()}
+    roof = None
+    if roofs:
+        roof = roofs[max(roofs, key=lambda d: roofs[d]["ms_per_step_rank0"])]      # dominant = most time per step
+    kern_ms = [ms for ms, _ in fwd]
     spmm_ms_step = sum(kern_ms) / args.steps if kern_ms else None
     # the matrix-core kernels: GRU recurrence (+ sum/LayerNorm) and the input projection
-    gru = [(s.elapsed_time(e), meta) for name, s, e, meta in launches if name == "gru_seq"]
-    proj = [(s.elapsed_time(e), meta) for name, s, e, meta in launches if name == "gru_proj"]
+    gru = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_seq"]
+    proj = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_proj"]
+    fused = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_fused"]
     roof_mfma = None
+    mode = ops.forward_split_mode()
+    peak = {2: 2500.0 / 3.0, 1: 2500.0 / 6.0, 0: 157.3}[mode]
     if gru:
-        mode = ops.forward_split_mode()
         # fp32-equivalent flops; step 0 (h = 0) issues no MFMA.  The matrix-core bound is the dense 16-bit peak divided by
         # the number of 16-bit products per fp32 product (fp16x2: 3, bf16x3: 6), or the fp32 MFMA peak for the exact path.
-        peak = {2: 2500.0 / 3.0, 1: 2500.0 / 6.0, 0: 157.3}[mode]
         name = {2: "gru_seq_h2_kernel (GRU recurrence + sum + LayerNorm; fp32 operands scaled per row and split into two fp16 "
                    "terms, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)",
                 1: "gru_seq_x3_kernel (GRU recurrence + sum + LayerNorm; fp32 operands split 3-way into bf16, "
@@ -238,19 +330,77 @@ def main():
             roof_mfma["input_projection"] = {"kernel": pname, "bound": "hbm", "ms_per_step_rank0": round(pms / args.steps, 3),
                                              "achieved": round(pbytes / (pms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": round(pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if fused:
+        # projection + recurrence in one kernel: 2*128*384 flops per row-step for the projection, the same for every step but the first
+        flops = sum(m["rows"] * (2 * m["steps"] - 1) * 2.0 * 128 * 384 for _, m in fused)
+        ms = sum(t for t, _ in fused)
+        hbm = sum(m["rows"] * (m["steps"] * 512.0 + 512.0) for _, m in fused)       # H tile in, one output row out
+        fr = {"kernel": "gru_fused kernel (input projection + recurrence + sum + LayerNorm of a node tile in one block, fp16x2 split)",
+              "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
+              "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
+              "compulsory_hbm_GBps": round(hbm / (ms * 1e-3) / 1e9, 1), "launches_timed": len(fused),
+              "ms_per_step_rank0": round(ms / args.steps, 3)}
+        if roof_mfma is None:
+            roof_mfma = fr
+        else:
+            roof_mfma["fused_layers"] = fr
+
+    # ------------------------------------------------------------------------- extras: exact fp32 forward, k-core peel
+    exact = None
+    roof_kcore = None
+    if not args.no_extras and not args.train and not args.graph:
+        prev = os.environ.get("CTGCN_FP32_MFMA_ONLY")
+        os.environ["CTGCN_FP32_MFMA_ONLY"] = "1"
+        try:
+            ms_exact, out_exact = timed(max(2, min(3, args.steps)), 1)
+        finally:
+            if prev is None:
+                del os.environ["CTGCN_FP32_MFMA_ONLY"]
+            else:
+                os.environ["CTGCN_FP32_MFMA_ONLY"] = prev
+        diff = float((out_exact - out).abs().max().item())
+        exact = {"ms_per_step": round(ms_exact, 3), "mode": "CTGCN_FP32_MFMA_ONLY=1: hipBLASLt fp32 GEMM projection + v_mfma_f32_16x16x4_f32 "
+                 "recurrence (no 16-bit operand split)", "max_abs_diff_vs_default": diff,
+                 "note": "the default line's GRU products use the fp16x2 split (22 mantissa bits per operand, fp32 accumulate)"}
+        if kc_graph is not None and rank == 0:
+            rp, col = kc_graph
+            res = {}
+            for label, cap in (("exact", -1), ("capped", max_core)):
+                ops.kcore(rp, col, level_cap=cap)
+                times = []
+                for _ in range(5):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    _, mk = ops.kcore(rp, col, level_cap=cap)
+                    b.record()
+                    b.synchronize()
+                    times.append(a.elapsed_time(b))
+                res[label] = (statistics.median(times), mk)
+            nb = kcore_bytes(n, int(col.numel()))
+            ms_k = res["exact"][0]
+            roof_kcore = {"kernel": "kcore_init_kernel + kcore_level_kernel x levels (integer peel, bit-exact core numbers)", "bound": "hbm",
+                          "achieved": round(nb / (ms_k * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(nb / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                          "algorithmic_bytes": nb, "peel_ms_exact": round(ms_k, 3), "max_core": int(res["exact"][1]),
+                          "peel_ms_capped_at_max_core_%d" % max_core: round(res["capped"][0], 3),
+                          "snapshot": kc_t, "stored_entries": int(col.numel()),
+                          "note": "includes the host read-back of the level counter every 16 levels; latency-bound (peel depth), not bandwidth-bound"}
     if use_dist:
         dist.barrier()
     if rank != 0:
         dist.destroy_process_group()
         return
 
-    # ------------------------------------------------------------------------------------- CPU baseline (N=1)
-    cpu = None
+    # ------------------------------------------------------------------------------------- CPU baselines (N=1)
+    cpu = cpu_k = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(adj_list[T - 1], emb, args.cpu_budget_s, log)
+        widths = [hid if W["model"] == "C" else emb] + [emb] * (layers - 1)
+        cpu = cpu_baseline(adj_list, widths, args.cpu_budget_s, log)
+        cpu_k = cpu_baseline_kcore(kc_graph, n, log) if kc_graph is not None else None
 
+    agg_rate = None if not spmm_ms_step else layers * sum(stats[t]["agg"] for t in mine) / (spmm_ms_step * 1e-3)
     line = {
-        "metric": "aggregated edges/s over T-snapshot window (CTGCN-C %s)" % ("training step: forward + backward + Adam" if args.train else "embedding forward"),
+        "metric": "aggregated edges/s over T-snapshot window (CTGCN-%s %s)" % (W["model"], "training step: forward + backward + Adam" if args.train else "embedding forward"),
         "value": agg_edges_step / (ms_per_step * 1e-3),
         "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -260,20 +410,28 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (seed %d power-law dynamic graph, random-init weights)" % DEFAULT_SEED,
-        "config": {"workload": "%s; CTGCN-C hid=%d embed=%d, 2 diffusion layers, max_core=%d" % (desc, hid, emb, max_core),
-                   "nodes": n, "snapshots": T, "avg_deg": avg_deg, "max_core": max_core,
+        "config": {"workload": "%s; CTGCN-%s hid=%d embed=%d, %d transform + %d diffusion layers, max_core=%d, %s features" % (
+                       W["desc"], W["model"], hid, emb, W["trans"], layers, max_core, W["features"]),
+                   "name": args.workload, "nodes": n, "snapshots": T, "edges_last_snapshot": sizes[-1], "max_core": max_core,
+                   "input_dim": input_dim,
                    "K_per_snapshot": [stats[t]["K"] for t in range(T)],
                    "stored_entries_per_snapshot": [stats[t]["nnz"] for t in range(T)],
                    "aggregated_edges_per_step": agg_edges_step,
                    "parallelism": "snapshot-parallel x%d (%s exchange before the temporal GRU)" % (world, args.exchange) if world > 1 else ("single GPU, hipGraph replay" if args.graph else "single GPU"),
                    "assignment": assignment},
+        "value_definition": "headline `value` = aggregated edges / WHOLE forward wall-clock (embed_wall_ms; conservative: includes the dense "
+                            "GRU/Linear/LayerNorm time); `aggregation_edges_per_s_rank0` = the same edges / time inside the aggregation "
+                            "kernels only (SURVEY §8d(i))",
         "embed_wall_ms": round(ms_per_step, 3),
         "aggregation_ms_per_step_rank0": None if spmm_ms_step is None else round(spmm_ms_step, 3),
-        "aggregation_edges_per_s_rank0": None if not spmm_ms_step else
-            layers * sum(stats[t]["agg"] for t in mine) / (spmm_ms_step * 1e-3),
+        "aggregation_edges_per_s_rank0": agg_rate,
         "roofline": roof,
+        "roofline_by_width": {str(d): r for d, r in sorted(roofs.items())} if len(roofs) > 1 else None,
         "roofline_gru": roof_mfma,
+        "roofline_kcore": roof_kcore,
+        "exact_fp32": exact,
         "cpu_baseline": cpu,
+        "cpu_baseline_kcore": cpu_k,
     }
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
@@ -282,34 +440,100 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(adj, d, budget_s, log):
-    """Reference CPU path (layers.py:41-48 loop of torch.sparse.mm on uncoalesced COO, utils.py:89-95) timed on
-    the host cores for ONE CoreDiffusion aggregation of the window's LAST snapshot at d=128; stops adding
-    matrices once the budget is spent and reports edges/s over what was run."""
+def cpu_baseline(adj_list, widths, budget_s, log):
+    """Reference CPU path (layers.py:41-48: the loop of torch.sparse.mm over the k-core list + add + ReLU; operands built as
+    utils.py:89-95 builds them: int64-index, uncoalesced COO) on all host cores, for the CoreDiffusion aggregations of ONE snapshot
+    of the window at the model's layer widths.  Protocol: warm-up 2, 5 timed repeats, median; plus the same loop on
+    coalesced CSR operands.  The sample snapshot is the largest one whose 2 x 7 passes fit the budget (rate calibrated on the
+    smallest)."""
+    import torch
     from oracle import torch_path as TP
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    mats = adj.cpu().to_scipy_list()
-    coo = [TP.coo_like_reference(m) for m in mats]
-    x = torch.randn(adj.n, d)
-    done_edges, t_used, acc, used = 0, 0.0, None, 0
-    for j, a in enumerate(coo):
+    owned = sorted((t for t, a in enumerate(adj_list) if a is not None), key=lambda t: adj_list[t].aggregated_edges)
+    n = adj_list[owned[0]].n
+    xs = {d: torch.randn(n, d) for d in set(widths)}
+
+    def operands(t):
+        mats = adj_list[t].cpu().to_scipy_list()
+        coo = [TP.coo_like_reference(m) for m in mats]
+        csr = [torch.sparse_csr_tensor(torch.from_numpy(m.indptr.astype("int64")), torch.from_numpy(m.indices.astype("int64")),
+                                       torch.from_numpy(m.data), size=m.shape) for m in mats]
+        return coo, csr
+
+    def loop(ops_):
         t0 = time.perf_counter()
-        y = torch.sparse.mm(a, x)
-        acc = y if acc is None else acc + y
-        acc_r = torch.relu(acc)
-        dt = time.perf_counter() - t0
-        t_used += dt
-        done_edges += a._nnz()
-        used = j + 1
-        if t_used > budget_s:
-            break
-    del acc_r
-    log("cpu baseline: %d/%d matrices, %.1fs" % (used, len(coo), t_used))
-    return {"value": done_edges / t_used, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": "oracle/torch_path.py (reference layers.py:41-48 restated: torch.sparse.mm on uncoalesced COO + add + relu), "
-                      "last snapshot of the window, first %d of %d k-core matrices, d=%d, %d aggregated edges in %.1f s, "
-                      "single un-warmed pass" % (used, len(coo), d, done_edges, t_used)}
+        for d in widths:
+            hs = TP.aggregate_loop(ops_, xs[d])
+        del hs
+        return time.perf_counter() - t0
+
+    t_small = owned[0]
+    coo, csr = operands(t_small)
+    loop(coo)
+    calib = loop(coo)
+    rate = adj_list[t_small].aggregated_edges * len(widths) / calib
+    pick = t_small
+    for t in owned:
+        if adj_list[t].aggregated_edges * len(widths) * 14 / rate <= budget_s:
+            pick = t
+    if pick != t_small:
+        coo, csr = operands(pick)
+    edges = adj_list[pick].aggregated_edges * len(widths)
+    res = {}
+    for label, ops_ in (("coo", coo), ("csr", csr)):
+        for _ in range(2):
+            loop(ops_)
+        times = [loop(ops_) for _ in range(5)]
+        res[label] = (statistics.median(times), min(times), max(times))
+    log("cpu baseline: snapshot %d, %d aggregated edges/pass, coo %.3fs csr %.3fs" % (pick, edges, res["coo"][0], res["csr"][0]))
+    return {"value": edges / res["coo"][0], "unit": "edges/s", "cores": cores, "kind": "port",
+            "value_coalesced_csr": edges / res["csr"][0],
+            "protocol": "warm-up 2, 5 timed repeats, median (min %.3f / max %.3f s for COO)" % (res["coo"][1], res["coo"][2]),
+            "sample": "oracle/torch_path.py (reference layers.py:41-48 restated: torch.sparse.mm on uncoalesced int64 COO operands as "
+                      "utils.py:89-95 builds them + add + relu; `value_coalesced_csr` = the same loop on coalesced torch CSR operands), "
+                      "snapshot %d of the window (%d k-core matrices, %d nodes), feature widths %s, %d aggregated edges per pass, "
+                      "median pass %.3f s (COO) / %.3f s (CSR), torch.set_num_threads(%d)" % (
+                          pick, adj_list[pick].K, n, widths, edges, res["coo"][0], res["csr"][0], cores)}
+
+
+def cpu_baseline_kcore(kc_graph, n, log):
+    """k-core baseline (reference structure_generation.py:35 nx.core_number): the oracle's C Batagelj-Zaversnik peel, one thread,
+    on the same snapshot the GPU peel was timed on; warm-up 1, 5 repeats, median.  networkx itself is timed when the snapshot is
+    small enough to finish in seconds."""
+    import ctypes
+    import numpy as np
+    from oracle import oracle as O
+    rp, col = kc_graph
+    indptr = rp.cpu().numpy().astype(np.int64)
+    indices = col.cpu().numpy().astype(np.int32)
+    core = np.zeros(n, dtype=np.int32)
+    lib = O.lib()
+    call = lambda: lib.oracle_kcore_bz(ctypes.c_int64(n), indptr.ctypes.data_as(ctypes.c_void_p), indices.ctypes.data_as(ctypes.c_void_p),
+                                       core.ctypes.data_as(ctypes.c_void_p))
+    call()
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        call()
+        times.append(time.perf_counter() - t0)
+    out = {"value": statistics.median(times) * 1e3, "unit": "ms", "cores": 1, "kind": "port",
+           "sample": "oracle/ctgcn_oracle.c Batagelj-Zaversnik bin-sort peel (the algorithm of networkx.core_number, reference "
+                     "structure_generation.py:35), %d nodes, %d stored entries, warm-up 1, 5 repeats, median" % (n, len(indices)),
+           "max_core": int(core.max(initial=0))}
+    if len(indices) <= 1_500_000:
+        try:
+            import networkx as nx
+            import scipy.sparse as sp
+            g = nx.from_scipy_sparse_array(sp.csr_matrix((np.ones(len(indices), dtype=np.int8), indices, indptr), shape=(n, n)))
+            t0 = time.perf_counter()
+            cn = nx.core_number(g)
+            out["networkx_core_number_ms"] = (time.perf_counter() - t0) * 1e3
+            assert max(cn.values(), default=0) == out["max_core"]
+        except ImportError:
+            pass
+    log("cpu k-core baseline: %.1f ms" % out["value"])
+    return out
 
 
 if __name__ == "__main__":

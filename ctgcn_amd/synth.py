@@ -64,6 +64,50 @@ def dynamic_graph(n, avg_deg, snapshots, seed=DEFAULT_SEED, max_degree_hint=None
     return out
 
 
+def snapshot_rows(n, n_edges, snapshots, seed=DEFAULT_SEED, cumulative=True, max_degree_hint=None):
+    """Edge rows of every snapshot of a synthetic window as (u, v, [index array per snapshot]).
+
+    cumulative=True   n_edges = size of the LAST snapshot; snapshot i = the first prefix_sizes()[i] rows of the shuffled
+                      list (reference graph.py:101-108 — Enron / Facebook / math style growth).
+    cumulative=False  n_edges = rows PER snapshot; every snapshot is an independent seeded draw of n_edges rows from a pool
+                      of 2 x n_edges power-law edges (AS-style daily graphs: same node set, mostly-overlapping edge sets,
+                      no growth; reference README.md:168-176)."""
+    if cumulative:
+        u, v = powerlaw_edges(n, n_edges, seed, max_degree_hint=max_degree_hint)
+        return u, v, [np.arange(m) for m in prefix_sizes(len(u), snapshots)]
+    u, v = powerlaw_edges(n, 2 * n_edges, seed, max_degree_hint=max_degree_hint)
+    rng = np.random.default_rng(seed + 1)
+    return u, v, [np.sort(rng.choice(len(u), size=n_edges, replace=False)) for _ in range(snapshots)]
+
+
+def window_graph_device(n, n_edges, snapshots, device, seed=DEFAULT_SEED, cumulative=True, max_degree_hint=None, which=None):
+    """{t: (row_ptr, col, val)} device CSR triples of the snapshots in `which` (default all) of snapshot_rows(...)."""
+    u, v, picks = snapshot_rows(n, n_edges, snapshots, seed, cumulative, max_degree_hint)
+    from . import ops
+    ud, vd = torch.from_numpy(u.astype(np.int32)).to(device), torch.from_numpy(v.astype(np.int32)).to(device)
+    out = {}
+    for t in (range(snapshots) if which is None else which):
+        if cumulative:
+            m = len(picks[t])
+            out[t] = ops.edges_to_csr(ud[:m], vd[:m], None, n)
+        else:
+            idx = torch.from_numpy(picks[t]).to(device)
+            out[t] = ops.edges_to_csr(ud[idx], vd[idx], None, n)
+    return out
+
+
+def window_graph(n, n_edges, snapshots, seed=DEFAULT_SEED, cumulative=True, max_degree_hint=None):
+    """Same windows as window_graph_device, as scipy CSR on the host (tests, CPU oracle)."""
+    u, v, picks = snapshot_rows(n, n_edges, snapshots, seed, cumulative, max_degree_hint)
+    out = []
+    for idx in picks:
+        uu, vv = u[idx], v[idx]
+        a = sp.coo_matrix((np.ones(2 * len(uu)), (np.concatenate([uu, vv]), np.concatenate([vv, uu]))), shape=(n, n)).tocsr()
+        a.sort_indices()
+        out.append(a)
+    return out
+
+
 def dynamic_graph_device(n, avg_deg, snapshots, device, seed=DEFAULT_SEED, max_degree_hint=None, which=None):
     """Same graphs as dynamic_graph, built as device CSR triples (row_ptr int32, col int32, val float32) by the
     library's GPU ingest (ctgcn_edges_to_csr).  `which`: iterable of snapshot indices to build (default all);

@@ -1,0 +1,88 @@
+"""BASELINE configs 2, 3, 4 on the GPU (VERDICT r1 "configs untested"): the HIP path on the Enron / Facebook-S / math / AS
+window shapes (synthetic stand-ins with the datasets' published statistics, reference README.md:168-176) against the CPU
+oracle (oracle/torch_path.py: the reference's torch.sparse path, pinned to reference outputs by tests/test_oracle_golden.py)
+on the FULL output, plus the loader-level integers (K per snapshot, core numbers) bit for bit.
+
+Tolerance: SURVEY.md §8c after GRU + LayerNorm — rtol 1e-4, atol 1e-5.  Observed max |err| is printed per case."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = {
+    # name: nodes, edges, T, cumulative, max_core, hid, model, trans, diff, act, features
+    "enron_c2": dict(n=87_036, edges=530_284, T=12, cumulative=True, max_core=5, hid=500, model="C", trans=1, diff=2, act="L", feat="one-hot"),
+    "facebook_s_c3": dict(n=60_730, edges=607_487, T=27, cumulative=True, max_core=-1, hid=500, model="S", trans=3, diff=1, act="N", feat="gaussian"),
+    "math_c4": dict(n=24_740, edges=323_357, T=8, cumulative=True, max_core=-1, hid=500, model="C", trans=1, diff=2, act="L", feat="one-hot"),
+    "as_c4": dict(n=6_828, edges=19_500, T=8, cumulative=False, max_core=-1, hid=500, model="C", trans=1, diff=2, act="L", feat="one-hot"),
+}
+
+
+def _build(case):
+    """graphs on the host (oracle side) and through the device route (product side), with the loader's sticky max_core"""
+    from ctgcn_amd.helper import core_adj_from_scipy
+    from ctgcn_amd.synth import window_graph
+    from oracle import oracle as O, torch_path as TP
+    c = CASES[case]
+    graphs = window_graph(c["n"], c["edges"], c["T"], cumulative=c["cumulative"], max_degree_hint=500 if c["feat"] == "gaussian" else None)
+    cores = [O.core_numbers(g) for g in graphs]
+    mats = [O.kcore_matrices(g, core) for g, core in zip(graphs, cores)]
+    ref_lists = O.core_adj_list(mats, 0, c["T"], c["T"], max_core=c["max_core"])
+    adj, mc = [], c["max_core"]
+    for g, core in zip(graphs, cores):
+        a, core_dev, files = core_adj_from_scipy(g, mc, DEV)
+        want = core if mc < 0 else np.minimum(core, mc)
+        assert np.array_equal(core_dev.cpu().numpy(), want)                  # integer k-core assignment: bit-exact
+        if mc == -1:
+            mc = files                                                       # helper.py:61-62
+        adj.append(a)
+    assert [len(a) for a in adj] == [len(l) for l in ref_lists]
+    for a, l in zip(adj, ref_lists):
+        assert a.nnz_per_slot == [m.nnz for m in l]
+    ref_adj = [[TP.coo_like_reference(m) for m in l] for l in ref_lists]
+    return c, graphs, adj, ref_adj
+
+
+def _features(c, graphs):
+    n, T = c["n"], c["T"]
+    if c["feat"] == "one-hot":
+        idx = torch.arange(n).repeat(2, 1)
+        xs = [torch.sparse_coo_tensor(idx, torch.ones(n), (n, n)) for _ in range(T)]
+        return xs, n
+    # Normal(degree, 1e-4) rows of width max degree + 1 (helper.py:128-135); the SAME host tensors feed both sides
+    deg = [np.asarray(g.sum(axis=1)).reshape(-1).astype(int) for g in graphs]
+    width = max(int(d.max()) for d in deg) + 1
+    rng = np.random.default_rng(7)
+    xs = [torch.from_numpy((d[:, None] + 1e-4 * rng.standard_normal((n, width))).astype(np.float32)) for d in deg]
+    return xs, width
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_baseline_config_shapes_match_cpu_oracle(case):
+    import ctgcn_amd
+    from ctgcn_amd import ops
+    from oracle import torch_path as TP
+    c, graphs, adj, ref_adj = _build(case)
+    xs, input_dim = _features(c, graphs)
+    torch.manual_seed(0)
+    model = ctgcn_amd.CTGCN(input_dim, c["hid"], 128, c["trans"], c["diff"], c["T"], rnn_type="GRU", model_type=c["model"],
+                            trans_activate_type=c["act"]).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    assert ops.gru_fused_ok(model.rnn, torch.zeros(1, 1, 128, device=DEV))     # the HIP GRU kernels are the ones running
+    with torch.no_grad():
+        got = model([x.to(DEV) for x in xs], adj)
+        want = TP.ctgcn(sd, xs, ref_adj, "GRU", c["model"], c["act"])
+    if c["model"] == "S":
+        (got, got_tr), (want, want_tr) = got, want
+        for a, b in zip(got_tr, want_tr):
+            scale = float(b.abs().max())
+            assert float((a.cpu() - b).abs().max()) <= 1e-5 * scale + 1e-6, "transform outputs (dense Linear + SELU)"
+    got = got.cpu().numpy()
+    want = want.numpy()
+    assert got.shape == want.shape == (c["T"], c["n"], 128)
+    err = np.abs(got - want)
+    print("%s: max |err| %.3e, mean %.3e, max|ref| %.3f" % (case, err.max(), err.mean(), np.abs(want).max()))
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)

@@ -329,3 +329,56 @@ def test_binary_core_cache_route_matches_reference_loader(tmp_path):
                 assert np.array_equal(m.data, want.data)
     auto = dl.get_core_adj_list(str(tmp_path / "2.corecache"), 0, 7, max_core=5)         # same entry point as the reference
     assert [len(g) for g in auto] == ca["mc5_K"].tolist()
+
+
+# ------------------------------------------- hidden = embed = 128 against the REFERENCE's own outputs (models_w128.npz)
+def test_width_128_hip_path_matches_reference_outputs_and_gradients():
+    """The fused HIP GRU kernels (projection + recurrence, fp16x2 split) and their backward are pinned to outputs of the
+    reference itself at the width every shipped config uses: CoreDiffusion(128,128) forward / dX / parameter gradients,
+    CTGCN-C(24,128,128,1,2,3) and CTGCN-S(24,128,128,3,1,3) forward and gradients (tests/golden/make_golden.py w128)."""
+    import ctgcn_amd
+    from ctgcn_amd import ops
+    from conftest import seeded_parameters, check_sampled_tensor
+    g = load_golden("models_w128.npz")
+    rows = g["rows"]
+    adj = _window()
+    n, T = 1899, 3
+    assert ops.split_mfma_enabled()
+
+    layer = ctgcn_amd.CoreDiffusion(128, 128, rnn_type="GRU").to(DEV)
+    seeded_parameters(layer, 11)
+    assert ops.gru_fused_ok(layer.rnn, torch.zeros(1, 1, 128, device=DEV))
+    x = torch.from_numpy(formula_tensor((n, 128), 0.19, 0.2)).to(DEV).requires_grad_(True)
+    gout = torch.from_numpy(formula_tensor((n, 128), 0.41, 0.9)).to(DEV)
+    out = layer(x, adj[0])
+    np.testing.assert_allclose(out.detach().cpu().numpy()[rows], g["cd_out_rows"], rtol=1e-4, atol=1e-5)
+    check_sampled_tensor(g, "cd_out", out.detach().cpu().numpy(), 1e-4, 1e-5)
+    (out * gout).sum().backward()
+    dx = x.grad.cpu().numpy()
+    np.testing.assert_allclose(dx[rows], g["cd_dx_rows"], rtol=1e-4, atol=2e-5 * float(np.abs(g["cd_dx_rows"]).max()))
+    for name, p in layer.named_parameters():
+        if name.startswith("linear"):
+            continue
+        check_sampled_tensor(g, "cd_grad_" + name, p.grad.cpu().numpy(), 5e-4, 5e-5)
+
+    xd = [torch.from_numpy(a).to(DEV) for a in formula_tensor((T, n, 24), 0.11, 0.3)]
+    gsel = torch.from_numpy(formula_tensor((T, n, 128), 0.37, 1.1)).to(DEV)
+    for tag, seed, kw in (("ctgcn_c_", 21, dict(trans_num=1, diffusion_num=2, model_type="C", trans_activate_type="L")),
+                          ("ctgcn_s_", 22, dict(trans_num=3, diffusion_num=1, model_type="S", trans_activate_type="N"))):
+        m = ctgcn_amd.CTGCN(24, 128, 128, duration=T, rnn_type="GRU", **kw).to(DEV)
+        seeded_parameters(m, seed)
+        with torch.no_grad():
+            res = m(xd, adj)
+        res = res[0] if kw["model_type"] == "S" else res
+        np.testing.assert_allclose(res.cpu().numpy()[:, rows], g[tag + "out_rows"], rtol=1e-4, atol=1e-5)     # inference path
+        res = m(xd, adj)
+        if kw["model_type"] == "S":
+            res, trans = res
+            np.testing.assert_allclose(torch.stack(trans).detach().cpu().numpy()[:, rows], g[tag + "trans_rows"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(res.detach().cpu().numpy()[:, rows], g[tag + "out_rows"], rtol=1e-4, atol=1e-5)
+        check_sampled_tensor(g, tag + "out", res.detach().cpu().numpy(), 1e-4, 1e-5)
+        (res * gsel).sum().backward()
+        for name, p in m.named_parameters():
+            if ".linear." in name and "mlp_list" not in name:
+                continue
+            check_sampled_tensor(g, tag + "grad_" + name, p.grad.cpu().numpy(), 1e-3, 2e-4)

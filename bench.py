@@ -303,7 +303,7 @@ def main():
     # the matrix-core kernels: GRU recurrence (+ sum/LayerNorm) and the input projection
     gru = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_seq"]
     proj = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_proj"]
-    fused = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_fused"]
+    fused = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name in ("gru_layer", "gru_fused")]
     roof_mfma = None
     mode = ops.forward_split_mode()
     peak = {2: 2500.0 / 3.0, 1: 2500.0 / 6.0, 0: 157.3}[mode]
@@ -335,7 +335,8 @@ def main():
         flops = sum(m["rows"] * (2 * m["steps"] - 1) * 2.0 * 128 * 384 for _, m in fused)
         ms = sum(t for t, _ in fused)
         hbm = sum(m["rows"] * (m["steps"] * 512.0 + 512.0) for _, m in fused)       # H tile in, one output row out
-        fr = {"kernel": "gru_fused kernel (input projection + recurrence + sum + LayerNorm of a node tile in one block, fp16x2 split)",
+        fr = {"kernel": "gru_layer_h2_kernel (CoreDiffusion GRU: input projection + recurrence + sum over cores + LayerNorm in one kernel, "
+                        "both weight matrices resident in the register file, the projection consumed from the MFMA accumulators; fp16x2 split)",
               "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
               "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
               "compulsory_hbm_GBps": round(hbm / (ms * 1e-3) / 1e9, 1), "launches_timed": len(fused),
@@ -436,6 +437,7 @@ def main():
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(line), flush=True)
+    os.dup2(2, 1)               # whatever RCCL prints while shutting down must not follow the JSON line on stdout
     if use_dist:
         dist.destroy_process_group()
 

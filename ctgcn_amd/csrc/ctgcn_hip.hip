@@ -25,6 +25,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "../../include/ctgcn_hip.h"
 
@@ -1770,6 +1771,323 @@ __global__ __launch_bounds__(512, 2) void gru_fused_h2_kernel(const FusedArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// gru_layer_h2_kernel: input projection AND recurrence of a node tile in one kernel with BOTH weight matrices resident in
+// the register file — GI is never materialised anywhere (not in HBM, not in the memory-side cache, not in LDS).
+// Why it fits: W_ih and W_hh as fp16x2 MFMA fragments are 2 x 196 KB = 77 % of a CU's 512 KB unified VGPR/AGPR file.  A
+// block is therefore FOUR waves, one per SIMD (512 registers each): wave w owns hidden units [32w, 32w + 32) of all three
+// gates of both matrices = 2 x 192 registers of ready-made MFMA A operands, most of them in the accumulator half of the
+// file (MFMA reads A/B operands from AGPRs directly), which leaves the 128-odd architectural VGPRs a wave needs for
+// accumulators, B operands and gate math.  Per (step, 16-row tile) a wave issues 72 MFMAs for x_t·W_ihᵀ and 72 for
+// h_{t-1}·W_hhᵀ and finishes its 32 hidden units' gate math straight from the accumulators.
+// Data flow per block (persistent, 64-row tiles, "unit" = one step of one 16-row sub-tile):
+//   global x -> registers (two units ahead) -> per-row power-of-two scale + fp16x2 split -> LDS ring of two 16-row slots;
+//   h_t: fp32 in LDS (the lane that wrote a value is the only one that reads it back) + fp16x2 planes in LDS for the
+//   next step's MFMAs, published one unit late so that one barrier per unit orders every hazard;
+//   REDUCE: running sum in LDS, LayerNorm at the end of the tile; otherwise LayerNorm(h_t) rows are emitted per unit.
+// Arithmetic is that of gru_proj_h2_kernel + gru_seq_h2_kernel operation for operation (same splits, same MFMA order
+// per accumulator, same epilogue expressions): results are bit-identical to the kernel pair.
+// HBM traffic: x in (512 B per row-step) + out; the pair moves 3.6 KB per row-step.
+// ------------------------------------------------------------------------------------------------
+constexpr int LY_BM = 32;     // rows per tile (2 MFMA row tiles): small, so that LDS has room for weight fragments
+constexpr int LY_RT = LY_BM / 16;
+constexpr int LY_WL_TOTAL = 80;   // W_ih fragments of the block kept in LDS (1 KB each): 80 KB, split evenly over the waves
+// Fragment (unit tile of the wave, split, k chunk, gate) of W_ih that lives in LDS, or -1.  Residual plane first.
+//   NW = 4 (two unit tiles per wave, 20 slots): chunks 0-2 of both unit tiles + (chunk 3, ut 0, gates r z)
+//   NW = 8 (one unit tile per wave, 10 slots):  chunks 0-2 + (chunk 3, gate r)
+template <int NW>
+__device__ __forceinline__ constexpr int ly_lds_slot(int ut, int sp, int c, int g)
+{
+    if (NW == 4) return (sp == 1 && c < 3) ? (c * 2 + ut) * 3 + g : ((sp == 1 && c == 3 && ut == 0 && g < 2) ? 18 + g : -1);
+    return (sp == 1 && c < 3) ? c * 3 + g : ((sp == 1 && c == 3 && g == 0) ? 9 : -1);
+}
+// ... and these W_ih fragments are pinned to AGPRs next to all of W_hh; the rest of the AGPRs is left to the MFMA accumulators.
+template <int NW>
+__device__ __forceinline__ constexpr bool ly_in_agpr(int ut, int sp, int c, int g)
+{
+    if (NW == 4) return (sp == 1 && ly_lds_slot<4>(ut, sp, c, g) < 0) || (sp == 0 && c == 3 && ut == 1);     // 48 + 7 fragments = 220 registers
+    return (sp == 1 && ly_lds_slot<8>(ut, sp, c, g) < 0) || (sp == 0 && c >= 2);                               // 24 + 8 fragments = 128 registers
+}
+
+struct LayerArgs {
+    int64_t rows;            // sequences (nodes)
+    int32_t steps;
+    const float *x;          // [rows, steps, 128], row-step stride ldx
+    int64_t ldx;
+    const float *wih, *whh;  // [384, 128] each
+    const float *bias_gi;    // [384] or null: b_ih (+ b_hh for r, z)
+    const float *bhn;        // [128] or null
+    const float *gamma, *beta;
+    float eps;
+    float *out;              // REDUCE: [rows, ldo]; else [rows, steps, 128]
+    int64_t ldo;
+};
+
+// weight fragments of ONE 16-unit tile (tile16 = hidden units [16*tile16, 16*tile16+16)) of all three gates, as h2_load_weights
+template <int RS>
+__device__ __forceinline__ void h2_load_weight_tile(const float *w, int tile16, int col, int grp, h8v (&Wf)[2][4][3], float (*wscale)[GRU_H])
+{
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        const float *row = w + (int64_t)(g * GRU_H + tile16 * 16 + col) * GRU_H;
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f4v lo = *(const f4v *)(row + c * 32 + 8 * grp), hi = *(const f4v *)(row + c * 32 + 8 * grp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m = fmaxf(m, fmaxf(fabsf(lo[j]), fabsf(hi[j])));
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sc, inv;
+        h2_scale(m, sc, inv);
+        if (grp == 0) wscale[g][tile16 * 16 + col] = sc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h2_split_x8<RS>(row + c * 32 + 8 * grp, inv, Wf[0][c][g], Wf[1][c][g]);
+    }
+}
+
+// NW = waves per block: 4 (one per SIMD, 512 registers each, two 16-unit tiles per wave) or 8 (two per SIMD, 256 registers
+// each, one 16-unit tile per wave: the second wave of a SIMD covers the first one's LDS latency).
+template <bool REDUCE, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const LayerArgs a)
+{
+    constexpr int UTW = 8 / NW;                          // 16-unit tiles per wave
+    constexpr int NT = 64 * NW;
+    constexpr int WL = LY_WL_TOTAL / NW;                 // LDS-resident W_ih fragments per wave
+    constexpr int SL = 4 * NW;                           // staging lanes per x row (16 rows per unit)
+    constexpr int SF = GRU_H / SL;                       // floats per staging lane: 8 or 4
+    __shared__ _Float16 Xs[2][2][16][PJ_PITCH];          // ring of two units: the two fp16 planes of 16 rows of x_t
+    __shared__ _Float16 Hs[2][LY_BM][PJ_PITCH];          // the two fp16 planes of h_{t-1}·2^14 for the tile's rows
+    __shared__ float hold[LY_BM][GRU_PITCH];             // h_{t-1} in fp32 (each value is read back only by the lane that wrote it)
+    __shared__ float hsum[LY_BM][GRU_PITCH];             // REDUCE: running sum over steps
+    __shared__ float xscale[2][16];
+    __shared__ float wsc_ih[3][GRU_H];
+    __shared__ float csc_hh[4][GRU_H];                   // rows 0-2: product scales of the three gates, row 3: b_hn
+    __shared__ float bias_s[3][GRU_H];
+    __shared__ h8v Wl[NW][WL][64];                       // per wave: the W_ih fragments that do not fit the register file
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int S = a.steps;
+
+    h8v Wi[UTW][2][4][3], Wh[UTW][2][4][3];              // [unit tile][split][k chunk][gate]
+#pragma unroll
+    for (int ut = 0; ut < UTW; ++ut) {
+        h2_load_weight_tile<2048>(a.wih, wave * UTW + ut, col, grp, Wi[ut], wsc_ih);
+        h2_load_weight_tile<1>(a.whh, wave * UTW + ut, col, grp, Wh[ut], csc_hh);
+    }
+    // Register-file placement: MFMA A operands may live in the accumulator half (AGPRs) of the unified file, everything the
+    // VALU touches must be in the architectural half.  The empty asm gives a value the AGPR register class for its whole
+    // live range (the MFMAs read it there); WL fragments per wave go to LDS and are read on the spot; the rest stays in VGPRs.
+#pragma unroll
+    for (int ut = 0; ut < UTW; ++ut)
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    asm volatile("" : "+a"(Wh[ut][sp][c][g]));
+                    if (ly_in_agpr<NW>(ut, sp, c, g)) asm volatile("" : "+a"(Wi[ut][sp][c][g]));
+                    if (ly_lds_slot<NW>(ut, sp, c, g) >= 0) Wl[wave][ly_lds_slot<NW>(ut, sp, c, g)][lane] = Wi[ut][sp][c][g];
+                }
+    __syncthreads();
+    for (int i = tid; i < 3 * GRU_H; i += NT) {
+        (&csc_hh[0][0])[i] *= (1.f / 16384.f);           // x the scale of h (planes hold h·2^14)
+        (&bias_s[0][0])[i] = a.bias_gi ? a.bias_gi[i] : 0.f;
+    }
+    if (tid < GRU_H) csc_hh[3][tid] = a.bhn ? a.bhn[tid] : 0.f;
+    __syncthreads();
+
+    const int64_t ntiles = (a.rows + LY_BM - 1) / LY_BM;
+    const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
+    // staging role: 16 rows x SL lanes, a lane holds SF consecutive floats of its row
+    const int sr = tid / SL, sc = (tid % SL) * SF;
+    struct Unit { int64_t tile; int t, rt; };
+    auto advance = [&](Unit u, int n) {                  // n units later in this block's (tile, step, row tile) order
+        u.rt += n;
+        u.t += u.rt / LY_RT; u.rt %= LY_RT;
+        while (u.t >= S) { u.t -= S; u.tile += gridDim.x; }
+        return u;
+    };
+    auto load_x = [&](const Unit u, f4v (&v)[SF / 4]) {
+        if (u.tile < ntiles) {
+            const int64_t row = min(u.tile * LY_BM + u.rt * 16 + sr, a.rows - 1);
+            const float *p = a.x + (row * S + u.t) * a.ldx + sc;
+#pragma unroll
+            for (int i = 0; i < SF / 4; ++i) v[i] = *(const f4v *)(p + 4 * i);
+        }
+    };
+    auto stage_x = [&](int slot, const f4v (&v)[SF / 4]) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < SF / 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(v[i][j]));
+#pragma unroll
+        for (int d = 1; d < SL; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+        float scl, inv;
+        h2_scale(m, scl, inv);
+        if ((tid % SL) == 0) xscale[slot][sr] = scl;
+#pragma unroll
+        for (int i = 0; i < SF / 4; ++i) {
+            h4v s0, s1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 p, q;
+                h2_split<2048>(v[i][j] * inv, p, q); s0[j] = p; s1[j] = q;
+            }
+            *(h4v *)(&Xs[slot][0][sr][sc + 4 * i]) = s0;
+            *(h4v *)(&Xs[slot][1][sr][sc + 4 * i]) = s1;
+        }
+    };
+
+    Unit cur{(int64_t)blockIdx.x, 0, 0};
+    if (cur.tile >= ntiles) return;
+    f4v xr[2][SF / 4];                                    // unit q is staged from xr[q & 1] (q & 1 == rt & 1: LY_RT*S units per tile)
+    load_x(cur, xr[0]);
+    load_x(advance(cur, 1), xr[1]);
+    stage_x(0, xr[0]);
+    load_x(advance(cur, 2), xr[0]);
+    __syncthreads();
+
+    f4v hpub[UTW];                                        // h of the previous unit, published one unit late
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * LY_BM;
+        const int last = (int)min((int64_t)LY_BM, a.rows - row0) - 1;
+        for (int t = 0; t < S; ++t) {
+#pragma unroll
+            for (int rt = 0; rt < LY_RT; ++rt) {
+                const int slot = rt & 1;
+                // ---- the previous unit's leftovers (its rows are complete: the barrier that ended it has been passed)
+                if (rt > 0 || t > 0) {
+                    const int rp = (rt + LY_RT - 1) & (LY_RT - 1);
+                    const int r_ = rp * 16 + col;
+#pragma unroll
+                    for (int ut = 0; ut < UTW; ++ut) {   // fp16x2 planes of h·2^14 for the next step's MFMAs
+                        const int oc = (wave * UTW + ut) * 16 + 4 * grp;
+                        h4v p, q;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            _Float16 x, y;
+                            h2_split<1>(hpub[ut][j] * 16384.f, x, y);
+                            p[j] = x; q[j] = y;
+                        }
+                        *(h4v *)(&Hs[0][r_][oc]) = p;
+                        *(h4v *)(&Hs[1][r_][oc]) = q;
+                    }
+                    if (!REDUCE) {                       // LayerNorm(h_t) of the previous unit's 16 rows, 16 / NW rows per wave
+                        const int tp = rt > 0 ? t : t - 1;
+                        for (int r = rp * 16 + wave * (16 / NW); r < rp * 16 + (wave + 1) * (16 / NW); ++r)
+                            if (r <= last) gru_layernorm_row(hold[r], a.out + ((row0 + r) * S + tp) * GRU_H, lane, a.gamma, a.beta, a.eps);
+                    }
+                }
+                // ---- x of the next unit: registers -> planes; request the unit after the next two
+                {
+                    const Unit nx = advance(Unit{tile, t, rt}, 1);
+                    if (nx.tile < ntiles) stage_x(slot ^ 1, xr[(rt + 1) & 1]);
+                    load_x(advance(Unit{tile, t, rt}, 3), xr[(rt + 1) & 1]);
+                }
+                // ---- this unit: the wave's UTW x 16 hidden units (unit-tile-major measured fastest: 6.16 ms per 1M x 8 call, against
+                // 6.40 with the B operands of a chunk shared by both unit tiles and 6.84 with explicitly double-buffered operand
+                // sets — both cost VGPRs the allocator then takes back as scratch reloads inside the MFMA stream)
+                const int r_ = rt * 16 + col;
+                const float rs = xscale[slot][col];
+#pragma unroll
+                for (int ut = 0; ut < UTW; ++ut) {
+                    f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};
+                    // Issue order is pinned with sched_barriers (left alone, the scheduler sinks every ds_read to just before its
+                    // first use and waits with lgkmcnt(0): one exposed LDS latency per three MFMAs, and a single wave per SIMD has
+                    // nobody to cover it).  Per k chunk: the h planes and the LDS-resident weight fragments are requested before
+                    // the nine x MFMAs, the x planes of the NEXT chunk before the nine h MFMAs.
+                    auto body = [&](auto with_h_tag) {
+                        constexpr bool with_h = decltype(with_h_tag)::value;
+                        // (hoisting these first loads above the previous unit's publish / staging work, or above the previous unit
+                        // tile's gate math, was measured slower: 5.93 vs 5.43 ms — the extra live registers come back as spills)
+                        h8v xa1 = *(const h8v *)(&Xs[slot][0][col][8 * grp]);
+                        h8v xa2 = *(const h8v *)(&Xs[slot][1][col][8 * grp]);
+                        h8v wl[3];
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const int sl = ly_lds_slot<NW>(ut, 1, 0, g);
+                            if (sl >= 0) wl[g] = Wl[wave][sl < 0 ? 0 : sl][lane];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            h8v h1, h2;
+                            if (with_h) {
+                                h1 = *(const h8v *)(&Hs[0][r_][c * 32 + 8 * grp]);
+                                h2 = *(const h8v *)(&Hs[1][r_][c * 32 + 8 * grp]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            // = CTGCN_H2_MFMA(Wi[ut], c, x1, x2, acc0, acc1)
+#pragma unroll
+                            for (int g = 0; g < 3; ++g) acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wi[ut][0][c][g], xa2, acc1[g], 0, 0, 0);
+#pragma unroll
+                            for (int g = 0; g < 3; ++g)
+                                acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ly_lds_slot<NW>(ut, 1, c, g) >= 0 ? wl[g] : Wi[ut][1][c][g], xa1, acc1[g], 0, 0, 0);
+#pragma unroll
+                            for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wi[ut][0][c][g], xa1, acc0[g], 0, 0, 0);
+                            if (c < 3) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                xa1 = *(const h8v *)(&Xs[slot][0][col][(c + 1) * 32 + 8 * grp]);
+                                xa2 = *(const h8v *)(&Xs[slot][1][col][(c + 1) * 32 + 8 * grp]);
+#pragma unroll
+                                for (int g = 0; g < 3; ++g) {
+                                    const int sl = ly_lds_slot<NW>(ut, 1, c + 1, g);
+                                    if (sl >= 0) wl[g] = Wl[wave][sl < 0 ? 0 : sl][lane];
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#ifndef LY_ABL_NO_HH
+                            if (with_h) { CTGCN_H2_MFMA1(Wh[ut], c, h1, h2, ach) }
+#endif
+                        }
+                    };
+                    if (t > 0) body(std::true_type{}); else body(std::false_type{});
+                    const int oc = (wave * UTW + ut) * 16 + 4 * grp;
+                    f4v gi[3];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        gi[g] = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
+                    const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
+                    const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
+                    const f4v hprev = t > 0 ? *(const f4v *)(&hold[r_][oc]) : zero4;
+                    f4v h;
+#ifdef LY_ABL_NO_GATES
+                    h = gi[0] + gi[1] + gi[2] + ach[0] * csc[0] + ach[1] * csc[1] + ach[2] * csc[2] + b_hn + hprev;
+#else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], gi[0][j]));
+                        const float zv = gru_sigmoid(fmaf(ach[1][j], csc[1][j], gi[1][j]));
+                        const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
+                        const float nv = gru_tanh(fmaf(rv, an, gi[2][j]));
+                        h[j] = nv + zv * (hprev[j] - nv);
+                    }
+#endif
+                    *(f4v *)(&hold[r_][oc]) = h;
+                    if (REDUCE) {
+                        f4v *sp_ = (f4v *)(&hsum[r_][oc]);
+                        *sp_ = t > 0 ? *sp_ + h : h;
+                    }
+                    hpub[ut] = h;
+                }
+                __syncthreads();
+            }
+        }
+        // ---- end of the tile
+        if (REDUCE) {
+            for (int r = wave * (LY_BM / NW); r < (wave + 1) * (LY_BM / NW); ++r)
+                if (r <= last) gru_layernorm_row(hsum[r], a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
+        } else {
+            for (int r = (LY_RT - 1) * 16 + wave * (16 / NW); r < (LY_RT - 1) * 16 + (wave + 1) * (16 / NW); ++r)
+                if (r <= last) gru_layernorm_row(hold[r], a.out + ((row0 + r) * S + (S - 1)) * GRU_H, lane, a.gamma, a.beta, a.eps);
+        }
+        __syncthreads();       // hold / hsum rows are rewritten by the next tile's first units
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LSTM recurrence (rnn_type = 'LSTM', reference layers.py:27-28 / models.py:234-235), same fusion as the GRU:
 //   gates = GI_t + h_{t-1}·W_hhᵀ (order i,f,g,o; both biases are already in GI);  c_t = σ(f)·c_{t-1} + σ(i)·tanh(g);
 //   h_t = σ(o)·tanh(c_t);   out = LayerNorm(Σ_t h_t)  or  LayerNorm(h_t) per step.
@@ -2760,6 +3078,40 @@ int ctgcn_gru_fused_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
     a.scratch = (float *)(ws + frag_bytes + scale_bytes);
     hipLaunchKernelGGL(gru_presplit_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, w_ih, w_hh, b_hn, (h8v *)ws, (float *)(ws + frag_bytes));
     hipLaunchKernelGGL(gru_fused_h2_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
+                        const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
+                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, void *stream)
+{
+    if (hidden != GRU_H || d_in != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer: only d_in = hidden = %d is built (got %d, %d)", GRU_H, d_in, hidden);
+    if (rows < 0 || steps < 1 || ldx < d_in) return fail(CTGCN_E_INVALID, "gru_layer: bad sizes rows=%lld steps=%d ldx=%lld", (long long)rows, steps, (long long)ldx);
+    if (rows == 0) return CTGCN_OK;
+    if (!x || !w_ih || !w_hh || !out) return fail(CTGCN_E_INVALID, "gru_layer: null pointer");
+    if (!aligned16(x) || !aligned16(w_ih) || !aligned16(w_hh) || (ldx % 4) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
+        (ln_weight && (reinterpret_cast<uintptr_t>(ln_weight) & 7u)) || (ln_bias && (reinterpret_cast<uintptr_t>(ln_bias) & 7u)))
+        return fail(CTGCN_E_INVALID, "gru_layer: x / weights must be 16-byte aligned, ldx a multiple of 4, out / LayerNorm vectors 8-byte aligned");
+    const int64_t ldo = ld_out > 0 ? ld_out : GRU_H;
+    if (ld_out > 0 && (!reduce_sum || ld_out < GRU_H || (ld_out & 1)))
+        return fail(CTGCN_E_INVALID, "gru_layer: ld_out=%lld needs reduce_sum and an even value >= %d", (long long)ld_out, GRU_H);
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t ntiles = (rows + LY_BM - 1) / LY_BM;
+    const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 4-wave block per CU (one wave per SIMD, 512 registers)
+    LayerArgs a{};
+    a.rows = rows; a.steps = steps; a.x = x; a.ldx = ldx; a.wih = w_ih; a.whh = w_hh; a.bias_gi = bias_gi; a.bhn = b_hn;
+    a.gamma = ln_weight; a.beta = ln_bias; a.eps = ln_eps; a.out = out; a.ldo = ldo;
+    static const int nw = [] { const char *e = getenv("CTGCN_GRU_LAYER_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
+    if (nw == 8) {
+        if (reduce_sum) hipLaunchKernelGGL((gru_layer_h2_kernel<true, 8>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gru_layer_h2_kernel<false, 8>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    } else {
+        if (reduce_sum) hipLaunchKernelGGL((gru_layer_h2_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gru_layer_h2_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

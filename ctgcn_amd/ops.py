@@ -268,6 +268,17 @@ def fused_gru_enabled():
     return os.environ.get("CTGCN_GRU_FUSED", "0") == "1"
 
 
+def layer_kernel_enabled(reduce_sum=True):
+    """ctgcn_gru_layer_f32: input projection and recurrence of a GRU with d_in = hidden = 128 in one kernel, both weight matrices
+    resident in the register file, the projection consumed from the MFMA accumulators (never materialised).  Bit-identical to
+    the projection + recurrence kernel pair (tests/test_gpu_gru.py) at 1/7 of its HBM traffic.
+    CTGCN_GRU_LAYER = 1 (default): used where it is faster — the sum-over-steps form of CoreDiffusion (5.4 vs 6.4 ms per
+    1M x 8 call); the per-step form of the temporal GRU keeps the pair (15.7 vs 17 ms per 1M x 16 call).  all: both forms.  0: never."""
+    import os
+    mode = os.environ.get("CTGCN_GRU_LAYER", "1")
+    return mode == "all" or (mode != "0" and bool(reduce_sum))
+
+
 def forward_split_mode():
     """Arithmetic of the forward GRU products (include/ctgcn_hip.h CTGCN_SPLIT_*): 2 = fp16x2 (default: per-row scaled
     two-term fp16 split, three products — half the matrix work of bf16x3 and measured more accurate), 1 = bf16x3
@@ -347,6 +358,13 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
         with torch.cuda.device(seq.device), _timed("gru_fused", rows=rows, steps=steps):
             check(lib.ctgcn_gru_fused_f32(rows, steps, d_in, hid, ptr(seq), seq.stride(1), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn),
                                           ptr(ln_w), ptr(ln_b), eps, ptr(out), ldo, ptr(ws), ws_bytes, _stream()), "ctgcn_gru_fused_f32")
+        return out
+    if split == 2 and d_in == hid and layer_kernel_enabled(reduce_sum) and seq.stride(2) == 1 and seq.stride(1) % 4 == 0 \
+            and seq.stride(0) == steps * seq.stride(1) and seq.data_ptr() % 16 == 0 and w_ih.is_contiguous():
+        # projection + recurrence in one kernel, both weight matrices in the register file, gi never materialised
+        with torch.cuda.device(seq.device), _timed("gru_layer", rows=rows, steps=steps, reduce_sum=bool(reduce_sum)):
+            check(lib.ctgcn_gru_layer_f32(rows, steps, d_in, hid, ptr(seq), seq.stride(1), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn),
+                                          ptr(ln_w), ptr(ln_b), eps, 1 if reduce_sum else 0, ptr(out), ldo, _stream()), "ctgcn_gru_layer_f32")
         return out
     chunks = _row_chunks(lib, rows, steps, hid)
     gi_buf = _gi_buffer(chunks[0][1], steps, hid, seq.device)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 7
+#define CTGCN_ABI_VERSION 8
 
 enum {
     CTGCN_OK = 0,
@@ -210,6 +210,20 @@ int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float 
 int ctgcn_gru_fused_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
                         const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
                         float ln_eps, float *out, int64_t ld_out, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * layers.py:59-62 / models.py:249-250 in ONE kernel for d_in = hidden = 128 with both weight matrices resident in the register
+ * file of the CU (four waves, one per SIMD, 512 registers each): the input projection gi is consumed from the MFMA accumulators
+ * and never materialised - not in HBM, not in a workspace.  x [rows, steps, 128] with row-step stride ldx.
+ *   reduce_sum != 0: out[rows, ld_out] = LayerNorm(sum_t h_t) (ld_out as in ctgcn_gru_seq_f32, 0 = dense 128)
+ *   reduce_sum == 0: out[rows, steps, 128] = LayerNorm(h_t) per step (ld_out must be 0)
+ * ln_weight / ln_bias NULL: no LayerNorm.  bias_gi [384] = b_ih (+ b_hh for the r and z gates), b_hn [128] = bias_hh_l0[256:384];
+ * either may be NULL.  CTGCN_SPLIT_F16X2 arithmetic, operation for operation that of ctgcn_gru_input_proj_f32 followed by
+ * ctgcn_gru_seq_f32: results are bit-identical to the kernel pair.  HBM traffic: x in + out (the pair: 7x that).
+ */
+int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
+                        const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
+                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, void *stream);
 
 /*
  * Backward of the recurrence above (autograd of nn.GRU, layers.py:59 / models.py:249).  Inputs: the saved gates and

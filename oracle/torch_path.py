@@ -37,7 +37,7 @@ def _rnn(sd, prefix, rnn_type, seq):
     b_ih, b_hh = sd.get(prefix + "bias_ih_l0"), sd.get(prefix + "bias_hh_l0")
     hid = w_hh.shape[1]
     mod = (torch.nn.LSTM if rnn_type == "LSTM" else torch.nn.GRU)(w_ih.shape[1], hid, 1, bias=b_ih is not None,
-                                                                 batch_first=True)
+                                                                 batch_first=True).to(w_ih.dtype)   # float64 runs = exact truth
     with torch.no_grad():
         mod.weight_ih_l0.copy_(w_ih)
         mod.weight_hh_l0.copy_(w_hh)

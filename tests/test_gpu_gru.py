@@ -274,3 +274,33 @@ def test_fused_projection_recurrence_kernel_equals_the_kernel_pair(rows, steps, 
         ops.gru_sequence(rnn, x, norm, True, out=wide[:, 1])
     assert torch.equal(got, want)
     assert torch.equal(wide[:, 1], want) and not wide[:, 0].any() and not wide[:, 2].any()
+
+
+@pytest.mark.parametrize("rows,steps", [(1, 1), (63, 2), (64, 8), (1000, 5), (70001, 8), (40000, 16)])
+@pytest.mark.parametrize("reduce_sum", [True, False])
+def test_register_resident_layer_kernel_equals_the_kernel_pair(rows, steps, reduce_sum, monkeypatch):
+    """ctgcn_gru_layer_f32 (projection + recurrence in one kernel, both weight matrices in the register file, gi consumed from
+    the accumulators) performs the kernel pair's arithmetic operation for operation: bit-identical outputs, with and without
+    bias / LayerNorm, dense and strided outputs."""
+    from ctgcn_amd import ops
+    torch.manual_seed(rows + steps)
+    for bias, use_norm in ((True, True), (False, False)):
+        rnn = torch.nn.GRU(128, 128, 1, bias=bias, batch_first=True).to(DEV)
+        norm = torch.nn.LayerNorm(128).to(DEV) if use_norm else None
+        if norm is not None:
+            with torch.no_grad():
+                norm.weight.uniform_(0.5, 1.5)
+                norm.bias.uniform_(-0.5, 0.5)
+        x = torch.relu(torch.randn(rows, steps, 128, device=DEV)) * torch.rand(rows, 1, 1, device=DEV) * 3
+        with torch.no_grad():
+            monkeypatch.setenv("CTGCN_GRU_LAYER", "0")
+            want = ops.gru_sequence(rnn, x, norm, reduce_sum)
+            monkeypatch.setenv("CTGCN_GRU_LAYER", "all")
+            assert ops.layer_kernel_enabled(reduce_sum)
+            got = ops.gru_sequence(rnn, x, norm, reduce_sum)
+            assert torch.isfinite(got).all()
+            assert torch.equal(got, want), float((got - want).abs().max())
+            if reduce_sum:                                   # strided output view (column t of a [rows, T, 128] tensor)
+                buf = torch.zeros(rows, 3, 128, device=DEV)
+                ops.gru_sequence(rnn, x, norm, True, out=buf[:, 1])
+                assert torch.equal(buf[:, 1], want) and not buf[:, 0].any() and not buf[:, 2].any()

@@ -51,7 +51,9 @@ def test_bench_single_rank_sharded_path_matches_plain(tmp_path):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1",
                               "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
-        lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
+        json_lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(json_lines) == 1 and out.stdout.strip().splitlines()[-1] == json_lines[0], out.stdout[-500:]   # ONE line, and it is the last
+        lines.append(json.loads(json_lines[0]))
     a, b = lines
     assert a["config"]["aggregated_edges_per_step"] == b["config"]["aggregated_edges_per_step"]
     assert a["config"]["K_per_snapshot"] == b["config"]["K_per_snapshot"]

@@ -40,6 +40,13 @@ def main():
     total_ms = s.elapsed_time(e) / a.iters
     k_ms = sum(ss.elapsed_time(ee) for nm, ss, ee, _ in rec if nm == "gru_seq") / a.iters
     p_ms = sum(ss.elapsed_time(ee) for nm, ss, ee, _ in rec if nm == "gru_proj") / a.iters
+    l_ms = sum(ss.elapsed_time(ee) for nm, ss, ee, _ in rec if nm == "gru_layer") / a.iters
+    if l_ms > 0:
+        fl = a.rows * (2 * a.steps - 1) * 2.0 * 128 * 384
+        print("rows=%d steps=%d: ctgcn_gru_layer_f32 %.3f ms per call = %.1f TF/s fp32-equivalent (%.0f%% of the 833 TF/s fp16x2 bound), "
+              "x + out traffic %.0f GB/s" % (a.rows, a.steps, l_ms, fl / l_ms / 1e9, 100 * fl / l_ms / 1e9 / 833.3,
+                                             a.rows * (a.steps + (a.steps if a.full_seq else 1)) * 512.0 / l_ms / 1e6))
+        return
     fl_rec = a.rows * (a.steps - 1) * 2.0 * 128 * 384
     fl_in = a.rows * a.steps * 2.0 * a.din * 384
     print("rows=%d steps=%d din=%d: total %.3f ms | recurrent kernel %.3f ms = %.1f TF/s (%.0f%% of 157.3) | projection+rest %.3f ms = %.1f TF/s | split-proj kernel %.3f ms (%.0f GB/s)"

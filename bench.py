@@ -114,6 +114,9 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if os.environ.get("CTGCN_BENCH_WATCHDOG"):      # debugging aid: dump every thread's Python stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["CTGCN_BENCH_WATCHDOG"]), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     import torch

@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(_HERE, "csrc", f) for f in ("ctgcn_hip.hip", "ctgcn_ingest.hip", "ctgcn_walks.hip", "ctgcn_export.cpp")]
+SRCS = [os.path.join(_HERE, "csrc", f) for f in ("ctgcn_hip.hip", "ctgcn_gemm.hip", "ctgcn_ingest.hip", "ctgcn_walks.hip", "ctgcn_export.cpp")]
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctgcn_hip.h")
 OUT = os.path.join(_HERE, "csrc", "libctgcn_hip.so")
 

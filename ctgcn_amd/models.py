@@ -5,6 +5,8 @@ CTGCN additionally supports snapshot-parallel execution (one process per GPU, sn
 ranks, one all-gather of the per-snapshot hidden states right before the temporal RNN) — see
 ctgcn_amd/snapshot_parallel.py.  With no process group the behaviour is the reference's.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -117,6 +119,61 @@ class CTGCN(nn.Module):
         return any(p.requires_grad for p in self.parameters()) or any(
             isinstance(x, torch.Tensor) and x.requires_grad for x in x_list)
 
+    def _snapshot_streams(self, seq, n, T, x_list):
+        """HIP streams for the snapshot branches of an inference forward, or None.  CTGCN_STREAMS=k asks for k (1 = off); default:
+        4 streams for graphs up to 200 000 nodes (launches of tens of microseconds: tails and launch gaps overlap), none above
+        (config-5 kernels fill the chip and are HBM-bound: concurrency buys nothing there).
+        Only when every dense step of a branch runs in this library's own kernels (GRU width 128, one-hot or split-GEMM-able
+        inputs): library GEMMs may use stream-K / split-K kernels whose workgroups wait for each other through flags, and two of
+        those running concurrently can occupy every CU with waiting workgroups — measured: the facebook-like CTGCN-S window (its
+        1737-wide first Linear went to hipBLASLt) never finished on 4 streams."""
+        if seq is None or not seq.is_cuda or T < 2:
+            return None
+        env = os.environ.get("CTGCN_STREAMS")
+        k = int(env) if env else (4 if n <= 200_000 else 1)
+        k = min(k, T)
+        if k <= 1 or not self._branches_use_own_kernels(x_list):
+            return None
+        cache = getattr(self, "_stream_cache", None)
+        if cache is None or cache[0] != (seq.device, k):
+            cache = self._stream_cache = ((seq.device, k), [torch.cuda.Stream(device=seq.device) for _ in range(k)])
+        return cache[1]
+
+    def _branches_use_own_kernels(self, x_list):
+        from . import ops
+        key = (ops.forward_split_mode(), ops.linear_split_enabled()) + tuple(
+            (id(x), x.is_sparse, tuple(x.shape)) if torch.is_tensor(x) else None for x in x_list)
+        cache = getattr(self, "_own_kernel_cache", None)
+        if cache is None or cache[0] != key:
+            cache = self._own_kernel_cache = (key, self._branches_use_own_kernels_uncached(x_list))
+        return cache[1]
+
+    def _branches_use_own_kernels_uncached(self, x_list):
+        from . import ops
+        from .layers import _is_identity
+        if self.rnn_type != 'GRU' or self.output_dim != 128 or ops.forward_split_mode() != 2 or not ops.linear_split_enabled():
+            return False
+        for t, x in enumerate(x_list):
+            if not torch.is_tensor(x):
+                return False
+            mlp = self.mlp_list[t]
+            layers = [mlp.linear] if mlp.layer_num == 1 else list(mlp.linears)
+            if x.is_sparse:
+                if not _is_identity(x):
+                    return False                                # generic sparse features: torch.sparse.mm
+                layers = layers[1:]                             # Linear(I) = W^T + b: transpose kernel
+                width = mlp.output_dim if mlp.layer_num == 1 else mlp.hidden_dim
+            else:
+                width = x.shape[1]
+            for lin in layers:                                  # dense Linear layers must qualify for ctgcn_linear_f32
+                if width < 32 or lin.weight.dtype != torch.float32 or not lin.weight.is_cuda:
+                    return False
+                width = lin.weight.shape[0]
+            for cd in self.duffision_list[t].diffusion_list:    # CoreDiffusion GRU input width: 128 (resident-weight kernels) or split-GEMM-able
+                if cd.input_dim != 128 and cd.input_dim < 32:
+                    return False
+        return True
+
     def forward(self, x_list, adj_list):
         if self.process_group is not None:
             return sp_par.ctgcn_forward_sharded(self, x_list, adj_list)
@@ -129,11 +186,29 @@ class CTGCN(nn.Module):
             n = adj_list[0].n if hasattr(adj_list[0], "n") else adj_list[0][0].shape[0]
             p0 = next(self.parameters())
             seq = torch.empty(n, T, self.output_dim, dtype=p0.dtype, device=p0.device)
-        for t in range(T):
-            h, tr = self.snapshot_branch(t, x_list[t], adj_list[t], out=None if seq is None else seq[:, t])
-            if seq is not None and h.data_ptr() != seq[:, t].data_ptr():
-                seq[:, t].copy_(h)           # a layer that could not write in place (other rnn type/width) returned its own tensor
-            hx.append(h)
-            trans.append(tr)
+        lanes = self._snapshot_streams(seq, n if seq is not None else 0, T, x_list)
+        if lanes:
+            # inference on a small graph: the snapshot branches are independent until the temporal GRU (models.py:243-247) and their
+            # kernels are too short to fill the chip one after the other — run them on a few HIP streams, join before the head
+            main = torch.cuda.current_stream(seq.device)
+            for s_ in lanes:
+                s_.wait_stream(main)
+            for t in range(T):
+                with torch.cuda.stream(lanes[t % len(lanes)]):
+                    h, tr = self.snapshot_branch(t, x_list[t], adj_list[t], out=seq[:, t])
+                    if h.data_ptr() != seq[:, t].data_ptr():
+                        seq[:, t].copy_(h)
+                    tr.record_stream(main)                 # returned to the caller ('S'), who uses it on the main stream
+                hx.append(h)
+                trans.append(tr)
+            for s_ in lanes:
+                main.wait_stream(s_)
+        else:
+            for t in range(T):
+                h, tr = self.snapshot_branch(t, x_list[t], adj_list[t], out=None if seq is None else seq[:, t])
+                if seq is not None and h.data_ptr() != seq[:, t].data_ptr():
+                    seq[:, t].copy_(h)           # a layer that could not write in place (other rnn type/width) returned its own tensor
+                hx.append(h)
+                trans.append(tr)
         out = self.temporal_head(seq if seq is not None else torch.stack(hx).transpose(0, 1))
         return out if self.model_type == 'C' else (out, trans)

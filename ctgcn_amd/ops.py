@@ -289,6 +289,46 @@ def forward_split_mode():
     return 1 if os.environ.get("CTGCN_GRU_SPLIT", "f16x2") == "bf16x3" else 2
 
 
+_LINEAR_WS_MAX = 2 << 30       # bytes of fp16 planes per ctgcn_linear_f32 call (rows are chunked above that)
+
+
+def linear_split_enabled():
+    """CTGCN_LINEAR_SPLIT=0 (or CTGCN_FP32_MFMA_ONLY=1) selects the fp32 library GEMM instead of ctgcn_linear_f32."""
+    import os
+    return forward_split_mode() == 2 and os.environ.get("CTGCN_LINEAR_SPLIT", "1") != "0"
+
+
+def linear_split_ok(x2d, weight):
+    """ctgcn_linear_f32 covers fp32 CUDA operands with unit column stride and k >= 32 (any k and row stride: rows that are not
+    16-byte aligned are read with scalar loads)."""
+    return (linear_split_enabled() and x2d.is_cuda and x2d.dtype == torch.float32 and weight.dtype == torch.float32 and x2d.dim() == 2
+            and x2d.stride(1) == 1 and weight.stride(1) == 1 and x2d.data_ptr() % 4 == 0 and weight.data_ptr() % 4 == 0
+            and x2d.shape[0] > 0 and x2d.shape[1] >= 32 and x2d.stride(0) >= x2d.shape[1] and weight.stride(0) >= weight.shape[1])
+
+
+def linear_split(x2d, weight, bias, out=None):
+    """out[rows, n_out] = x2d @ weight^T + bias in fp32-accurate fp16x2 split arithmetic on the matrix cores (ctgcn_linear_f32)."""
+    lib = _lib.load()
+    rows, k = x2d.shape
+    n_out = weight.shape[0]
+    if out is None:
+        out = torch.empty(rows, n_out, dtype=torch.float32, device=x2d.device)
+    kp = -(-k // 32) * 32
+    chunk = max(128, (_LINEAR_WS_MAX // (kp * 4 + 4)) // 128 * 128)
+    b = None if bias is None else bias.detach().contiguous()
+    w = weight.detach()
+    with torch.cuda.device(x2d.device):
+        ws_bytes = int(lib.ctgcn_linear_workspace_bytes(min(rows, chunk), n_out, k))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2d.device)
+        for lo in range(0, rows, chunk):
+            n = min(chunk, rows - lo)
+            xs, ys = x2d[lo:lo + n], out[lo:lo + n]
+            with _timed("linear_split", rows=n, k=k, n_out=n_out):
+                check(lib.ctgcn_linear_f32(n, n_out, k, ptr(xs), xs.stride(0), ptr(w), w.stride(0), ptr(b), ptr(ys), ys.stride(0), ptr(ws), ws_bytes,
+                                           _stream()), "ctgcn_linear_f32")
+    return out
+
+
 def _project(x2d, w_ih, bias, out, steps_blocked=0):
     """out = x2d @ w_ih^T + bias — the GRU input projection.  Returns True when `out` was written in the recurrence
     kernel's blocked tile layout (only asked for with steps_blocked > 0, only done by the fp16x2 kernel), else [rows, 3h]."""
@@ -302,6 +342,9 @@ def _project(x2d, w_ih, bias, out, steps_blocked=0):
                                                mode, blocked, _stream()), "ctgcn_gru_input_proj_f32")
         return blocked > 0
     out = out[: x2d.shape[0] * w_ih.shape[0]].view(x2d.shape[0], w_ih.shape[0])
+    if linear_split_ok(x2d, w_ih):
+        linear_split(x2d, w_ih, bias, out=out)
+        return False
     if bias is None:
         torch.mm(x2d, w_ih.t(), out=out)
     else:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 8
+#define CTGCN_ABI_VERSION 9
 
 enum {
     CTGCN_OK = 0,
@@ -224,6 +224,18 @@ int ctgcn_gru_fused_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
 int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
                         const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
                         float ln_eps, int reduce_sum, float *out, int64_t ld_out, void *stream);
+
+/*
+ * Dense  y[rows, n_out] = x[rows, k]·w[n_out, k]^T + bias  (bias [n_out] may be NULL) in fp32-accurate fp16x2 split arithmetic on the
+ * matrix cores (CTGCN_SPLIT_F16X2: operand rows scaled by a power of two and written as two fp16 terms, three
+ * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation) - the GRU input projection for d_in != 128 (layers.py:59 with
+ * input_size = hid_dim = 500) and nn.Linear on dense inputs (layers.py:95-106), which otherwise run as fp32 library GEMMs.
+ * ldx / ldw / ldy: row strides in floats.  Any k >= 1 (rows that are not 16-byte aligned or k % 4 != 0 are read with scalar loads).
+ * workspace: ctgcn_linear_workspace_bytes(rows, n_out, k) bytes, 256-byte aligned (the fp16 planes + row scales of x and w).
+ */
+size_t ctgcn_linear_workspace_bytes(int64_t rows, int32_t n_out, int32_t k);
+int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
+                     float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Backward of the recurrence above (autograd of nn.GRU, layers.py:59 / models.py:249).  Inputs: the saved gates and

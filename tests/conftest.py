@@ -114,3 +114,13 @@ def check_sampled_tensor(g, key, got, rtol, atol_scale):
     # checksums: the sum of N entries each within the tolerance above
     assert abs(np.abs(got).sum() - abssum) <= 10 * rtol * abssum + 1e-12, (key, "abssum", np.abs(got).sum(), abssum)
     assert abs(got.sum() - float(g[key + "__sum"])) <= 10 * rtol * abssum + 1e-12, (key, "sum")
+
+
+def check_close(got, want, rtol, atol, what=""):
+    """assert_allclose that also REPORTS how much of the tolerance was used (run with -s): tolerances in the GPU tests are
+    set to about ten times the worst observed use, not to whatever passes."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    err = np.abs(got - want)
+    used = float((err / (atol + rtol * np.abs(want))).max(initial=0.0))
+    print("  [tol] %-46s max |err| %.3e  = %.3f of (rtol %g, atol %g)" % (what, float(err.max(initial=0.0)), used, rtol, atol))
+    assert used <= 1.0, "%s: max |err| %.3e is %.2f x the tolerance (rtol %g, atol %g)" % (what, err.max(), used, rtol, atol)

@@ -4,12 +4,13 @@ oracle (oracle/torch_path.py: the reference's torch.sparse path, pinned to refer
 on the FULL output, plus the loader-level integers (K per snapshot, core numbers) bit for bit.
 
 Tolerance.  SURVEY.md §8c gives rtol 1e-4 / atol 1e-5 after GRU + LayerNorm, probed on UCI (1 899 nodes, degree <= 198).  At
-these sizes (10^8 output values, hub rows that sum hundreds of 500-wide terms, three stacked recurrences) the fp32 CPU path
-ITSELF is further than that from the exact result on a handful of entries, so the check has two parts:
-  (a) the HIP output is within rtol 1e-4 / atol 1e-5 of the fp32 CPU oracle on all but a 1e-5 fraction of the entries, and
-      nowhere further than 2e-4;
-  (b) against the SAME oracle evaluated in float64, the HIP path's worst error is no larger than twice the fp32 CPU path's
-      worst error (+ 2e-6): it is as close to the reference's mathematics as the reference's own fp32 arithmetic is.
+these sizes (10^8 output values, hub rows that sum hundreds of 500-wide terms, degree features of magnitude 10^2-10^3 through
+three SELU layers, three stacked recurrences) the fp32 CPU path ITSELF is further than that from the exact result on a small
+fraction of the entries (facebook shape: 3.7e-4 worst).  The oracle is therefore also evaluated in float64 and the HIP path is
+held to the fp32 reference path's OWN distance from that exact result:
+  (a) the fraction of entries outside rtol 1e-4 / atol 1e-5 of the float64 result is at most twice the fp32 CPU path's
+      fraction (+ 1e-6), and against the fp32 oracle itself the HIP output is nowhere further than 5e-4;
+  (b) the worst HIP error against float64 is at most twice the fp32 CPU path's worst error (+ 2e-6).
 Observed errors are printed per case."""
 import time
 
@@ -97,9 +98,11 @@ def test_baseline_config_shapes_match_cpu_oracle(case):
     want, want64 = want.numpy(), want64.numpy()
     assert got.shape == want.shape == (c["T"], c["n"], 128)
     err = np.abs(got - want)
-    bad = err > 1e-4 * np.abs(want) + 1e-5
+    tol64 = 1e-4 * np.abs(want64) + 1e-5
+    bad_hip, bad_cpu = (np.abs(got - want64) > tol64).mean(), (np.abs(want - want64) > tol64).mean()
     err_hip64, err_cpu64 = np.abs(got - want64).max(), np.abs(want - want64).max()
-    print("%s: vs fp32 oracle max |err| %.3e mean %.3e, %d / %d outside rtol 1e-4 atol 1e-5; vs fp64 oracle: HIP %.3e, fp32 CPU path %.3e "
-          "(oracle fp32 %.0fs, fp64 %.0fs)" % (case, err.max(), err.mean(), bad.sum(), bad.size, err_hip64, err_cpu64, t1 - t0, time.time() - t1))
-    assert bad.mean() <= 1e-5 and err.max() <= 2e-4
+    print("%s: vs fp32 oracle max |err| %.3e mean %.3e; vs fp64 oracle: max HIP %.3e / fp32 CPU path %.3e, fraction outside rtol 1e-4 atol 1e-5 "
+          "HIP %.2e / fp32 CPU path %.2e (oracle fp32 %.0fs, fp64 %.0fs)" % (case, err.max(), err.mean(), err_hip64, err_cpu64, bad_hip, bad_cpu,
+                                                                        t1 - t0, time.time() - t1))
+    assert bad_hip <= 2 * bad_cpu + 1e-6 and err.max() <= 5e-4
     assert err_hip64 <= 2 * err_cpu64 + 2e-6

@@ -1,0 +1,64 @@
+"""ctgcn_linear_f32 (fp16x2 split GEMM on the matrix cores) against float64: the GRU input projection at d_in = 500 and the
+dense nn.Linear layers of the MLP run through it.  Bar: never less accurate than the fp32 library GEMM it replaces."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("rows,k,n_out,bias", [
+    (1, 32, 1, True), (127, 36, 5, False), (1000, 500, 384, True), (4097, 500, 128, True), (300, 1740, 500, True),
+    (129, 128, 129, False), (60_730, 500, 500, True), (5000, 1737, 500, True), (333, 61, 7, False),
+])
+def test_split_gemm_is_fp32_accurate(rows, k, n_out, bias):
+    from ctgcn_amd import ops
+    torch.manual_seed(rows + k)
+    x = torch.randn(rows, k, device=DEV) * torch.rand(rows, 1, device=DEV).mul(6).exp()       # row magnitudes over e^6
+    w = torch.randn(n_out, k, device=DEV) / k ** 0.5
+    b = torch.randn(n_out, device=DEV) if bias else None
+    assert ops.linear_split_ok(x, w)
+    got = ops.linear_split(x, w, b)
+    ref = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    lib32 = torch.addmm(b, x, w.t()) if bias else x @ w.t()
+    scale = (x.double().abs() @ w.double().abs().t()) + 1e-30                   # sum |x_k w_k|: the natural error scale of a dot product
+    err_split = ((got.double() - ref).abs() / scale).max().item()
+    err_lib = ((lib32.double() - ref).abs() / scale).max().item()
+    print("rows=%d k=%d n=%d: max err / sum|xw|  split %.2e  fp32 library %.2e" % (rows, k, n_out, err_split, err_lib))
+    assert err_split <= max(2 * err_lib, 2e-7), (err_split, err_lib)
+
+
+def test_split_gemm_strided_views_and_special_rows():
+    from ctgcn_amd import ops
+    torch.manual_seed(3)
+    big = torch.randn(500, 3, 512, device=DEV)
+    x = big[:, 1, :500]                                   # row stride 1536, 500 columns
+    x[7] = 0.0                                            # all-zero row
+    x[8] *= 1e30
+    x[9] *= 1e-30
+    w = torch.randn(384, 512, device=DEV)[:, :500]
+    out = torch.full((500, 400), 7.0, device=DEV)
+    assert ops.linear_split_ok(x, w)
+    ops.linear_split(x, w, None, out=out[:, :384])
+    ref = x.double() @ w.double().t()
+    scale = (x.double().abs() @ w.double().abs().t()) + 1e-300
+    assert torch.isfinite(out).all() and bool((out[:, 384:] == 7.0).all()) and bool((out[7, :384] == 0).all())
+    assert ((out[:, :384].double() - ref).abs() / scale).max().item() <= 4e-7
+
+
+def test_gru_with_wide_input_uses_the_split_gemm_and_matches_torch():
+    """nn.GRU(500 -> 128): the shape of the first CoreDiffusion layer of every shipped config (hid_dim 500)."""
+    from ctgcn_amd import ops
+    torch.manual_seed(5)
+    rnn = torch.nn.GRU(500, 128, 1, batch_first=True)
+    norm = torch.nn.LayerNorm(128)
+    x = torch.relu(torch.randn(3000, 5, 500))
+    with torch.no_grad():
+        want = norm(rnn(x)[0].sum(1))
+        seen = []
+        ops.set_launch_timer(lambda name, s, e, meta: seen.append(name))
+        got = ops.gru_sequence(rnn.to(DEV), x.to(DEV), norm.to(DEV), True)
+        ops.set_launch_timer(None)
+    assert "linear_split" in seen and "gru_seq" in seen
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)

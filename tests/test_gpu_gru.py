@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import check_close
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -35,7 +37,7 @@ def test_fused_gru_matches_torch(rows, steps, d_in, reduce_sum, bias, use_norm, 
     with torch.no_grad():
         assert ops.gru_fused_ok(rnn_d, x.to(DEV))
         got = ops.gru_sequence(rnn_d, x.to(DEV), norm_d, reduce_sum)
-    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    check_close(got.cpu().numpy(), want.numpy(), 1e-4, 1e-5, what="fused GRU vs torch")
 
 
 def test_fused_gru_row_chunking_and_determinism():
@@ -84,13 +86,14 @@ def test_fused_gru_gradients_match_torch_autograd(rows, steps, d_in, reduce_sum,
         p.grad = None
     xd = x.detach().to(DEV).requires_grad_(True)
     got = ops.gru_sequence(rnn_d, xd, norm_d, reduce_sum)
-    np.testing.assert_allclose(got.detach().cpu().numpy(), out.detach().numpy(), rtol=1e-4, atol=2e-5)
+    check_close(got.detach().cpu().numpy(), out.detach().numpy(), 1e-4, 1e-5, what="fused GRU (training forward) vs torch")
     (got * G.to(DEV)).sum().backward()
 
     def close(a, b, name):
         a, b = a.cpu().numpy(), b.numpy()
         scale = max(1e-6, float(np.abs(b).max()))
-        assert np.abs(a - b).max() <= 2e-4 * scale, (name, np.abs(a - b).max(), scale)
+        print("  [tol] grad %-24s |err| / max|grad| %.3e (limit 1e-5)" % (name, np.abs(a - b).max() / scale))
+        assert np.abs(a - b).max() <= 1e-5 * scale, (name, np.abs(a - b).max(), scale)      # observed worst 5.5e-7
 
     close(xd.grad, x.grad, "dx")
     for (name, pd), (_, pc) in zip(rnn_d.named_parameters(), rnn.named_parameters()):
@@ -169,10 +172,10 @@ def test_fused_lstm_matches_torch(rows, steps, d_in, reduce_sum, bias):
     with torch.no_grad():
         assert ops.lstm_fused_ok(rnn_d, x.to(DEV))
         got = layers.rnn_reduce_norm(rnn_d, norm_d, x.to(DEV), reduce_sum)
-    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    check_close(got.cpu().numpy(), want.numpy(), 1e-4, 1e-5, what="fused GRU vs torch")
     # with gradients enabled the framework LSTM runs (and agrees)
     got_train = layers.rnn_reduce_norm(rnn_d, norm_d, x.to(DEV).requires_grad_(True), reduce_sum)
-    np.testing.assert_allclose(got_train.detach().cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    check_close(got_train.detach().cpu().numpy(), want.numpy(), 1e-4, 1e-5, what="fused LSTM (training path) vs torch")
 
 
 def test_split_bf16_projection_wide_dynamic_range(split_mode):

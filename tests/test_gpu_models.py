@@ -7,11 +7,11 @@ import pytest
 import scipy.sparse as sp
 import torch
 
-from conftest import load_golden, csr_from, formula_tensor
+from conftest import load_golden, csr_from, formula_tensor, check_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = dict(rtol=1e-4, atol=2e-5)          # after GRU + LayerNorm (MIOpen vs ATen-CPU accumulation order)
+TOL = dict(rtol=1e-4, atol=1e-5)          # after GRU + LayerNorm
 
 
 def _write_uci(tmp_path):
@@ -80,12 +80,16 @@ def _load(model, g, tag):
     return model.to(DEV)
 
 
-def _check_grads(model, g, tag, rtol=2e-3):
+def _check_grads(model, g, tag, rtol=1e-4):
+    """every parameter gradient within rtol of its tensor's largest entry (observed worst: 8.3e-6, printed with -s)"""
+    worst = 0.0
     for name, p in model.named_parameters():
         want = g[tag + "grad_" + name]
         got = np.zeros_like(want) if p.grad is None else p.grad.cpu().numpy()
         scale = max(1e-6, float(np.abs(want).max()))
+        worst = max(worst, float(np.abs(got - want).max()) / scale)
         assert np.abs(got - want).max() <= rtol * scale, (name, np.abs(got - want).max(), scale)
+    print("  [tol] %-46s worst |err| / max|grad| %.3e (limit %g)" % (tag + "grads", worst, rtol))
 
 
 def test_ctgcn_and_cgcn_match_reference_outputs_and_grads():
@@ -102,37 +106,37 @@ def test_ctgcn_and_cgcn_match_reference_outputs_and_grads():
 
     m = _load(ctgcn_amd.CTGCN(n, 16, 8, 1, 2, T), g, "ctgcn_c_")
     out = m(eye, adj)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["ctgcn_c_out"], **TOL)
+    check_close(out.detach().cpu().numpy(), g["ctgcn_c_out"], what='g["ctgcn_c_out"]', **TOL)
     (out * gsel(8)).sum().backward()
     _check_grads(m, g, "ctgcn_c_")
 
     m = _load(ctgcn_amd.CTGCN(24, 16, 8, 3, 1, T, model_type="S", trans_activate_type="N"), g, "ctgcn_s_")
     out, trans = m(xd, adj)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["ctgcn_s_out"], **TOL)
-    np.testing.assert_allclose(torch.stack(trans).detach().cpu().numpy(), g["ctgcn_s_trans"], **TOL)
+    check_close(out.detach().cpu().numpy(), g["ctgcn_s_out"], what='g["ctgcn_s_out"]', **TOL)
+    check_close(torch.stack(trans).detach().cpu().numpy(), g["ctgcn_s_trans"], what='g["ctgcn_s_trans"]', **TOL)
     (out * gsel(8)).sum().backward()
     _check_grads(m, g, "ctgcn_s_")
 
     m = _load(ctgcn_amd.CTGCN(24, 16, 8, 1, 2, T, rnn_type="LSTM"), g, "ctgcn_c_lstm_")
     out = m(xd, adj)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["ctgcn_c_lstm_out"], **TOL)
+    check_close(out.detach().cpu().numpy(), g["ctgcn_c_lstm_out"], what='g["ctgcn_c_lstm_out"]', **TOL)
     (out * gsel(8)).sum().backward()
     _check_grads(m, g, "ctgcn_c_lstm_")
 
     m = _load(ctgcn_amd.CGCN(24, 16, 8, 1, 2), g, "cgcn_c_")
     out = torch.stack(m(xd, adj))
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["cgcn_c_out"], **TOL)
+    check_close(out.detach().cpu().numpy(), g["cgcn_c_out"], what='g["cgcn_c_out"]', **TOL)
     (out * gsel(8)).sum().backward()
     _check_grads(m, g, "cgcn_c_")
 
     m = _load(ctgcn_amd.CGCN(24, 16, 8, 3, 1, model_type="S", trans_activate_type="N"), g, "cgcn_s_")
     emb, st = m(xd, adj)
-    np.testing.assert_allclose(torch.stack(emb).detach().cpu().numpy(), g["cgcn_s_out"], **TOL)
-    np.testing.assert_allclose(torch.stack(st).detach().cpu().numpy(), g["cgcn_s_trans"], **TOL)
+    check_close(torch.stack(emb).detach().cpu().numpy(), g["cgcn_s_out"], what='g["cgcn_s_out"]', **TOL)
+    check_close(torch.stack(st).detach().cpu().numpy(), g["cgcn_s_trans"], what='g["cgcn_s_trans"]', **TOL)
 
     m = _load(ctgcn_amd.CGCN(24, 16, 8, 2, 3, trans_activate_type="N"), g, "cgcn_c_single_")
     out = m(xd[0], adj[0])
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["cgcn_c_single_out"], **TOL)
+    check_close(out.detach().cpu().numpy(), g["cgcn_c_single_out"], what='g["cgcn_c_single_out"]', **TOL)
 
 
 def test_models_accept_the_reference_loaders_tensor_lists():
@@ -147,7 +151,7 @@ def test_models_accept_the_reference_loaders_tensor_lists():
     xd = [torch.from_numpy(a).to(DEV) for a in formula_tensor((T, n, 24), 0.11, 0.3)]
     m = _load(ctgcn_amd.CGCN(24, 16, 8, 1, 2), g, "cgcn_c_")
     out = torch.stack(m(xd, lists))
-    np.testing.assert_allclose(out.detach().cpu().numpy(), g["cgcn_c_out"], **TOL)
+    check_close(out.detach().cpu().numpy(), g["cgcn_c_out"], what='g["cgcn_c_out"]', **TOL)
 
 
 def test_core_diffusion_layer_golden():
@@ -162,9 +166,9 @@ def test_core_diffusion_layer_golden():
         layer.load_state_dict({k[len(p + "cd_sd_"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(p + "cd_sd_")})
         layer.to(DEV)
         out = layer(x, adj)
-        np.testing.assert_allclose(out.detach().cpu().numpy(), g[p + "cd_out"], **TOL)
+        check_close(out.detach().cpu().numpy(), g[p + "cd_out"], what='g[p + "cd_out"]', **TOL)
         (out * torch.from_numpy(g[p + "cd_gout"]).to(DEV)).sum().backward()
-        np.testing.assert_allclose(x.grad.cpu().numpy(), g[p + "cd_dx"], rtol=1e-3, atol=5e-5)
+        check_close(x.grad.cpu().numpy(), g[p + "cd_dx"], 1e-4, 1e-5 * float(np.abs(g[p + "cd_dx"]).max()), what=p + "cd_dx")
 
 
 # ---------------------------------------------------------------- full-size, size-independent properties
@@ -227,20 +231,22 @@ def test_ctgcn_width_128_fused_path_matches_cpu_oracle():
         out_inf = model([v.to(DEV) for v in x], adj)
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     ref = TP.ctgcn_with_grad(sd, x, ref_adj)
-    np.testing.assert_allclose(out_inf.cpu().numpy(), ref.detach().numpy(), **TOL)
+    check_close(out_inf.cpu().numpy(), ref.detach().numpy(), what='ref.detach().numpy()', **TOL)
     (ref * gsel).sum().backward()
     out = model([v.to(DEV) for v in x], adj)
     assert torch.equal(out.detach(), out_inf)
     (out * gsel.to(DEV)).sum().backward()
-    checked = 0
+    checked, worst = 0, 0.0
     for name, p in model.named_parameters():
         want = sd[name].grad
         if want is None:
             continue
         scale = max(1e-6, float(want.abs().max()))
         err = float((p.grad.cpu() - want).abs().max())
-        assert err <= 3e-3 * scale, (name, err, scale)
+        worst = max(worst, err / scale)
+        assert err <= 6e-5 * scale, (name, err, scale)        # observed worst 5.3e-6
         checked += 1
+    print("  [tol] width-128 fused path gradients: worst |err| / max|grad| %.3e (limit 6e-5)" % worst)
     assert checked >= 30
 
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""ctgcn_linear_f32 (fp16x2 split GEMM) vs the fp32 library GEMM on the shapes the models produce.
+  python tools/gemm_bench.py [--iters 10]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ctgcn_amd import ops  # noqa: E402
+
+SHAPES = [(435_180, 500, 384, "Enron layer-0 GRU projection (87 036 x 5 rows)"), (60_730, 1737, 500, "Facebook-S MLP layer 0"),
+          (60_730, 500, 500, "MLP layer 1"), (60_730, 500, 128, "MLP layer 2"), (197_920, 500, 384, "math layer-0 projection (24 740 x 8)")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    for rows, k, n, what in SHAPES:
+        x = torch.randn(rows, k, device=dev)
+        w = torch.randn(n, k, device=dev) / k ** 0.5
+        b = torch.randn(n, device=dev)
+        out = torch.empty(rows, n, device=dev)
+
+        def timeit(fn):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(a.iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            return s.elapsed_time(e) / a.iters
+
+        t_split = timeit(lambda: ops.linear_split(x, w, b, out=out))
+        t_lib = timeit(lambda: torch.addmm(b, x, w.t(), out=out))
+        fl = 2.0 * rows * k * n
+        print("%-52s rows=%d k=%d n=%d: split %.3f ms (%.0f TF/s fp32-equivalent) | fp32 library %.3f ms (%.0f TF/s)"
+              % (what, rows, k, n, t_split, fl / t_split / 1e9, t_lib, fl / t_lib / 1e9))
+
+
+if __name__ == "__main__":
+    main()

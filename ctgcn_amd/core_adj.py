@@ -237,6 +237,68 @@ class CoreAdj(object):
                       nnz_per_slot)
         return adj.to(device)
 
+    # ------------------------------------------------------------------ builder 1b: device, from NESTED k-core matrices
+    @staticmethod
+    def from_nested_matrices_device(mats, device, self_loop=True):
+        """The .npz loader route at scale: `mats` = the kept k-core matrices of one snapshot in list order (scipy sparse,
+        smallest first: A_kmax ⊆ ... ⊆ A_1, zero diagonal, as helper.py:63-78 visits them; slot 0 gets + I through the
+        SELF_LOOP flag).  The K coordinate lists are uploaded once and tagged on the GPU: an entry's slot is K minus the number
+        of matrices that contain it (one sort + run-length count), then one more sort puts rows in (slot, col) order — instead
+        of from_matrices' host lexsort over all K·nnz entries.  Returns None when the list turns out not to be nested (or the
+        values differ between matrices): the caller then uses the general host builder."""
+        import scipy.sparse as sp
+        K = len(mats)
+        if K == 0 or K > _lib.MAX_SLOTS:
+            return None
+        n = mats[0].shape[0]
+        dev = torch.device(device)
+        keys, vals, nnz_per_slot = [], [], []
+        for m in mats:
+            m = sp.coo_matrix(m)
+            if m.shape != (n, n):
+                raise ValueError("adjacency matrices must all be %d x %d" % (n, n))
+            keys.append(torch.from_numpy(m.row.astype(np.int64) * n + m.col.astype(np.int64)))
+            vals.append(torch.from_numpy(m.data.astype(np.float32)))
+            nnz_per_slot.append(int(m.nnz))
+        if self_loop:
+            nnz_per_slot[0] += n
+        key_all = torch.cat(keys).to(dev)
+        val_all = torch.cat(vals).to(dev)
+        uniq, inverse, counts = torch.unique(key_all, sorted=True, return_inverse=True, return_counts=True)
+        if uniq.numel() != mats[-1].nnz or uniq.numel() >= 2 ** 31:
+            return None                                   # an entry outside the largest matrix (or duplicates inside one): not nested
+        # one value per entry: every copy must equal the copy in the largest matrix
+        last_lo = key_all.numel() - mats[-1].nnz
+        val_of = torch.empty(uniq.numel(), dtype=torch.float32, device=dev)
+        val_of[inverse[last_lo:]] = val_all[last_lo:]
+        if not bool((val_of[inverse] == val_all).all()):
+            return None
+        rows = torch.div(uniq, n, rounding_mode="floor")
+        cols = uniq - rows * n
+        if bool((rows == cols).any()):
+            return None                                   # a stored diagonal: the + I fold below would be wrong
+        slot = (K - counts).to(torch.int64)               # nested: present in matrices slot .. K-1
+        # nestedness proper: the copies of an entry must sit in the LAST `count` matrices
+        mat_of = torch.repeat_interleave(torch.arange(K, device=dev), torch.tensor([k.numel() for k in keys], device=dev))
+        if not bool((mat_of >= slot[inverse]).all()):
+            return None
+        order = torch.argsort((rows * K + slot) * n + cols)
+        rows, cols, slot, val_of = rows[order], cols[order], slot[order], val_of[order]
+        row_ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        row_ptr[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+        # symmetric in structure, value and tag?  (always for the reference's k-core files)  key of the transposed entry
+        tkey = cols * n + rows
+        pos = torch.searchsorted(uniq, tkey)
+        pos_ok = pos < uniq.numel()
+        symmetric = bool(pos_ok.all()) and bool((uniq[pos.clamp(max=uniq.numel() - 1)] == tkey).all())
+        if symmetric:
+            inv_order = torch.empty_like(order)
+            inv_order[order] = torch.arange(order.numel(), device=dev)
+            mate = inv_order[pos]                         # position (in the final order) of the transposed entry
+            symmetric = bool((val_of[mate] == val_of).all()) and bool((slot[mate] == slot).all())
+        return CoreAdj(n, K, row_ptr.to(torch.int32), cols.to(torch.int32).contiguous(), val_of.contiguous(),
+                       slot.to(torch.uint8).contiguous(), bool(self_loop), True, symmetric, nnz_per_slot)
+
     # ------------------------------------------------------------------ builder 2: device, from the snapshot graph
     @staticmethod
     def from_graph(row_ptr, col, val, max_core=-1, core=None):

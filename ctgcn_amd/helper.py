@@ -60,7 +60,8 @@ class DataLoader(object):
             if not kept:
                 window.append([])       # snapshot without edges: the reference also yields an empty list
                 continue
-            window.append(CoreAdj.from_matrices(kept, self_loop=True, device=self.device))
+            adj = CoreAdj.from_nested_matrices_device(kept, self.device, self_loop=True) if self.has_cuda else None
+            window.append(adj if adj is not None else CoreAdj.from_matrices(kept, self_loop=True, device=self.device))
         return window
 
     # -------------------------------------------------------------------------- native route

@@ -378,3 +378,60 @@ def test_core_adj_device_copies_are_cached():
     fake = adj._copy_to(torch.device("cpu"))
     adj._moved["meta"] = fake                              # what .to() stores after the first move to another device
     assert adj.to("meta") is fake
+
+
+def test_columnar_edge_reader_equals_the_line_loop(tmp_path):
+    """utils.read_edge_rows (Arrow CSV + hash join) returns exactly what the per-line loop returns — order, duplicates, self
+    loops, float weights in every notation Python's float() accepts in these files, 2-column files — and raises KeyError for a
+    name that is not in the node list, as the reference's dict lookup does (utils.py:52-53)."""
+    from ctgcn_amd.utils import read_edge_rows, _read_edge_rows_loop
+    rng = np.random.default_rng(4)
+    names = ["N%d" % i for i in range(300)] + ["17", "0042", "a b"]
+    node2idx = dict(zip(names, range(len(names))))
+    rows = rng.integers(0, len(names), size=(5000, 2))
+    weights = ["1", "2.5", "1e-3", "3.0000000000000004", "7E2", "-0.125", "12345678.875", "0.1"]
+    path = tmp_path / "g.csv"
+    with open(path, "w") as fp:
+        fp.write("from_id\tto_id\tweight\n")
+        for i, (a, b) in enumerate(rows):
+            fp.write("%s\t%s\t%s\n" % (names[a], names[b], weights[i % len(weights)]))
+    got, want = read_edge_rows(str(path), node2idx), _read_edge_rows_loop(str(path), node2idx)
+    for g_, w_ in zip(got, want):
+        assert g_.dtype == w_.dtype and np.array_equal(g_, w_)
+    path2 = tmp_path / "g2.csv"
+    with open(path2, "w") as fp:
+        fp.write("from_id,to_id\n")
+        for a, b in rows[:100]:
+            fp.write("%s,%s\n" % (names[a], names[b]))
+    got, want = read_edge_rows(str(path2), node2idx, sep=","), _read_edge_rows_loop(str(path2), node2idx, sep=",")
+    for g_, w_ in zip(got, want):
+        assert np.array_equal(g_, w_)
+    (tmp_path / "empty.csv").write_text("from_id\tto_id\tweight\n")
+    assert all(len(a) == 0 for a in read_edge_rows(str(tmp_path / "empty.csv"), node2idx))
+    (tmp_path / "bad.csv").write_text("from_id\tto_id\tweight\nN1\tNOPE\t1\n")
+    with pytest.raises(KeyError):
+        read_edge_rows(str(tmp_path / "bad.csv"), node2idx)
+
+
+def test_device_builder_for_nested_npz_lists_equals_the_host_builder():
+    """CoreAdj.from_nested_matrices_device (the .npz loader route with has_cuda: K coordinate lists tagged with torch sort /
+    unique ops on the loader's device) gives the same arrays as the host lexsort builder on the reference loader's outputs,
+    and declines (None) lists that are not nested."""
+    ca = load_golden("uci_core_adj.npz")
+    for tag in ("mcm1_", "mc5_"):
+        for t, k in enumerate(ca[tag + "K"]):
+            mats = [csr_from(ca, tag + "t%d_j%d" % (t, j), 1899, np.float32) for j in range(int(k))]
+            host = CoreAdj.from_matrices(mats)
+            kept = [m.copy() for m in mats]
+            first = kept[0].tolil()
+            first.setdiag(0)                                  # the loader hands over A_kmax and asks for + I (helper.py:71-72)
+            kept[0] = first.tocsr()
+            kept[0].eliminate_zeros()
+            dev = CoreAdj.from_nested_matrices_device(kept, "cpu", self_loop=True)
+            assert dev is not None and dev.nested and dev.symmetric and dev.self_loop
+            for a in ("row_ptr", "col", "val", "slot"):
+                assert np.array_equal(getattr(host, a).numpy(), getattr(dev, a).numpy()), (tag, t, a)
+            assert host.nnz_per_slot == dev.nnz_per_slot
+    a = sp.random(50, 50, 0.1, format="csr", random_state=1)
+    b = sp.random(50, 50, 0.1, format="csr", random_state=2)
+    assert CoreAdj.from_nested_matrices_device([a + a.T, b + b.T], "cpu") is None

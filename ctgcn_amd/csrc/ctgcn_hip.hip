@@ -1943,11 +1943,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
 
     Unit cur{(int64_t)blockIdx.x, 0, 0};
     if (cur.tile >= ntiles) return;
-    f4v xr[2][SF / 4];                                    // unit q is staged from xr[q & 1] (q & 1 == rt & 1: LY_RT*S units per tile)
-    load_x(cur, xr[0]);
-    load_x(advance(cur, 1), xr[1]);
-    stage_x(0, xr[0]);
-    load_x(advance(cur, 2), xr[0]);
+    f4v xr[SF / 4];                                       // x of the NEXT unit, requested one unit (~2.7 us) before it is staged
+    load_x(cur, xr);
+    stage_x(0, xr);
+    load_x(advance(cur, 1), xr);
     __syncthreads();
 
     f4v hpub[UTW];                                        // h of the previous unit, published one unit late
@@ -1984,8 +1983,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
                 // ---- x of the next unit: registers -> planes; request the unit after the next two
                 {
                     const Unit nx = advance(Unit{tile, t, rt}, 1);
-                    if (nx.tile < ntiles) stage_x(slot ^ 1, xr[(rt + 1) & 1]);
-                    load_x(advance(Unit{tile, t, rt}, 3), xr[(rt + 1) & 1]);
+                    if (nx.tile < ntiles) stage_x(slot ^ 1, xr);
+                    load_x(advance(Unit{tile, t, rt}, 2), xr);
                 }
                 // ---- this unit: the wave's UTW x 16 hidden units (unit-tile-major measured fastest: 6.16 ms per 1M x 8 call, against
                 // 6.40 with the B operands of a chunk shared by both unit tiles and 6.84 with explicitly double-buffered operand

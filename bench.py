@@ -306,7 +306,7 @@ def main():
     # the matrix-core kernels: GRU recurrence (+ sum/LayerNorm) and the input projection
     gru = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_seq"]
     proj = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_proj"]
-    fused = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name in ("gru_layer", "gru_fused")]
+    fused = [(s.elapsed_time(e), meta) for name, s, e, meta in recorded if name == "gru_layer"]
     roof_mfma = None
     mode = ops.forward_split_mode()
     peak = {2: 2500.0 / 3.0, 1: 2500.0 / 6.0, 0: 157.3}[mode]

@@ -12,9 +12,8 @@ LIB_PATH = os.environ.get("CTGCN_HIP_LIB") or os.path.join(_HERE, "csrc", "libct
 F_SELF_LOOP, F_RELU, F_NESTED = 1, 2, 4
 OP_KCORE = 1
 OP_INGEST = 2
-OP_GRU_FUSED = 3
 MAX_SLOTS = 255
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c = ctypes
 _vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_int, _c.c_size_t
@@ -35,7 +34,6 @@ SIGNATURES = {
     "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _i64, _vp, _int, _int, _vp]),
     "ctgcn_lstm_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp]),
-    "ctgcn_gru_fused_f32": (_int, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _vp, _i64, _vp, _sz, _vp]),
     "ctgcn_gru_layer_f32": (_int, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _i64, _vp]),
     "ctgcn_linear_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "ctgcn_linear_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp]),

@@ -1534,243 +1534,6 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// gru_fused_h2_kernel: projection AND recurrence of one 64-node tile in the same block, GI through a per-block scratch
-// that never leaves the Infinity Cache.
-// Why: gru_proj_h2_kernel is bound by writing GI to HBM (12.3 of its 16.4 GB per 1 M x 8 call), gru_seq_h2_kernel by
-// reading it back.  Both weight matrices do not fit a wave's registers at once (2 x 96 VGPRs + ~100 of working set), but
-// they do not have to: a block first computes GI for all steps of ITS tile with W_ih resident (P phase), then swaps in
-// W_hh and runs the recurrence over the same tile (R phase).  The swap is 24 x 16 B per lane from a pre-split fragment
-// table (gru_presplit_kernel; 48 KB per wave and tile from L2, ~4 % of a tile's time).  The GI tile (steps x 96 KB) goes
-// to a scratch slot owned by the block and is read back by the same block a few tens of microseconds later: all slots
-// together are 256 x 786 KB = 201 MB for 8 steps — resident in the 256 MB memory-side cache (a just-written buffer of
-// that size is read back at twice the cold rate, tools/probes/mall_probe.py) and overwritten in place by the next tile.
-// HBM traffic per row-step drops from 3.6 KB to the 0.5 KB of X plus whatever the cache evicts.
-// MEASURED: correct (bit-identical to the kernel pair) but 15 % slower on config 5 — 256 blocks writing and re-reading
-// 786 KB every ~70 us is 6-8 TB/s of Infinity-Fabric traffic; the memory-side cache saves HBM bandwidth, not fabric
-// bandwidth.  Kept as an opt-in (CTGCN_GRU_FUSED=1: 0.2 GB scratch instead of a 4 GB gi buffer); the pair stays default.
-// No inter-block communication; a work-group-scope fence + barrier between the phases orders the block's own stores and loads.
-// ------------------------------------------------------------------------------------------------
-struct FusedArgs {
-    int64_t rows;            // sequences (nodes)
-    int32_t steps;
-    const float *x;          // [rows, steps, 128], row-step stride ldx
-    int64_t ldx;
-    const h8v *frag;         // [2 matrices][8 waves][24 fragments][64 lanes]
-    const float *scales;     // [2][4][128]: W_ih row scales (row 3 unused) | W_hh row scales * 2^-14, b_hn
-    const float *bias_gi;    // [384] or null: b_ih (+ b_hh for r, z)
-    const float *gamma, *beta;
-    float eps;
-    float *out;              // [rows, ldo]
-    int64_t ldo;
-    float *scratch;          // [gridDim.x][steps][3][8][1024]
-};
-
-__global__ __launch_bounds__(512) void gru_presplit_kernel(const float *w_ih, const float *w_hh, const float *b_hn, h8v *frag, float *scales)
-{
-    __shared__ float wscale[4][GRU_H];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 15, grp = lane >> 4;
-    h8v Wf[2][4][3];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        if (m == 0) h2_load_weights<2048>(w_ih, wave, col, grp, Wf, wscale);
-        else h2_load_weights<1>(w_hh, wave, col, grp, Wf, wscale);
-        __syncthreads();
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) frag[((m * 8 + wave) * 24 + (sp * 4 + c) * 3 + g) * 64 + lane] = Wf[sp][c][g];
-        if (threadIdx.x < 3 * GRU_H) {
-            const int g = threadIdx.x / GRU_H, j = threadIdx.x % GRU_H;
-            scales[(m * 4 + g) * GRU_H + j] = wscale[g][j] * (m == 0 ? 1.f : 1.f / 16384.f);
-        } else if (threadIdx.x < 4 * GRU_H) {
-            const int j = threadIdx.x - 3 * GRU_H;
-            scales[(m * 4 + 3) * GRU_H + j] = (m == 1 && b_hn) ? b_hn[j] : 0.f;
-        }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(512, 2) void gru_fused_h2_kernel(const FusedArgs a)
-{
-    __shared__ _Float16 Ps[2][2][GRU_BM][PJ_PITCH];     // P phase: the two fp16 planes of X_t; R phase: of h_{t-1} (double buffered)
-    __shared__ float sbuf[GRU_BM][GRU_PITCH];            // running sum over steps
-    __shared__ float rscale[2][GRU_BM];
-    __shared__ float sc_s[2][4][GRU_H];                  // a.scales
-    __shared__ float bias_s[3][GRU_H];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int col = lane & 15, grp = lane >> 4;
-    const int oc = wave * 16 + 4 * grp;
-    const int S = a.steps;
-    for (int i = tid; i < 2 * 4 * GRU_H; i += 512) (&sc_s[0][0][0])[i] = a.scales[i];
-    for (int i = tid; i < 3 * GRU_H; i += 512) (&bias_s[0][0])[i] = a.bias_gi ? a.bias_gi[i] : 0.f;
-    __syncthreads();
-
-    h8v Wf[2][4][3];      // the resident matrix: W_ih in the P phase, W_hh in the R phase
-    auto load_frags = [&](int m) {
-        const h8v *src = a.frag + (int64_t)(m * 8 + wave) * 24 * 64 + lane;
-#pragma unroll
-        for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) Wf[sp][c][g] = src[((sp * 4 + c) * 3 + g) * 64];
-    };
-    float *gi = a.scratch + (int64_t)blockIdx.x * S * (3 * 8 * 1024);
-    float *gi_lane = gi + wave * 1024 + col * 16 + 4 * grp;              // + t * 24576 + gate * 8192 + rt * 256
-    const int64_t ntiles = (a.rows + GRU_BM - 1) / GRU_BM;
-    const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
-
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * GRU_BM;
-        const int last = (int)min((int64_t)GRU_BM, a.rows - row0) - 1;
-
-        // ================================================================== P phase: GI_t = X_t · W_ih^T + b for every step
-        load_frags(0);
-        // staging role: 64 rows x 32 float4; idx -> (row = idx >> 5, c4 = idx & 31): the 32 lanes of a half wave hold one row
-        auto load_x = [&](int t, f4v (&v)[4]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = tid + 512 * i;
-                v[i] = *(const f4v *)(a.x + ((row0 + min(idx >> 5, last)) * S + t) * a.ldx + (idx & 31) * 4);
-            }
-        };
-        auto stage_x = [&](int buf, const f4v (&v)[4]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = tid + 512 * i;
-                float m = fmaxf(fmaxf(fabsf(v[i][0]), fabsf(v[i][1])), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
-#pragma unroll
-                for (int d = 1; d < 32; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
-                float sc, inv;
-                h2_scale(m, sc, inv);
-                if ((idx & 31) == 0) rscale[buf][idx >> 5] = sc;
-                h4v s0, s1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    _Float16 p, q;
-                    h2_split<2048>(v[i][j] * inv, p, q);
-                    s0[j] = p; s1[j] = q;
-                }
-                _Float16 *dst = &Ps[buf][0][idx >> 5][(idx & 31) * 4];
-                *(h4v *)dst = s0;
-                *(h4v *)(dst + GRU_BM * PJ_PITCH) = s1;
-            }
-        };
-        {
-            f4v stage[4];
-            load_x(0, stage);
-            stage_x(0, stage);
-            __syncthreads();
-            for (int t = 0; t < S; ++t) {
-                const int buf = t & 1;
-                if (t + 1 < S) load_x(t + 1, stage);                     // in flight during the MFMAs
-#pragma unroll
-                for (int rt = 0; rt < GRU_RT; ++rt) {
-                    f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const h8v x1 = *(const h8v *)(&Ps[buf][0][rt * 16 + col][c * 32 + 8 * grp]);
-                        const h8v x2 = *(const h8v *)(&Ps[buf][1][rt * 16 + col][c * 32 + 8 * grp]);
-                        CTGCN_H2_MFMA(Wf, c, x1, x2, acc0, acc1)
-                    }
-                    const float rs = rscale[buf][rt * 16 + col];
-                    float *o = gi_lane + t * (3 * 8 * 1024) + rt * 256;
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        *(f4v *)(o + g * 8192) = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (*(const f4v *)(&sc_s[0][g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
-                }
-                if (t + 1 < S) stage_x(buf ^ 1, stage);
-                __syncthreads();
-            }
-        }
-        // Work-group scope is enough: producer and consumer waves share the CU's write-through L1.  (An agent-scope
-        // __threadfence() writes back the XCD's whole L2 every time — it made this kernel 2x slower inside the model.)
-        __threadfence_block();
-        __syncthreads();
-
-        // ================================================================== R phase: the recurrence over the same tile
-        load_frags(1);
-        f4v hreg[GRU_RT];
-        auto publish = [&](int buf, int r_, const f4v h) {     // split h·2^14 and store the two fp16 planes
-            h4v p, q;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                _Float16 x, y;
-                h2_split<1>(h[j] * 16384.f, x, y);
-                p[j] = x; q[j] = y;
-            }
-            *(h4v *)(&Ps[buf][0][r_][oc]) = p;
-            *(h4v *)(&Ps[buf][1][r_][oc]) = q;
-        };
-        auto gates = [&](const f4v gr, const f4v gz, const f4v gn, const f4v (&ac)[3], const f4v hold) {
-            const f4v csc[3] = {*(const f4v *)(&sc_s[1][0][oc]), *(const f4v *)(&sc_s[1][1][oc]), *(const f4v *)(&sc_s[1][2][oc])};
-            const f4v b_hn = *(const f4v *)(&sc_s[1][3][oc]);
-            f4v h;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float rv = gru_sigmoid(fmaf(ac[0][j], csc[0][j], gr[j]));
-                const float zv = gru_sigmoid(fmaf(ac[1][j], csc[1][j], gz[j]));
-                const float an = fmaf(ac[2][j], csc[2][j], b_hn[j]);
-                const float nv = gru_tanh(fmaf(rv, an, gn[j]));
-                h[j] = nv + zv * (hold[j] - nv);
-            }
-            return h;
-        };
-        const f4v zero3[3] = {zero4, zero4, zero4};
-        f4v gq[4][3];
-        auto load_gi = [&](int t, int rt) {
-            const float *p = gi_lane + t * (3 * 8 * 1024) + rt * 256;
-            gq[rt][0] = *(const f4v *)p; gq[rt][1] = *(const f4v *)(p + 8192); gq[rt][2] = *(const f4v *)(p + 2 * 8192);
-        };
-        // ---- step 0: h_{-1} = 0, no MFMA
-#pragma unroll
-        for (int rt = 0; rt < GRU_RT; ++rt) {
-            load_gi(0, rt);
-            const f4v h = gates(gq[rt][0], gq[rt][1], gq[rt][2], zero3, zero4);
-            hreg[rt] = h;
-            publish(0, rt * 16 + col, h);
-            *(f4v *)(&sbuf[rt * 16 + col][oc]) = h;
-        }
-        if (S > 1) { load_gi(1, 0); load_gi(1, 1); }
-        __syncthreads();
-        for (int t = 1; t < S; ++t) {
-            const int pb = (t - 1) & 1, cb = t & 1;
-            f4v acc[2][3];
-#pragma unroll
-            for (int rt = 0; rt <= GRU_RT; ++rt) {
-                const int cur = rt & 1, prv = cur ^ 1;
-                if (rt < GRU_RT) {
-                    if (rt + 2 < GRU_RT) load_gi(t, rt + 2);
-                    else if (t + 1 < S) load_gi(t + 1, rt + 2 - GRU_RT);
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[cur][g] = zero4;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const h8v x1 = *(const h8v *)(&Ps[pb][0][rt * 16 + col][c * 32 + 8 * grp]);
-                        const h8v x2 = *(const h8v *)(&Ps[pb][1][rt * 16 + col][c * 32 + 8 * grp]);
-                        CTGCN_H2_MFMA1(Wf, c, x1, x2, acc[cur])
-                    }
-                }
-                if (rt > 0) {
-                    const int rp = rt - 1;
-                    const f4v h = gates(gq[rp][0], gq[rp][1], gq[rp][2], acc[prv], hreg[rp]);
-                    hreg[rp] = h;
-                    publish(cb, rp * 16 + col, h);
-                    f4v *sp_ = (f4v *)(&sbuf[rp * 16 + col][oc]);
-                    *sp_ = *sp_ + h;
-                }
-            }
-            __syncthreads();
-        }
-        for (int r = wave; r <= last; r += 8)
-            gru_layernorm_row(sbuf[r], a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
-        __syncthreads();       // LDS is reused by the next tile
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // gru_layer_h2_kernel: input projection AND recurrence of a node tile in one kernel with BOTH weight matrices resident in
 // the register file — GI is never materialised anywhere (not in HBM, not in the memory-side cache, not in LDS).
 // Why it fits: W_ih and W_hh as fp16x2 MFMA fragments are 2 x 196 KB = 77 % of a CU's 512 KB unified VGPR/AGPR file.  A
@@ -1787,6 +1550,9 @@ __global__ __launch_bounds__(512, 2) void gru_fused_h2_kernel(const FusedArgs a)
 // Arithmetic is that of gru_proj_h2_kernel + gru_seq_h2_kernel operation for operation (same splits, same MFMA order
 // per accumulator, same epilogue expressions): results are bit-identical to the kernel pair.
 // HBM traffic: x in (512 B per row-step) + out; the pair moves 3.6 KB per row-step.
+// (Round 1's attempt kept the pair's 8-wave blocks, time-shared the weight registers between a projection phase and a recurrence
+// phase of the same tile and parked GI in a per-block scratch served by the memory-side cache: bit-identical, but 15 % SLOWER
+// than the pair — the round trip costs Infinity-Fabric bandwidth whether it ends in HBM or in the cache.  Removed.)
 // ------------------------------------------------------------------------------------------------
 constexpr int LY_BM = 32;     // rows per tile (2 MFMA row tiles): small, so that LDS has room for weight fragments
 constexpr int LY_RT = LY_BM / 16;
@@ -2909,13 +2675,6 @@ size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t 
                + 2 * align_up(nn * 4, 256) /*pool*/;
     }
     if (op == CTGCN_OP_INGEST) return ctgcn_ingest_workspace_bytes_(n, nnz);   /* nnz = number of edge rows m */
-    if (op == CTGCN_OP_GRU_FUSED) {      /* n = sequences (rows), K = steps */
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int64_t ntiles = (n + GRU_BM - 1) / GRU_BM;
-        const int64_t blocks = ntiles < cus ? ntiles : cus;
-        return (size_t)2 * 8 * 24 * 64 * 16 + (size_t)2 * 4 * GRU_H * 4 + (size_t)(blocks > 0 ? blocks : 0) * (K > 0 ? K : 0) * 3 * 8 * 1024 * 4;
-    }
     return 0;
 }
 
@@ -3046,37 +2805,6 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
         hipLaunchKernelGGL((gru_seq_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((gru_seq_kernel<false, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
-    HIP_TRY(hipGetLastError());
-    return CTGCN_OK;
-}
-
-int ctgcn_gru_fused_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
-                         const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
-                         float ln_eps, float *out, int64_t ld_out, void *workspace, size_t workspace_bytes, void *stream)
-{
-    if (hidden != GRU_H || d_in != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_fused: only d_in = hidden = %d is built (got %d, %d)", GRU_H, d_in, hidden);
-    if (rows < 0 || steps < 1 || ldx < d_in) return fail(CTGCN_E_INVALID, "gru_fused: bad sizes");
-    if (rows == 0) return CTGCN_OK;
-    if (!x || !w_ih || !w_hh || !out || !workspace) return fail(CTGCN_E_INVALID, "gru_fused: null pointer");
-    if (!aligned16(x) || !aligned16(w_ih) || !aligned16(w_hh) || (ldx % 4) || !aligned16(workspace) || (reinterpret_cast<uintptr_t>(out) & 7u))
-        return fail(CTGCN_E_INVALID, "gru_fused: x / weights / workspace must be 16-byte aligned, ldx a multiple of 4, out 8-byte aligned");
-    const int64_t ldo = ld_out > 0 ? ld_out : GRU_H;
-    if (ldo < GRU_H || (ldo & 1)) return fail(CTGCN_E_INVALID, "gru_fused: ld_out=%lld", (long long)ld_out);
-    int dev = 0, cus = 256;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
-    const int64_t blocks = ntiles < cus ? ntiles : cus;
-    const size_t frag_bytes = (size_t)2 * 8 * 24 * 64 * sizeof(h8v), scale_bytes = (size_t)2 * 4 * GRU_H * sizeof(float);
-    const size_t need = frag_bytes + scale_bytes + (size_t)blocks * steps * 3 * 8 * 1024 * sizeof(float);
-    if (workspace_bytes < need) return fail(CTGCN_E_INVALID, "gru_fused: workspace %zu bytes, need %zu (ctgcn_workspace_bytes(CTGCN_OP_GRU_FUSED, rows, 0, 0, steps))", workspace_bytes, need);
-    char *ws = (char *)workspace;
-    FusedArgs a{};
-    a.rows = rows; a.steps = steps; a.x = x; a.ldx = ldx; a.frag = (const h8v *)ws; a.scales = (const float *)(ws + frag_bytes);
-    a.bias_gi = bias_gi; a.gamma = ln_weight; a.beta = ln_bias; a.eps = ln_eps; a.out = out; a.ldo = ldo;
-    a.scratch = (float *)(ws + frag_bytes + scale_bytes);
-    hipLaunchKernelGGL(gru_presplit_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, w_ih, w_hh, b_hn, (h8v *)ws, (float *)(ws + frag_bytes));
-    hipLaunchKernelGGL(gru_fused_h2_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -259,15 +259,6 @@ def split_mfma_enabled():
     return os.environ.get("CTGCN_FP32_MFMA_ONLY", "0") != "1"
 
 
-def fused_gru_enabled():
-    """CTGCN_GRU_FUSED=1: ctgcn_gru_fused_f32 for the CoreDiffusion GRU (reduce_sum, d_in = hidden = 128, fp16x2) instead of the
-    projection + recurrence kernel pair.  Same arithmetic (bit-identical results), 0.2 GB of scratch instead of a 4 GB gi
-    buffer, one launch — but measured 15 % SLOWER on config 5 (308 vs 263 ms per window): the gi round trip costs
-    Infinity-Fabric bandwidth whether it ends in HBM or in the memory-side cache.  Off by default."""
-    import os
-    return os.environ.get("CTGCN_GRU_FUSED", "0") == "1"
-
-
 def layer_kernel_enabled(reduce_sum=True):
     """ctgcn_gru_layer_f32: input projection and recurrence of a GRU with d_in = hidden = 128 in one kernel, both weight matrices
     resident in the register file, the projection consumed from the MFMA accumulators (never materialised).  Bit-identical to
@@ -393,15 +384,6 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
     if rows == 0:
         return out
     split = forward_split_mode()
-    if reduce_sum and split == 2 and d_in == hid and fused_gru_enabled() and seq.stride(2) == 1 and seq.stride(1) % 4 == 0 \
-            and seq.stride(0) == steps * seq.stride(1) and seq.data_ptr() % 16 == 0 and w_ih.is_contiguous():
-        # projection + recurrence of a 64-row tile in one block, gi through a cache-resident per-block scratch: one launch, no chunks
-        ws_bytes = int(lib.ctgcn_workspace_bytes(_lib.OP_GRU_FUSED, rows, 0, 0, steps))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=seq.device)
-        with torch.cuda.device(seq.device), _timed("gru_fused", rows=rows, steps=steps):
-            check(lib.ctgcn_gru_fused_f32(rows, steps, d_in, hid, ptr(seq), seq.stride(1), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn),
-                                          ptr(ln_w), ptr(ln_b), eps, ptr(out), ldo, ptr(ws), ws_bytes, _stream()), "ctgcn_gru_fused_f32")
-        return out
     if split == 2 and d_in == hid and layer_kernel_enabled(reduce_sum) and seq.stride(2) == 1 and seq.stride(1) % 4 == 0 \
             and seq.stride(0) == steps * seq.stride(1) and seq.data_ptr() % 16 == 0 and w_ih.is_contiguous():
         # projection + recurrence in one kernel, both weight matrices in the register file, gi never materialised

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 9
+#define CTGCN_ABI_VERSION 10
 
 enum {
     CTGCN_OK = 0,
@@ -48,8 +48,7 @@ enum {
 
 enum { /* `op` of ctgcn_workspace_bytes */
     CTGCN_OP_KCORE = 1,
-    CTGCN_OP_INGEST = 2,    /* pass the number of edge rows m as `nnz` */
-    CTGCN_OP_GRU_FUSED = 3  /* ctgcn_gru_fused_f32: n = sequences (rows), K = steps */
+    CTGCN_OP_INGEST = 2     /* pass the number of edge rows m as `nnz` */
 };
 
 #define CTGCN_MAX_SLOTS 255
@@ -197,19 +196,6 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
 int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                        const float *ln_weight, const float *ln_bias, float ln_eps, int reduce_sum, float *out,
                        void *stream);
-
-/*
- * layers.py:59-62 in ONE kernel for d_in = hidden = 128 (inference):  out = LayerNorm(sum_t GRU(x)_t), x [rows, steps, 128]
- * with row-step stride ldx.  Each block projects all steps of its 64-sequence tile (W_ih resident), then swaps W_hh in and
- * runs the recurrence on the same tile; gi lives in a per-block scratch slot inside `workspace`
- * (ctgcn_workspace_bytes(CTGCN_OP_GRU_FUSED, rows, 0, 0, steps): <= CUs x steps x 96 KB + 0.4 MB), small enough to stay in the
- * memory-side cache - the [rows, steps, 384] projection is never materialised in HBM.  CTGCN_SPLIT_F16X2 arithmetic.
- * bias_gi [384] = b_ih (+ b_hh for the r and z gates), b_hn [128] = bias_hh_l0[256:384]; either may be NULL.
- * ld_out as in ctgcn_gru_seq_f32.  Same arithmetic as ctgcn_gru_input_proj_f32 + ctgcn_gru_seq_f32 in CTGCN_SPLIT_F16X2.
- */
-int ctgcn_gru_fused_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
-                        const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
-                        float ln_eps, float *out, int64_t ld_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * layers.py:59-62 / models.py:249-250 in ONE kernel for d_in = hidden = 128 with both weight matrices resident in the register

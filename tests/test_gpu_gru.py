@@ -257,28 +257,6 @@ def test_split_bf16_weight_gradient_is_fp32_accurate(nodes, steps, shift):
     assert torch.allclose(part.sum(0).cpu().double(), 2 * ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item())   # accumulate flag
 
 
-@pytest.mark.parametrize("rows,steps", [(1, 1), (63, 3), (64, 8), (1000, 5), (40000, 8)])
-def test_fused_projection_recurrence_kernel_equals_the_kernel_pair(rows, steps, monkeypatch):
-    """ctgcn_gru_fused_f32 (opt-in, CTGCN_GRU_FUSED=1: projection and recurrence of a tile in one block, gi through a per-block
-    scratch) performs the same arithmetic in the same order as ctgcn_gru_input_proj_f32 + ctgcn_gru_seq_f32: identical bits,
-    also into a strided output."""
-    from ctgcn_amd import ops
-    torch.manual_seed(rows + steps)
-    rnn = torch.nn.GRU(128, 128, 1, batch_first=True).to(DEV)
-    norm = torch.nn.LayerNorm(128).to(DEV)
-    x = torch.relu(torch.randn(rows, steps, 128, device=DEV)) * 2.0
-    with torch.no_grad():
-        monkeypatch.setenv("CTGCN_GRU_FUSED", "0")
-        want = ops.gru_sequence(rnn, x, norm, True)
-        monkeypatch.setenv("CTGCN_GRU_FUSED", "1")
-        assert ops.fused_gru_enabled() and ops.forward_split_mode() == 2
-        got = ops.gru_sequence(rnn, x, norm, True)
-        wide = torch.zeros(rows, 3, 128, device=DEV)
-        ops.gru_sequence(rnn, x, norm, True, out=wide[:, 1])
-    assert torch.equal(got, want)
-    assert torch.equal(wide[:, 1], want) and not wide[:, 0].any() and not wide[:, 2].any()
-
-
 @pytest.mark.parametrize("rows,steps", [(1, 1), (63, 2), (64, 8), (1000, 5), (70001, 8), (40000, 16)])
 @pytest.mark.parametrize("reduce_sum", [True, False])
 def test_register_resident_layer_kernel_equals_the_kernel_pair(rows, steps, reduce_sum, monkeypatch):

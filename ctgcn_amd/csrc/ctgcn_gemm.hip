@@ -61,10 +61,22 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
     if (row >= rows) return;
     const float *src = x + row * ldx;
     float m = 0.f;
+    constexpr int HOLD = 8;                               // float4 per lane kept in registers: rows up to 2048 columns are read ONCE
+    f4v keep[HOLD];
+    const bool held = VEC && K <= HOLD * 256;
     if (VEC) {
-        for (int k = lane * 4; k < K; k += 256) {
-            const f4v v = *(const f4v *)(src + k);
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        if (held) {
+#pragma unroll
+            for (int i = 0; i < HOLD; ++i) {
+                const int k = lane * 4 + i * 256;
+                keep[i] = k < K ? *(const f4v *)(src + k) : f4v{0.f, 0.f, 0.f, 0.f};
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(keep[i][0]), fabsf(keep[i][1])), fmaxf(fabsf(keep[i][2]), fabsf(keep[i][3]))));
+            }
+        } else {
+            for (int k = lane * 4; k < K; k += 256) {
+                const f4v v = *(const f4v *)(src + k);
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
         }
     } else {
         for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(src[k]));
@@ -75,7 +87,23 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
     h2_scale(m, s, inv);
     if (lane == 0) scale[row] = s;
     _Float16 *d1 = p1 + row * Kp, *d2 = p2 + row * Kp;
-    if (VEC) {
+    if (VEC && held) {
+#pragma unroll
+        for (int i = 0; i < HOLD; ++i) {
+            const int k = lane * 4 + i * 256;
+            if (k < Kp) {
+                h4v a, b;                                 // columns >= K were loaded as zeros
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xs = keep[i][j] * inv;
+                    a[j] = (_Float16)xs;
+                    b[j] = (_Float16)(xs - (float)a[j]);
+                }
+                *(h4v *)(d1 + k) = a;
+                *(h4v *)(d2 + k) = b;
+            }
+        }
+    } else if (VEC) {
         for (int k = lane * 4; k < Kp; k += 256) {
             h4v a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
             if (k < K) {                                  // K % 4 == 0: a float4 is entirely inside or outside

@@ -429,6 +429,11 @@ def main():
         "embed_wall_ms": round(ms_per_step, 3),
         "aggregation_ms_per_step_rank0": None if spmm_ms_step is None else round(spmm_ms_step, 3),
         "aggregation_edges_per_s_rank0": agg_rate,
+        "kernel_ms_per_step_rank0": {k: round(sum(st.elapsed_time(en) for nm, st, en, _ in recorded if nm == k) / args.steps, 3)
+                                     for k in sorted({nm for nm, _, _, _ in recorded})},
+        "roofline_note": "`roofline` is the aggregation kernel — the HBM-bound kernel the metric is named after (BASELINE north_star); by time "
+                         "the largest kernel of the config-5 forward is the matrix-core-bound GRU (`roofline_gru.fused_layers`), see "
+                         "`kernel_ms_per_step_rank0`",
         "roofline": roof,
         "roofline_by_width": {str(d): r for d, r in sorted(roofs.items())} if len(roofs) > 1 else None,
         "roofline_gru": roof_mfma,

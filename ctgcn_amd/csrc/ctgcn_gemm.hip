@@ -17,6 +17,7 @@
 //   Block ids are remapped so that the N tiles of one M panel run on the same XCD (its L2 then serves the panel's re-reads).
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -132,7 +133,10 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
     }
 }
 
-constexpr int BM = 128, BN = 128, BK = 32, BKP = BK + 8;      // LDS pitch 40 halfs = 80 B: ds_read_b128 rows 16-B aligned, conflict-free
+constexpr int BN = 128, BK = 32, BKP = BK;          // LDS rows are 64 B, unpadded: 16-byte segment s of row r is stored at s ^ ((r >> 2) & 3)
+// (8 consecutive lanes of a ds_read_b128 / ds_write_b128 then hit 8 distinct bank groups).  With 8 halfs of padding per row the
+// double-buffered 128 x 128 tile took exactly half of the CU's 160 KB and only ONE block was resident (measured 2 waves per CU).
+__device__ __forceinline__ int swz(int row, int seg) { return ((seg ^ ((row >> 2) & 3)) << 3); }
 
 struct GemmArgs {
     int64_t M;
@@ -145,10 +149,18 @@ struct GemmArgs {
     int32_t ntiles;
 };
 
+// WM = 32-row MFMA tiles per wave along M: 2 -> 128 x 128 block tile, LDS double buffered (one barrier per k step); the
+// template also builds 4 -> 256 x 128 block tile, LDS single buffered (128 x 64 wave tiles read 12 KB of operands per 24
+// MFMAs instead of 8 KB per 12), not instantiated: it needs the registers of the second load set.
+// Measured (rocprofv3 SQ counters, 435 180 x 500 x 384): 0.99 ms, matrix pipe busy 31 % of CU-busy cycles, waves waiting 47 % —
+// neither two blocks per CU (swizzled LDS), nor loads two k steps ahead, nor the taller wave tile moved it by more than 7 %.
+template <int WM>
 __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 {
-    __shared__ _Float16 As[2][2][BM][BKP];
-    __shared__ _Float16 Bs[2][2][BN][BKP];
+    constexpr int BM = 64 * WM;
+    constexpr int ST = WM == 2 ? 2 : 1;                  // LDS stages
+    __shared__ _Float16 As[ST][2][BM][BKP];
+    __shared__ _Float16 Bs[ST][2][BN][BKP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order: consecutive block ids go round-robin over the 8 XCDs; the N tiles of M panel p all get p % 8
@@ -161,69 +173,105 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
     const int64_t m0 = mp * BM;
     const int n0 = nt * BN;
 
-    // staging role: a 128 x 32 half plane tile is 128 rows x 4 segments of 16 B; thread -> rows (tid >> 2) and + 64, segment tid & 3
+    // staging role: a plane tile is rows x 4 segments of 16 B; thread -> rows (tid >> 2) + 64 r, segment tid & 3
     const int lr = tid >> 2, ls = (tid & 3) * 8;
-    const int64_t ra0 = min(m0 + lr, a.M - 1), ra1 = min(m0 + lr + 64, a.M - 1);
-    const int64_t rb0 = min((int64_t)n0 + lr, (int64_t)a.N - 1), rb1 = min((int64_t)n0 + lr + 64, (int64_t)a.N - 1);
-    h8v ga[2][2], gb[2][2];                  // [plane][row half]
-    auto gload = [&](int kt) {
+    const int nk_ = a.Kp / BK;
+    // Two register sets: the tile of k step kt+1 waits in one while the loads of kt+2 / kt+3 are in flight in both — a global
+    // load issued only one k step (0.35 us of MFMAs) before its ds_write is still on its way (~1.5 us loaded latency).
+    h8v ga[2][2][WM], gb[2][2][2];           // [set][plane][row group]
+    auto gload = [&](int kt, int s) {
+        if (kt >= nk_) return;
         const int64_t k = (int64_t)kt * BK + ls;
-        ga[0][0] = *(const h8v *)(a.a1 + ra0 * a.Kp + k); ga[0][1] = *(const h8v *)(a.a1 + ra1 * a.Kp + k);
-        ga[1][0] = *(const h8v *)(a.a2 + ra0 * a.Kp + k); ga[1][1] = *(const h8v *)(a.a2 + ra1 * a.Kp + k);
-        gb[0][0] = *(const h8v *)(a.b1 + rb0 * a.Kp + k); gb[0][1] = *(const h8v *)(a.b1 + rb1 * a.Kp + k);
-        gb[1][0] = *(const h8v *)(a.b2 + rb0 * a.Kp + k); gb[1][1] = *(const h8v *)(a.b2 + rb1 * a.Kp + k);
+#pragma unroll
+        for (int r = 0; r < WM; ++r) {
+            const int64_t row = min(m0 + lr + 64 * r, a.M - 1);
+            ga[s][0][r] = *(const h8v *)(a.a1 + row * a.Kp + k);
+            ga[s][1][r] = *(const h8v *)(a.a2 + row * a.Kp + k);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t row = min((int64_t)n0 + lr + 64 * r, (int64_t)a.N - 1);
+            gb[s][0][r] = *(const h8v *)(a.b1 + row * a.Kp + k);
+            gb[s][1][r] = *(const h8v *)(a.b2 + row * a.Kp + k);
+        }
     };
-    auto lstore = [&](int st) {
+    auto lstore = [&](int st, int s) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            *(h8v *)(&As[st][p][lr][ls]) = ga[p][0]; *(h8v *)(&As[st][p][lr + 64][ls]) = ga[p][1];
-            *(h8v *)(&Bs[st][p][lr][ls]) = gb[p][0]; *(h8v *)(&Bs[st][p][lr + 64][ls]) = gb[p][1];
+#pragma unroll
+            for (int r = 0; r < WM; ++r) *(h8v *)(&As[st][p][lr + 64 * r][swz(lr + 64 * r, tid & 3)]) = ga[s][p][r];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) *(h8v *)(&Bs[st][p][lr + 64 * r][swz(lr + 64 * r, tid & 3)]) = gb[s][p][r];
         }
     };
 
-    f16v acc[2][2];
+    f16v acc[WM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    const int nk = a.Kp / BK;
-    gload(0);
-    lstore(0);
+    const int nk = nk_;
+    gload(0, 0);
+    lstore(0, 0);
+    gload(1, 1);
+    gload(2, 0);
     __syncthreads();
     // MFMA 32x32x16 operand layout: lane l holds row (l & 31), k = 8 (l >> 5) .. + 7 of a 32 x 16 slab
-    const int fr = lane & 31, fk = (lane >> 5) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);                                   // in flight during the MFMAs
+    const int fr = lane & 31;
+    auto compute = [&](int st) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            h8v fa[2][2], fb[2][2];                                       // [tile][plane]
+            h8v fa[WM][2], fb[2][2];                                      // [tile][plane]
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i][0] = *(const h8v *)(&As[st][0][wm * 64 + i * 32 + fr][kk * 16 + fk]);
-                fa[i][1] = *(const h8v *)(&As[st][1][wm * 64 + i * 32 + fr][kk * 16 + fk]);
-                fb[i][0] = *(const h8v *)(&Bs[st][0][wn * 64 + i * 32 + fr][kk * 16 + fk]);
-                fb[i][1] = *(const h8v *)(&Bs[st][1][wn * 64 + i * 32 + fr][kk * 16 + fk]);
+            for (int i = 0; i < WM; ++i) {
+                const int row = wm * (32 * WM) + i * 32 + fr, off = swz(row, kk * 2 + (lane >> 5));
+                fa[i][0] = *(const h8v *)(&As[st][0][row][off]);
+                fa[i][1] = *(const h8v *)(&As[st][1][row][off]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + fr, off = swz(row, kk * 2 + (lane >> 5));
+                fb[j][0] = *(const h8v *)(&Bs[st][0][row][off]);
+                fb[j][1] = *(const h8v *)(&Bs[st][1][row][off]);
             }
             // small terms first: x1·w2, x2·w1, then x1·w1
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(st ^ 1);                                  // stage st^1 was last read in iteration kt-1 (barrier since)
-        __syncthreads();
+    };
+    // one k step: compute from LDS stage st, then move the tile of step kt+1 (register set s) to LDS and request step kt+3 into s
+    auto step = [&](int kt, int s) {
+        const int st = ST == 2 ? (kt & 1) : 0;
+        compute(st);
+        if (ST == 2) {
+            if (kt + 1 < nk) lstore(st ^ 1, s);                           // stage st^1 was last read in iteration kt-1 (barrier since)
+            gload(kt + 3, s);
+            __syncthreads();
+        } else {
+            if (kt + 1 < nk) {
+                __syncthreads();                                          // everyone has read the stage
+                lstore(0, s);
+            }
+            gload(kt + 3, s);
+            __syncthreads();
+        }
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        step(kt, 1);                                                      // the tile of step kt+1 (odd) sits in set 1
+        if (kt + 1 < nk) step(kt + 1, 0);
     }
 
     // epilogue: D[i][j] of a 32 x 32 tile: lane l holds column j = l & 31, rows i = 8 (v / 4) + 4 (l >> 5) + v % 4
@@ -233,10 +281,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
         if (n >= a.N) continue;
         const float sb = a.sb[n], bs = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int64_t m = m0 + wm * 64 + i * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
+                const int64_t m = m0 + wm * (32 * WM) + i * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
                 if (m < a.M) a.y[m * a.ldy + n] = fmaf(acc[i][j][v], a.sa[m] * sb, bs);
             }
         }
@@ -283,11 +331,13 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
     else hipLaunchKernelGGL(split_rows_h2_kernel<false>, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, st, (int64_t)n_out, k, kp, w, ldw, b1, b2, sb);
     GemmArgs g{};
     g.M = rows; g.N = n_out; g.Kp = kp; g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.sa = sa; g.sb = sb; g.bias = bias; g.y = y; g.ldy = ldy;
-    g.mtiles = (rows + BM - 1) / BM;
     g.ntiles = (n_out + BN - 1) / BN;
+    constexpr int wm = 2;          // 128-row panels (a 256-row panel / 128 x 64 wave tile was measured: 7 % faster single-set, spills with two sets)
+    const int bm = 64 * wm;
+    g.mtiles = (rows + bm - 1) / bm;
     const int64_t blocks = (g.mtiles + 7) / 8 * 8 * g.ntiles;
     if (blocks > 0x7fffffffLL) return ctgcn_set_error_(CTGCN_E_INVALID, "linear: too many tiles for one launch; split the rows");
-    hipLaunchKernelGGL(gemm_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gemm_h2_kernel<wm>, dim3((unsigned)blocks), dim3(256), 0, st, g);
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

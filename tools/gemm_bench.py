@@ -17,9 +17,10 @@ SHAPES = [(435_180, 500, 384, "Enron layer-0 GRU projection (87 036 x 5 rows)"),
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", type=int, default=-1, help="index of the single shape to run")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    for rows, k, n, what in SHAPES:
+    for rows, k, n, what in (SHAPES if a.only < 0 else SHAPES[a.only:a.only + 1]):
         x = torch.randn(rows, k, device=dev)
         w = torch.randn(n, k, device=dev) / k ** 0.5
         b = torch.randn(n, device=dev)

@@ -388,3 +388,40 @@ def test_width_128_hip_path_matches_reference_outputs_and_gradients():
             if ".linear." in name and "mlp_list" not in name:
                 continue
             check_sampled_tensor(g, tag + "grad_" + name, p.grad.cpu().numpy(), 1e-3, 2e-4)
+
+
+def test_multi_stream_snapshot_branches_equal_the_single_stream_forward(monkeypatch):
+    """Small-graph inference runs the snapshot branches on several HIP streams (models.CTGCN._snapshot_streams): same kernels,
+    same inputs -> bit-identical embeddings, for CTGCN-C on one-hot features and CTGCN-S on dense features; graphs above the size
+    threshold and models whose dense steps would go to library GEMMs stay on one stream."""
+    import ctgcn_amd
+    adj = _window()
+    n, T = 1899, len(adj)
+    torch.manual_seed(9)
+    idx = torch.arange(n, device=DEV).repeat(2, 1)
+    eye = [torch.sparse_coo_tensor(idx, torch.ones(n, device=DEV), (n, n)) for _ in range(T)]
+    dense = [torch.randn(n, 61, device=DEV) for _ in range(T)]                     # 61 columns: not a multiple of 4
+    for kw, xs in ((dict(trans_num=1, diffusion_num=2, model_type="C", trans_activate_type="L"), eye),
+                   (dict(trans_num=3, diffusion_num=1, model_type="S", trans_activate_type="N"), dense)):
+        in_dim = n if xs is eye else 61
+        m = ctgcn_amd.CTGCN(in_dim, 500, 128, duration=T, rnn_type="GRU", **kw).to(DEV).eval()
+        with torch.no_grad():
+            monkeypatch.setenv("CTGCN_STREAMS", "1")
+            assert m._snapshot_streams(torch.empty(1, device=DEV), n, T, xs) is None
+            want = m(xs, adj)
+            monkeypatch.setenv("CTGCN_STREAMS", "3")
+            lanes = m._snapshot_streams(torch.empty(1, device=DEV), n, T, xs)
+            assert lanes is not None and len(lanes) == 3
+            got = m(xs, adj)
+            monkeypatch.delenv("CTGCN_STREAMS")
+            assert len(m._snapshot_streams(torch.empty(1, device=DEV), n, T, xs)) == min(4, T)      # default for small graphs
+            assert m._snapshot_streams(torch.empty(1, device=DEV), 1_000_000, T, xs) is None          # config-5 size: one stream
+        if kw["model_type"] == "S":
+            assert all(torch.equal(a, b) for a, b in zip(got[1], want[1]))
+            got, want = got[0], want[0]
+        assert torch.equal(got, want)
+    # an LSTM head / hidden width without HIP kernels -> library kernels in the branches -> never more than one stream
+    m = ctgcn_amd.CTGCN(61, 500, 128, 1, 2, T, rnn_type="LSTM").to(DEV).eval()
+    assert m._snapshot_streams(torch.empty(1, device=DEV), n, T, dense) is None
+    m = ctgcn_amd.CTGCN(61, 64, 64, 1, 2, T).to(DEV).eval()
+    assert m._snapshot_streams(torch.empty(1, device=DEV), n, T, dense) is None

@@ -14,7 +14,11 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", OUT] + SRCS
+    # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs.  gru_layer_h2_kernel fills the AGPR half of the register
+    # file with pinned weight fragments; with the default (AGPR-form) accumulators every result crosses back through
+    # v_accvgpr_read before the gate math (24 % of that kernel's VALU instructions).  The other kernels use no AGPRs either way.
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-shared", "-fPIC", "-pthread",
+           "-o", OUT] + SRCS
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

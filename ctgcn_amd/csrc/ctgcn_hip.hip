@@ -1570,7 +1570,7 @@ __device__ __forceinline__ constexpr int ly_lds_slot(int ut, int sp, int c, int 
 template <int NW>
 __device__ __forceinline__ constexpr bool ly_in_agpr(int ut, int sp, int c, int g)
 {
-    if (NW == 4) return (sp == 1 && ly_lds_slot<4>(ut, sp, c, g) < 0) || (sp == 0 && c == 3 && ut == 1);     // 48 + 7 fragments = 220 registers
+    if (NW == 4) return (sp == 1 && ly_lds_slot<4>(ut, sp, c, g) < 0) || (sp == 0 && c >= 2);                  // 48 + 16 fragments = 256 registers
     return (sp == 1 && ly_lds_slot<8>(ut, sp, c, g) < 0) || (sp == 0 && c >= 2);                               // 24 + 8 fragments = 128 registers
 }
 
@@ -1849,6 +1849,186 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
                 if (r <= last) gru_layernorm_row(hold[r], a.out + ((row0 + r) * S + (S - 1)) * GRU_H, lane, a.gamma, a.beta, a.eps);
         }
         __syncthreads();       // hold / hsum rows are rewritten by the next tile's first units
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gru_layer8_h2_kernel: the same fusion with EIGHT waves per block — two per SIMD, so that one wave's LDS / MFMA-result
+// latency is covered by the other instead of by hand-placed loads.  256 registers per wave; wave w owns hidden units
+// [16w, 16w+16) of both matrices = 48 fragments: W_hh (24) pinned to AGPRs, 15 fragments of W_ih (the whole residual plane +
+// chunk 3 of the leading plane) in LDS (120 KB), 9 in VGPRs.  That much LDS for weights forces 16-row tiles: one unit per step,
+// h planes double buffered by step parity (published right after the gate math), a lane owns ONE (row, 4 hidden units) patch
+// for the whole tile, so h_{t-1} and the running sum stay in registers; the sum goes through the idle x slot for the final
+// LayerNorm.  Sum-over-steps form only.  Same arithmetic as the other two paths (bit-identical).
+// ------------------------------------------------------------------------------------------------
+constexpr int L8_WL = 15;
+__device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : (c == 3 ? 12 + g : -1); }
+
+__global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
+{
+    __shared__ _Float16 Xs[2][2][16][PJ_PITCH];          // ring of two units: the two fp16 planes of 16 rows of x_t
+    __shared__ _Float16 Hs[2][2][16][PJ_PITCH];          // [step parity][plane]: h_t·2^14 (after the last step: the summed rows in fp32)
+    __shared__ float xscale[2][16];
+    __shared__ float wsc_ih[3][GRU_H];
+    __shared__ float csc_hh[4][GRU_H];                   // rows 0-2: product scales of the three gates, row 3: b_hn
+    __shared__ float bias_s[3][GRU_H];
+    __shared__ h8v Wl[8][L8_WL][64];
+    static_assert(sizeof(_Float16) * 2 * 16 * PJ_PITCH >= sizeof(float) * 16 * GRU_PITCH, "a plane buffer must hold 16 fp32 rows");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int oc = wave * 16 + 4 * grp;
+    const int S = a.steps;
+
+    h8v Wi[2][4][3], Wh[2][4][3];                        // [split][k chunk][gate]
+    h2_load_weight_tile<2048>(a.wih, wave, col, grp, Wi, wsc_ih);
+    h2_load_weight_tile<1>(a.whh, wave, col, grp, Wh, csc_hh);
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                asm volatile("" : "+a"(Wh[sp][c][g]));
+                if (l8_lds_slot(sp, c, g) >= 0) Wl[wave][l8_lds_slot(sp, c, g)][lane] = Wi[sp][c][g];
+                else if (c * 3 + g < 8) asm volatile("" : "+a"(Wi[sp][c][g]));     // at two waves per SIMD the file splits 128 / 128: 24 + 8 fragments fill the AGPR half
+            }
+    __syncthreads();
+    for (int i = tid; i < 3 * GRU_H; i += 512) {
+        (&csc_hh[0][0])[i] *= (1.f / 16384.f);
+        (&bias_s[0][0])[i] = a.bias_gi ? a.bias_gi[i] : 0.f;
+    }
+    if (tid < GRU_H) csc_hh[3][tid] = a.bhn ? a.bhn[tid] : 0.f;
+    __syncthreads();
+
+    const int64_t ntiles = (a.rows + 15) / 16;
+    const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
+    const int sr = tid >> 5, sc = (tid & 31) * 4;         // staging role: 16 rows x 32 lanes x one float4
+    auto load_x = [&](int64_t tile, int t, f4v &v) {
+        if (tile < ntiles) {
+            const int64_t row = min(tile * 16 + sr, a.rows - 1);
+            v = *(const f4v *)(a.x + (row * S + t) * a.ldx + sc);
+        }
+    };
+    auto stage_x = [&](int slot, const f4v v) {
+        float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+        float scl, inv;
+        h2_scale(m, scl, inv);
+        if ((tid & 31) == 0) xscale[slot][sr] = scl;
+        h4v s0, s1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            _Float16 p, q;
+            h2_split<2048>(v[j] * inv, p, q); s0[j] = p; s1[j] = q;
+        }
+        *(h4v *)(&Xs[slot][0][sr][sc]) = s0;
+        *(h4v *)(&Xs[slot][1][sr][sc]) = s1;
+    };
+    auto next_unit = [&](int64_t &tile, int &t) {
+        if (++t >= S) { t = 0; tile += gridDim.x; }
+    };
+
+    if ((int64_t)blockIdx.x >= ntiles) return;
+    f4v xr;
+    int64_t ptile = blockIdx.x;                           // unit whose x sits in xr
+    int pt = 0;
+    load_x(ptile, pt, xr);
+    stage_x(0, xr);
+    next_unit(ptile, pt);
+    load_x(ptile, pt, xr);
+    __syncthreads();
+
+    int slot = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * 16;
+        const int last = (int)min((int64_t)16, a.rows - row0) - 1;
+        f4v hprev = zero4, hsum = zero4;
+        for (int t = 0; t < S; ++t) {
+            // ---- x of the next unit: registers -> planes of the other slot; request the unit after it
+            if (ptile < ntiles) stage_x(slot ^ 1, xr);
+            next_unit(ptile, pt);
+            load_x(ptile, pt, xr);
+            // ---- this unit
+            const float rs = xscale[slot][col];
+            f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};
+            auto body = [&](auto with_h_tag) {
+                constexpr bool with_h = decltype(with_h_tag)::value;
+                const int hp = (t + 1) & 1;               // parity of step t-1
+                // issue order pinned as in gru_layer_h2_kernel: per k chunk the h planes and the residual-plane fragments are
+                // requested before the x MFMAs, the next chunk's x planes before the h MFMAs
+                h8v x1 = *(const h8v *)(&Xs[slot][0][col][8 * grp]);
+                h8v x2 = *(const h8v *)(&Xs[slot][1][col][8 * grp]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    h8v h1, h2, wr[3];
+                    if (with_h) {
+                        h1 = *(const h8v *)(&Hs[hp][0][col][c * 32 + 8 * grp]);
+                        h2 = *(const h8v *)(&Hs[hp][1][col][c * 32 + 8 * grp]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) wr[g] = Wl[wave][l8_lds_slot(1, c, g)][lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                    // = CTGCN_H2_MFMA(Wi, c, x1, x2, acc0, acc1), LDS-resident fragments of the leading plane read on the spot
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                        acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x2, acc1[g], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], x1, acc1[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                        acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x1, acc0[g], 0, 0, 0);
+                    }
+                    if (c < 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        x1 = *(const h8v *)(&Xs[slot][0][col][(c + 1) * 32 + 8 * grp]);
+                        x2 = *(const h8v *)(&Xs[slot][1][col][(c + 1) * 32 + 8 * grp]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (with_h) { CTGCN_H2_MFMA1(Wh, c, h1, h2, ach) }
+                }
+            };
+            if (t > 0) body(std::true_type{}); else body(std::false_type{});
+            f4v gi[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                gi[g] = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
+            const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
+            const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
+            f4v h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], gi[0][j]));
+                const float zv = gru_sigmoid(fmaf(ach[1][j], csc[1][j], gi[1][j]));
+                const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
+                const float nv = gru_tanh(fmaf(rv, an, gi[2][j]));
+                h[j] = nv + zv * (hprev[j] - nv);
+            }
+            hprev = h;
+            hsum = t > 0 ? hsum + h : h;
+            if (t + 1 < S) {                              // fp16x2 planes of h·2^14 for the next step (the buffer nobody reads in this unit)
+                h4v p, q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 x, y;
+                    h2_split<1>(h[j] * 16384.f, x, y);
+                    p[j] = x; q[j] = y;
+                }
+                *(h4v *)(&Hs[t & 1][0][col][oc]) = p;
+                *(h4v *)(&Hs[t & 1][1][col][oc]) = q;
+            } else {                                      // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
+                *(f4v *)((float *)&Hs[t & 1][0][0][0] + col * GRU_PITCH + oc) = hsum;
+            }
+            __syncthreads();
+            slot ^= 1;
+        }
+        // ---- end of the tile: LayerNorm of the 16 summed rows, two per wave
+        for (int r = wave * 2; r < wave * 2 + 2; ++r)
+            if (r <= last) gru_layernorm_row((const float *)&Hs[(S - 1) & 1][0][0][0] + r * GRU_PITCH, a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
+        __syncthreads();       // the buffer is a plane buffer again in the next tile
     }
 }
 
@@ -2831,10 +3011,11 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
     LayerArgs a{};
     a.rows = rows; a.steps = steps; a.x = x; a.ldx = ldx; a.wih = w_ih; a.whh = w_hh; a.bias_gi = bias_gi; a.bhn = b_hn;
     a.gamma = ln_weight; a.beta = ln_bias; a.eps = ln_eps; a.out = out; a.ldo = ldo;
-    static const int nw = [] { const char *e = getenv("CTGCN_GRU_LAYER_WAVES"); return e && atoi(e) == 8 ? 8 : 4; }();
-    if (nw == 8) {
-        if (reduce_sum) hipLaunchKernelGGL((gru_layer_h2_kernel<true, 8>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((gru_layer_h2_kernel<false, 8>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    // sum-over-steps form: the 8-wave kernel (4.6 ms per 1M x 8 call; 5.2 for the 4-wave one, 6.4 for the kernel pair); CTGCN_GRU_LAYER_WAVES=4 forces the latter
+    static const int nw = [] { const char *e = getenv("CTGCN_GRU_LAYER_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    if (nw == 8 && reduce_sum) {
+        const int64_t nt8 = (rows + 15) / 16;
+        hipLaunchKernelGGL(gru_layer8_h2_kernel, dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
     } else {
         if (reduce_sum) hipLaunchKernelGGL((gru_layer_h2_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gru_layer_h2_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

@@ -263,8 +263,9 @@ def layer_kernel_enabled(reduce_sum=True):
     """ctgcn_gru_layer_f32: input projection and recurrence of a GRU with d_in = hidden = 128 in one kernel, both weight matrices
     resident in the register file, the projection consumed from the MFMA accumulators (never materialised).  Bit-identical to
     the projection + recurrence kernel pair (tests/test_gpu_gru.py) at 1/7 of its HBM traffic.
-    CTGCN_GRU_LAYER = 1 (default): used where it is faster — the sum-over-steps form of CoreDiffusion (5.4 vs 6.4 ms per
-    1M x 8 call); the per-step form of the temporal GRU keeps the pair (15.7 vs 17 ms per 1M x 16 call).  all: both forms.  0: never."""
+    CTGCN_GRU_LAYER = 1 (default): used where it is faster — the sum-over-steps form of CoreDiffusion (4.6 vs 6.4 ms per
+    1M x 8 call); the per-step form of the temporal GRU keeps the pair (15.6 vs 16.5 ms per 1M x 16 call).  all: both forms.  0: never.
+    CTGCN_GRU_LAYER_WAVES=4 selects the 4-wave build of the sum form (one wave per SIMD, 5.2 ms)."""
     import os
     mode = os.environ.get("CTGCN_GRU_LAYER", "1")
     return mode == "all" or (mode != "0" and bool(reduce_sum))

@@ -257,7 +257,7 @@ def test_split_bf16_weight_gradient_is_fp32_accurate(nodes, steps, shift):
     assert torch.allclose(part.sum(0).cpu().double(), 2 * ref, rtol=1e-5, atol=1e-5 * ref.abs().max().item())   # accumulate flag
 
 
-@pytest.mark.parametrize("rows,steps", [(1, 1), (63, 2), (64, 8), (1000, 5), (70001, 8), (40000, 16)])
+@pytest.mark.parametrize("rows,steps", [(1, 1), (63, 2), (64, 8), (1000, 5), (70001, 8), (40000, 16), (600_000, 7)])
 @pytest.mark.parametrize("reduce_sum", [True, False])
 def test_register_resident_layer_kernel_equals_the_kernel_pair(rows, steps, reduce_sum, monkeypatch):
     """ctgcn_gru_layer_f32 (projection + recurrence in one kernel, both weight matrices in the register file, gi consumed from
@@ -265,7 +265,9 @@ def test_register_resident_layer_kernel_equals_the_kernel_pair(rows, steps, redu
     bias / LayerNorm, dense and strided outputs."""
     from ctgcn_amd import ops
     torch.manual_seed(rows + steps)
-    for bias, use_norm in ((True, True), (False, False)):
+    # (600 000 rows = 146 tiles per block: the first 8-wave build staged the summed rows in an x slot other waves were still
+    # reading — invisible at 70 001 rows, non-finite outputs at 1 M)
+    for bias, use_norm in ((True, True), (False, False)) if rows < 500_000 else ((True, True),):
         rnn = torch.nn.GRU(128, 128, 1, bias=bias, batch_first=True).to(DEV)
         norm = torch.nn.LayerNorm(128).to(DEV) if use_norm else None
         if norm is not None:

@@ -352,8 +352,9 @@ def main():
         flops = sum(m["rows"] * (2 * m["steps"] - 1) * 2.0 * 128 * 384 for _, m in fused)
         ms = sum(t for t, _ in fused)
         hbm = sum(m["rows"] * (m["steps"] * 512.0 + 512.0) for _, m in fused)       # H tile in, one output row out
-        fr = {"kernel": "gru_layer_h2_kernel (CoreDiffusion GRU: input projection + recurrence + sum over cores + LayerNorm in one kernel, "
-                        "both weight matrices resident in the register file, the projection consumed from the MFMA accumulators; fp16x2 split)",
+        fr = {"kernel": "gru_layer8_h2_kernel (CoreDiffusion GRU: input projection + recurrence + sum over cores + LayerNorm in one kernel, "
+                        "both weight matrices resident on the CU — registers + 120 KB of LDS, 8 waves — the projection consumed from the MFMA "
+                        "accumulators; fp16x2 split)",
               "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
               "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
               "compulsory_hbm_GBps": round(hbm / (ms * 1e-3) / 1e9, 1), "launches_timed": len(fused),

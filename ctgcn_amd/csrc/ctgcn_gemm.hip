@@ -9,11 +9,11 @@
 // mantissa bits; a product is x1·w1 + x1·w2 + x2·w1, three v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator (small terms
 // first), measured more accurate than an fp32 fma chain (tools/probes/mfma_f16x2_probe.hip).
 // Two kernels:
-//   split_rows_h2_kernel   fp32 rows -> per-row scale + the two fp16 planes [rows, Kp] (Kp = K rounded up to 32, zero padded).
+//   split_rows_h2_kernel   fp32 rows -> per-row scale + the two fp16 planes [rows, Kp] (Kp = K rounded up to 64, zero padded).
 //                          One pass over X (read 4 B, write 4 B per element); W's planes are rebuilt per call (tiny).
 //   gemm_h2_kernel         planes -> Y: 128 x 128 block tile, 4 waves (2 x 2) of 64 x 64, k steps of 32, operands staged
-//                          through LDS (double buffered, global loads of step k+1 in flight during the MFMAs of step k);
-//                          no VALU work in the main loop.  Epilogue: acc·sx[m]·sw[n] + bias[n], 128-byte row segments.
+//                          through LDS (two stages; LDS stores of step k+1 and global loads of step k+3 interleaved
+//                          with the MFMAs of step k).  Epilogue: acc·sx[m]·sw[n] + bias[n], 128-byte row segments.
 //   Block ids are remapped so that the N tiles of one M panel run on the same XCD (its L2 then serves the panel's re-reads).
 #include <cstdint>
 #include <cstdio>
@@ -149,18 +149,26 @@ struct GemmArgs {
     int32_t ntiles;
 };
 
-// WM = 32-row MFMA tiles per wave along M: 2 -> 128 x 128 block tile, LDS double buffered (one barrier per k step); the
-// template also builds 4 -> 256 x 128 block tile, LDS single buffered (128 x 64 wave tiles read 12 KB of operands per 24
-// MFMAs instead of 8 KB per 12), not instantiated: it needs the registers of the second load set.
-// Measured (rocprofv3 SQ counters, 435 180 x 500 x 384): 0.99 ms, matrix pipe busy 31 % of CU-busy cycles, waves waiting 47 % —
-// neither two blocks per CU (swizzled LDS), nor loads two k steps ahead, nor the taller wave tile moved it by more than 7 %.
-template <int WM>
+// 128 x 128 block tile, 4 waves (2 x 2) of 64 x 64 (2 x 2 MFMA tiles of 32 x 32), k steps of 32 = two MFMA k slabs of 16.
+// One wave is software-pipelined at half-step granularity (issue order pinned with sched_barrier; left alone the compiler
+// regroups the loop by instruction kind and reads, MFMAs, stores and loads of a k step run one after the other):
+//   phase A   request the fragments of slab 1 (tile kt); 12 MFMAs on slab 0, one ds_write of tile kt+1 (other LDS stage)
+//             behind each of the first eight;  barrier (tile kt+1 is complete, stage kt&1 will not be read again)
+//   phase B   request the fragments of slab 0 of tile kt+1 into the registers phase A just finished with; 12 MFMAs on
+//             slab 1, one global load of tile kt+3 behind each of the first eight.
+// One barrier per k step, two LDS stages, one set of fragment registers; global loads land 1.5 steps after their issue.
+// Where the time goes (435 180 x 500 x 384, kernel alone 0.94 ms; ingredients removed one at a time on the GPU): MFMAs
+// only 0.55 (of which the epilogue 0.18; the MFMA stream itself runs at the 1.93 PFLOP/s this chip sustains on
+// v_mfma_f32_32x32x16_f16 with real operands — tools/probes/mfma_peak_probe.hip — not the 2.5 of the data sheet),
+// + LDS traffic 0.70, + global loads 0.94; tile-contiguous global addresses instead of 64-byte row segments: 0.89.
+// Per k step and CU the matrix pipe needs ~1850 cycles, the LDS ~1350 (stores 830: ds_write_b128 moves 79 B/clk) and the
+// L1 fill ~1000: three resources of the same order that two resident blocks overlap only in part.  K = 500 is 16 k steps
+// per tile, so the prologue (exposed first loads) and the 64 KB epilogue of every block are a third of its life.
 __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 {
-    constexpr int BM = 64 * WM;
-    constexpr int ST = WM == 2 ? 2 : 1;                  // LDS stages
-    __shared__ _Float16 As[ST][2][BM][BKP];
-    __shared__ _Float16 Bs[ST][2][BN][BKP];
+    constexpr int BM = 128;
+    __shared__ _Float16 As[2][2][BM][BKP];                // [stage][plane][row][k]
+    __shared__ _Float16 Bs[2][2][BN][BKP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile order: consecutive block ids go round-robin over the 8 XCDs; the N tiles of M panel p all get p % 8
@@ -175,117 +183,111 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 
     // staging role: a plane tile is rows x 4 segments of 16 B; thread -> rows (tid >> 2) + 64 r, segment tid & 3
     const int lr = tid >> 2, ls = (tid & 3) * 8;
-    const int nk_ = a.Kp / BK;
-    // Two register sets: the tile of k step kt+1 waits in one while the loads of kt+2 / kt+3 are in flight in both — a global
-    // load issued only one k step (0.35 us of MFMAs) before its ds_write is still on its way (~1.5 us loaded latency).
-    h8v ga[2][2][WM], gb[2][2][2];           // [set][plane][row group]
-    auto gload = [&](int kt, int s) {
-        if (kt >= nk_) return;
-        const int64_t k = (int64_t)kt * BK + ls;
+    const int nk = a.Kp / BK;                             // even (Kp is a multiple of 64)
+    const _Float16 *gp[8];                                // the thread's 8 sources: A plane 0/1 rows lr, lr+64; B likewise
+    _Float16 *lp[8];                                      // and their LDS destinations in stage 0
 #pragma unroll
-        for (int r = 0; r < WM; ++r) {
-            const int64_t row = min(m0 + lr + 64 * r, a.M - 1);
-            ga[s][0][r] = *(const h8v *)(a.a1 + row * a.Kp + k);
-            ga[s][1][r] = *(const h8v *)(a.a2 + row * a.Kp + k);
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int64_t row = min((int64_t)n0 + lr + 64 * r, (int64_t)a.N - 1);
-            gb[s][0][r] = *(const h8v *)(a.b1 + row * a.Kp + k);
-            gb[s][1][r] = *(const h8v *)(a.b2 + row * a.Kp + k);
-        }
-    };
-    auto lstore = [&](int st, int s) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int r = 0; r < WM; ++r) *(h8v *)(&As[st][p][lr + 64 * r][swz(lr + 64 * r, tid & 3)]) = ga[s][p][r];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) *(h8v *)(&Bs[st][p][lr + 64 * r][swz(lr + 64 * r, tid & 3)]) = gb[s][p][r];
-        }
-    };
+    for (int r = 0; r < 2; ++r) {
+        const int64_t ra = min(m0 + lr + 64 * r, a.M - 1), rb = min((int64_t)n0 + lr + 64 * r, (int64_t)a.N - 1);
+        const int sw = swz(lr + 64 * r, tid & 3);
+        gp[r] = a.a1 + ra * a.Kp + ls;      lp[r] = &As[0][0][lr + 64 * r][sw];
+        gp[2 + r] = a.a2 + ra * a.Kp + ls;  lp[2 + r] = &As[0][1][lr + 64 * r][sw];
+        gp[4 + r] = a.b1 + rb * a.Kp + ls;  lp[4 + r] = &Bs[0][0][lr + 64 * r][sw];
+        gp[6 + r] = a.b2 + rb * a.Kp + ls;  lp[6 + r] = &Bs[0][1][lr + 64 * r][sw];
+    }
+    constexpr int A_STAGE = 2 * BM * BKP, B_STAGE = 2 * BN * BKP;          // halfs per LDS stage
+    // Two register sets of 8 x 16 B: tile kt+1 waits in one while tiles kt+2 / kt+3 are in flight.  Loads are never
+    // conditional: past the last k step the last tile is requested again and dropped (behind a branch the compiler cannot
+    // count the outstanding loads and waits for vmcnt(0) before every LDS store: the distance silently becomes one step).
+    h8v gr[2][8];
+    auto gload1 = [&](int kt, int s, int i) { gr[s][i] = *(const h8v *)(gp[i] + (int64_t)min(kt, nk - 1) * BK); };
+    auto lstore1 = [&](int st, int s, int i) { *(h8v *)(lp[i] + st * (i < 4 ? A_STAGE : B_STAGE)) = gr[s][i]; };
 
-    f16v acc[WM][2];
+    f16v acc[2][2];
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    const int nk = nk_;
-    gload(0, 0);
-    lstore(0, 0);
-    gload(1, 1);
-    gload(2, 0);
-    __syncthreads();
     // MFMA 32x32x16 operand layout: lane l holds row (l & 31), k = 8 (l >> 5) .. + 7 of a 32 x 16 slab
     const int fr = lane & 31;
-    auto compute = [&](int st) {
+    const _Float16 *fpa[2][2], *fpb[2][2];                // [slab][tile] -> plane 0 of stage 0 (plane 1: + BM*BKP, stage 1: + *_STAGE)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            h8v fa[WM][2], fb[2][2];                                      // [tile][plane]
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                const int row = wm * (32 * WM) + i * 32 + fr, off = swz(row, kk * 2 + (lane >> 5));
-                fa[i][0] = *(const h8v *)(&As[st][0][row][off]);
-                fa[i][1] = *(const h8v *)(&As[st][1][row][off]);
+        for (int t = 0; t < 2; ++t) {
+            const int ra = wm * 64 + t * 32 + fr, rb = wn * 64 + t * 32 + fr;
+            fpa[kk][t] = &As[0][0][ra][swz(ra, kk * 2 + (lane >> 5))];
+            fpb[kk][t] = &Bs[0][0][rb][swz(rb, kk * 2 + (lane >> 5))];
+        }
+    h8v fa[2][2][2], fb[2][2][2];                         // [slab][tile][plane]
+    auto fread = [&](int st, int kk) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fa[kk][t][p] = *(const h8v *)(fpa[kk][t] + st * A_STAGE + p * (BM * BKP));
+                fb[kk][t][p] = *(const h8v *)(fpb[kk][t] + st * B_STAGE + p * (BN * BKP));
             }
+    };
+    // the 12 MFMAs of one slab, small terms first (x1·w2, x2·w1, then x1·w1); after MFMA number t < 8 runs side(t)
+    auto slab = [&](int kk, auto side) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = wn * 64 + j * 32 + fr, off = swz(row, kk * 2 + (lane >> 5));
-                fb[j][0] = *(const h8v *)(&Bs[st][0][row][off]);
-                fb[j][1] = *(const h8v *)(&Bs[st][1][row][off]);
-            }
-            // small terms first: x1·w2, x2·w1, then x1·w1
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+        for (int t = 0; t < 12; ++t) {
+            const int term = t >> 2, i = (t >> 1) & 1, j = t & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][term == 1 ? 1 : 0], fb[kk][j][term == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
+            if (t < 8) side(t);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // one k step: compute from LDS stage st, then move the tile of step kt+1 (register set s) to LDS and request step kt+3 into s
+    // one k step: tile kt is in LDS stage kt & 1 and its slab-0 fragments are in registers; register set s holds tile kt+1
     auto step = [&](int kt, int s) {
-        const int st = ST == 2 ? (kt & 1) : 0;
-        compute(st);
-        if (ST == 2) {
-            if (kt + 1 < nk) lstore(st ^ 1, s);                           // stage st^1 was last read in iteration kt-1 (barrier since)
-            gload(kt + 3, s);
-            __syncthreads();
-        } else {
-            if (kt + 1 < nk) {
-                __syncthreads();                                          // everyone has read the stage
-                lstore(0, s);
-            }
-            gload(kt + 3, s);
-            __syncthreads();
-        }
+        const int st = kt & 1;
+        fread(st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        slab(0, [&](int t) { lstore1(st ^ 1, s, t); });   // stage st^1 was last read before the barrier of step kt-1
+        __syncthreads();
+        fread(st ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slab(1, [&](int t) { gload1(kt + 3, s, t); });
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, 1);                                                      // the tile of step kt+1 (odd) sits in set 1
-        if (kt + 1 < nk) step(kt + 1, 0);
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gload1(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lstore1(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gload1(1, 1, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gload1(2, 0, i);
+    __syncthreads();
+    fread(0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {                  // unrolled by two: each register set keeps its registers
+        step(kt, 1);
+        step(kt + 1, 0);
     }
 
-    // epilogue: D[i][j] of a 32 x 32 tile: lane l holds column j = l & 31, rows i = 8 (v / 4) + 4 (l >> 5) + v % 4
+    // epilogue: D[i][j] of a 32 x 32 tile: lane l holds column j = l & 31, rows i = 8 (v / 4) + 4 (l >> 5) + v % 4.
+    // The 32 row scales a lane needs are requested together (clamped row: no branch between the loads).
+    float sc[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+            sc[i][v] = a.sa[min(m0 + wm * 64 + i * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4), a.M - 1)];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + (lane & 31);
         if (n >= a.N) continue;
         const float sb = a.sb[n], bs = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int64_t m = m0 + wm * (32 * WM) + i * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
-                if (m < a.M) a.y[m * a.ldy + n] = fmaf(acc[i][j][v], a.sa[m] * sb, bs);
+                const int64_t m = m0 + wm * 64 + i * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
+                if (m < a.M) a.y[m * a.ldy + n] = fmaf(acc[i][j][v], sc[i][v] * sb, bs);
             }
         }
     }
@@ -300,7 +302,7 @@ extern "C" {
 size_t ctgcn_linear_workspace_bytes(int64_t rows, int32_t n_out, int32_t k)
 {
     if (rows < 0 || n_out < 0 || k < 0) return 0;
-    const size_t kp = align_up((size_t)k, BK);
+    const size_t kp = align_up((size_t)k, 2 * BK);        // an even number of k steps: the main loop is unrolled by two without a tail
     return align_up((size_t)rows * kp * 4 + (size_t)rows * 4, 256) + align_up((size_t)n_out * kp * 4 + (size_t)n_out * 4, 256) + 256;
 }
 
@@ -318,7 +320,7 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
     if (workspace_bytes < ctgcn_linear_workspace_bytes(rows, n_out, k))
         return ctgcn_set_error_(CTGCN_E_INVALID, "linear: workspace too small (ctgcn_linear_workspace_bytes)");
     hipStream_t st = (hipStream_t)stream;
-    const int32_t kp = (int32_t)align_up((size_t)k, BK);
+    const int32_t kp = (int32_t)align_up((size_t)k, 2 * BK);
     char *ws = (char *)workspace;
     _Float16 *a1 = (_Float16 *)ws, *a2 = a1 + (size_t)rows * kp;
     float *sa = (float *)(a2 + (size_t)rows * kp);
@@ -332,12 +334,10 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
     GemmArgs g{};
     g.M = rows; g.N = n_out; g.Kp = kp; g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.sa = sa; g.sb = sb; g.bias = bias; g.y = y; g.ldy = ldy;
     g.ntiles = (n_out + BN - 1) / BN;
-    constexpr int wm = 2;          // 128-row panels (a 256-row panel / 128 x 64 wave tile was measured: 7 % faster single-set, spills with two sets)
-    const int bm = 64 * wm;
-    g.mtiles = (rows + bm - 1) / bm;
+    g.mtiles = (rows + 127) / 128;
     const int64_t blocks = (g.mtiles + 7) / 8 * 8 * g.ntiles;
     if (blocks > 0x7fffffffLL) return ctgcn_set_error_(CTGCN_E_INVALID, "linear: too many tiles for one launch; split the rows");
-    hipLaunchKernelGGL(gemm_h2_kernel<wm>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gemm_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -305,7 +305,7 @@ def linear_split(x2d, weight, bias, out=None):
     n_out = weight.shape[0]
     if out is None:
         out = torch.empty(rows, n_out, dtype=torch.float32, device=x2d.device)
-    kp = -(-k // 32) * 32
+    kp = -(-k // 64) * 64
     chunk = max(128, (_LINEAR_WS_MAX // (kp * 4 + 4)) // 128 * 128)
     b = None if bias is None else bias.detach().contiguous()
     w = weight.detach()

@@ -91,8 +91,11 @@ def kcore_bytes(n, nnz):
     return 2 * (4 * (n + 1) + 4 * nnz) + 8 * n
 
 
-def agg_kernel_name(d):
+def agg_kernel_name(d, split=False):
     chunks = (d + 3) // 4
+    if split:
+        return ("agg_fwd_split_kernel<%d,4> (CoreDiffusion fused nested-core SpMM, d=%d, one pass; rows leave as the split GEMM's fp16 "
+                "operand planes + row scales, 4d B per row like the fp32 rows they replace)" % (-(-chunks // 64), d))
     lpr = 8
     while lpr < 64 and lpr < chunks:
         lpr <<= 1
@@ -300,7 +303,7 @@ def main():
         avg_bytes = sum(algorithmic_bytes(m["n"], m["nnz"], m["K"], m["d"]) for _, m in group) / len(group)
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
         rec = pmc.get(args.workload, {}).get(str(world)) if d == 128 else None
-        return {"kernel": agg_kernel_name(d), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        return {"kernel": agg_kernel_name(d, bool(group[0][1].get("split"))), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec["hbm_bytes_per_launch"] if rec else None,
                 "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/agg_bench.py on the same "
                                    "workload (separate run, not this one)") if rec else None,

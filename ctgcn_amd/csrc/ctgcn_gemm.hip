@@ -55,12 +55,15 @@ __device__ __forceinline__ void h2_scale(float m, float &s, float &inv_s)
 // VEC: rows are 16-byte aligned and K % 4 == 0 (float4 loads); otherwise scalar loads (coalesced 4-byte, e.g. K = 1737).
 template <bool VEC>
 __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_t K, int32_t Kp, const float *__restrict__ x, int64_t ldx,
-                                                             _Float16 *__restrict__ p1, _Float16 *__restrict__ p2, float *__restrict__ scale)
+                                                             _Float16 *__restrict__ p1, _Float16 *__restrict__ p2, float *__restrict__ scale,
+                                                             const int32_t *__restrict__ group_map, int32_t group)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *src = x + row * ldx;
+    // destination row: the same, or (hub rows of the fused aggregation) group g of `group` consecutive source rows -> group group_map[g]
+    const int64_t drow = group_map ? (int64_t)group_map[row / group] * group + row % group : row;
     float m = 0.f;
     constexpr int HOLD = 8;                               // float4 per lane kept in registers: rows up to 2048 columns are read ONCE
     f4v keep[HOLD];
@@ -86,8 +89,8 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     float s, inv;
     h2_scale(m, s, inv);
-    if (lane == 0) scale[row] = s;
-    _Float16 *d1 = p1 + row * Kp, *d2 = p2 + row * Kp;
+    if (lane == 0) scale[drow] = s;
+    _Float16 *d1 = p1 + drow * Kp, *d2 = p2 + drow * Kp;
     if (VEC && held) {
 #pragma unroll
         for (int i = 0; i < HOLD; ++i) {
@@ -306,17 +309,36 @@ size_t ctgcn_linear_workspace_bytes(int64_t rows, int32_t n_out, int32_t k)
     return align_up((size_t)rows * kp * 4 + (size_t)rows * 4, 256) + align_up((size_t)n_out * kp * 4 + (size_t)n_out * 4, 256) + 256;
 }
 
-int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
-                     float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream)
+// planes of `rows` fp32 rows: [optionally remapped] split_rows launch
+static void launch_split(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, _Float16 *p1, _Float16 *p2, float *scale,
+                         const int32_t *group_map, int32_t group, hipStream_t st)
 {
-    if (rows < 0 || n_out < 1 || k < 1 || ldx < k || ldw < k || ldy < n_out)
+    const bool vec = !(k & 3) && !(ldx & 3) && !(reinterpret_cast<uintptr_t>(x) & 15u);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (vec) hipLaunchKernelGGL(split_rows_h2_kernel<true>, grid, dim3(256), 0, st, rows, k, kp, x, ldx, p1, p2, scale, group_map, group);
+    else hipLaunchKernelGGL(split_rows_h2_kernel<false>, grid, dim3(256), 0, st, rows, k, kp, x, ldx, p1, p2, scale, group_map, group);
+}
+
+// internal (ctgcn_hip.hip: hub rows of ctgcn_core_aggregate_split_f32): source row r -> plane row group_map[r / group] * group + r % group
+int ctgcn_split_rows_mapped_(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, void *p1, void *p2, float *scale,
+                             const int32_t *group_map, int32_t group, void *stream)
+{
+    if (rows <= 0) return CTGCN_OK;
+    launch_split(rows, k, kp, x, ldx, (_Float16 *)p1, (_Float16 *)p2, scale, group_map, group, (hipStream_t)stream);
+    GEMM_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+// x == nullptr: the A planes and scales are already in the workspace (ctgcn_core_aggregate_split_f32 wrote them)
+static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
+                       float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (rows < 0 || n_out < 1 || k < 1 || (x && ldx < k) || ldw < k || ldy < n_out)
         return ctgcn_set_error_(CTGCN_E_INVALID, "linear: bad sizes");
     if (rows == 0) return CTGCN_OK;
-    if (!x || !w || !y || !workspace) return ctgcn_set_error_(CTGCN_E_INVALID, "linear: null pointer");
+    if (!w || !y || !workspace) return ctgcn_set_error_(CTGCN_E_INVALID, "linear: null pointer");
     if ((reinterpret_cast<uintptr_t>(x) & 3u) || (reinterpret_cast<uintptr_t>(w) & 3u) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return ctgcn_set_error_(CTGCN_E_INVALID, "linear: x / w must be 4-byte aligned, workspace 256-byte aligned");
-    const bool vx = !(k & 3) && !(ldx & 3) && !(reinterpret_cast<uintptr_t>(x) & 15u);
-    const bool vw = !(k & 3) && !(ldw & 3) && !(reinterpret_cast<uintptr_t>(w) & 15u);
     if (workspace_bytes < ctgcn_linear_workspace_bytes(rows, n_out, k))
         return ctgcn_set_error_(CTGCN_E_INVALID, "linear: workspace too small (ctgcn_linear_workspace_bytes)");
     hipStream_t st = (hipStream_t)stream;
@@ -327,10 +349,8 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
     char *wsb = ws + align_up((size_t)rows * kp * 4 + (size_t)rows * 4, 256);
     _Float16 *b1 = (_Float16 *)wsb, *b2 = b1 + (size_t)n_out * kp;
     float *sb = (float *)(b2 + (size_t)n_out * kp);
-    if (vx) hipLaunchKernelGGL(split_rows_h2_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rows, k, kp, x, ldx, a1, a2, sa);
-    else hipLaunchKernelGGL(split_rows_h2_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, rows, k, kp, x, ldx, a1, a2, sa);
-    if (vw) hipLaunchKernelGGL(split_rows_h2_kernel<true>, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, st, (int64_t)n_out, k, kp, w, ldw, b1, b2, sb);
-    else hipLaunchKernelGGL(split_rows_h2_kernel<false>, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, st, (int64_t)n_out, k, kp, w, ldw, b1, b2, sb);
+    if (x) launch_split(rows, k, kp, x, ldx, a1, a2, sa, nullptr, 1, st);
+    launch_split(n_out, k, kp, w, ldw, b1, b2, sb, nullptr, 1, st);
     GemmArgs g{};
     g.M = rows; g.N = n_out; g.Kp = kp; g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.sa = sa; g.sb = sb; g.bias = bias; g.y = y; g.ldy = ldy;
     g.ntiles = (n_out + BN - 1) / BN;
@@ -340,6 +360,19 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
     hipLaunchKernelGGL(gemm_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
+}
+
+int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
+                     float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (rows > 0 && !x) return ctgcn_set_error_(CTGCN_E_INVALID, "linear: null pointer");
+    return linear_impl(rows, n_out, k, x, ldx, w, ldw, bias, y, ldy, workspace, workspace_bytes, stream);
+}
+
+int ctgcn_linear_presplit_f32(int64_t rows, int32_t n_out, int32_t k, const float *w, int64_t ldw, const float *bias, float *y, int64_t ldy,
+                              void *workspace, size_t workspace_bytes, void *stream)
+{
+    return linear_impl(rows, n_out, k, nullptr, 0, w, ldw, bias, y, ldy, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -86,6 +86,7 @@ struct AggArgs {
     int32_t n_long;
     int32_t long_thresh;
     int32_t hub_groups;    // lane groups of the hub block that share one long row
+    int32_t hub_compact;   // fwd hub kernel: write hub row i of long_rows to out row i (a compact scratch) instead of its own row
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(HUB_THREADS) void agg_fwd_hub_kernel(const AggArgs 
     const bool nested = (a.flags & CTGCN_F_NESTED) != 0;
     const uint8_t *__restrict__ slot = a.slot;
     const float *__restrict__ X = a.src;
-    float *__restrict__ outrow = a.out + row * a.out_ld;
+    float *__restrict__ outrow = a.out + (a.hub_compact ? (int64_t)blockIdx.x : row) * a.out_ld;
 
     for (int pass = 0; pass < a.passes; ++pass) {
         const int ch = pass * LPR + lig;
@@ -1197,6 +1198,121 @@ __device__ __forceinline__ void h2_split(float xs, _Float16 &a, _Float16 &b)    
     a = (_Float16)xs;
     b = (_Float16)((xs - (float)a) * (float)RS);
 }
+// ------------------------------------------------------------------------------------------------
+// agg_fwd_split_kernel: the CoreDiffusion aggregation whose consumer is the split GEMM (ctgcn_gemm.hip) — the GRU input
+// projection of a layer with d_in != 128.  Same recurrence as agg_fwd_kernel, but ONE wave holds the whole feature row
+// (CH float4 chunks per lane, d <= 256 CH), so when a slot closes the row's maximum is a wave reduction away and the row
+// leaves as the GEMM's operand: per-row power-of-two scale + two fp16 planes [n K, kp] (exactly what split_rows_h2_kernel
+// would make of the fp32 row, bit for bit).  The fp32 H [n, K, d] is never written and never read back: per (row, slot)
+// 4 d bytes written instead of 4 d written + 4 d read + 4 d written, and one pass over the entries instead of d / 256.
+// ------------------------------------------------------------------------------------------------
+template <int CH, int U>
+__global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2,
+                                                            float *__restrict__ scale, int32_t kp)
+{
+    const int lig = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n) return;
+    const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    if (end - start > a.long_thresh) return;          // hub row: agg_fwd_hub_kernel into the compact scratch, split afterwards
+    const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0;
+    const bool relu = (a.flags & CTGCN_F_RELU) != 0;
+    const bool nested = (a.flags & CTGCN_F_NESTED) != 0;
+    const uint8_t *__restrict__ slot = a.slot;
+    const float *__restrict__ X = a.src;
+    bool live[CH];
+    int64_t foff[CH];
+    f4 R[CH], P[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int ch = c * 64 + lig;
+        live[c] = ch < a.chunks;
+        foff[c] = live[c] ? (int64_t)ch * 4 : 0;      // dead lanes read chunk 0 (valid memory): every load unconditional
+        R[c] = P[c] = vzero<4>();
+        if (self && live[c]) R[c] = *(const f4 *)(X + row * a.ldsrc + foff[c]);
+    }
+    int cur = 0;
+
+    auto close_slot = [&]() {
+        f4 v[CH];
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            R[c] += P[c];
+            if (!nested) P[c] = vzero<4>();
+            v[c] = relu ? vmax0(R[c]) : R[c];
+            if (!live[c]) v[c] = vzero<4>();
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].y)), fmaxf(fabsf(v[c].z), fabsf(v[c].w))));
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float s, inv;
+        h2_scale(m, s, inv);
+        const int64_t orow = row * a.K + cur;
+        if (lig == 0) scale[orow] = s;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int k = (c * 64 + lig) * 4;
+            if (k < kp) {                             // columns [d, kp) are written as zeros
+                const float xs[4] = {v[c].x * inv, v[c].y * inv, v[c].z * inv, v[c].w * inv};
+                h4v h1, h2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h1[j] = (_Float16)xs[j];
+                    h2[j] = (_Float16)(xs[j] - (float)h1[j]);
+                }
+                __builtin_nontemporal_store(h1, (h4v *)(p1 + orow * kp + k));
+                __builtin_nontemporal_store(h2, (h4v *)(p2 + orow * kp + k));
+            }
+        }
+        ++cur;
+    };
+
+    for (int base = start; base < end; base += 64) {
+        const int my = base + lig;
+        int c = 0, s = 0;
+        float w = 0.f;
+        if (my < end) {
+            c = a.col[my];
+            w = a.val[my];
+            s = slot ? (int)slot[my] : 0;
+        }
+        const int cnt = min(64, end - base);
+        int j = 0;
+        for (; j + U <= cnt; j += U) {
+            f4 xv[U][CH];
+            float wj[U];
+            int sj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int cj = __shfl(c, j + u, 64);
+                wj[u] = __shfl(w, j + u, 64);
+                sj[u] = __shfl(s, j + u, 64);
+#pragma unroll
+                for (int q = 0; q < CH; ++q) xv[u][q] = *(const f4 *)(X + (int64_t)cj * a.ldsrc + foff[q]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                while (cur < sj[u]) close_slot();
+#pragma unroll
+                for (int q = 0; q < CH; ++q) P[q] = vfma(wj[u], xv[u][q], P[q]);
+            }
+        }
+        for (; j < cnt; ++j) {
+            const int cj = __shfl(c, j, 64);
+            const float w1 = __shfl(w, j, 64);
+            const int s1 = __shfl(s, j, 64);
+            f4 x1[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) x1[q] = *(const f4 *)(X + (int64_t)cj * a.ldsrc + foff[q]);
+            while (cur < s1) close_slot();
+#pragma unroll
+            for (int q = 0; q < CH; ++q) P[q] = vfma(w1, x1[q], P[q]);
+        }
+    }
+    while (cur < a.K) close_slot();
+}
+
 // 8 consecutive fp32 weights, already multiplied by 1/s, -> two fp16x8 fragments
 template <int RS>
 __device__ __forceinline__ void h2_split_x8(const float *src, float inv_s, h8v &s0, h8v &s1)
@@ -2687,38 +2803,45 @@ __global__ __launch_bounds__(512, 2) void gru_dw_x3_kernel(const DwArgs a)
 }
 
 // transpose_bias_kernel: out[i][j] = w[j][i] + bias[j] — Linear applied to one-hot (identity) node features is just Wᵀ + b
-// (reference helper.py:161-172 builds the identity, layers.py:95-106 multiplies by it).  32 x 128 tiles through LDS:
-// 128-byte reads along i, 512-byte rows written.  HBM-bound: 4 B read + 4 B written per element.
+// (reference helper.py:161-172 builds the identity, layers.py:95-106 multiplies by it).  One 64 x 64 tile per block through
+// LDS: 256-byte reads along i, 256-byte writes along j, 16 bytes per lane both ways (VEC; otherwise element by element at
+// the edges and for unaligned rows).  HBM-bound: 4 B read + 4 B written per element.
+template <bool VEC>
 __global__ __launch_bounds__(256) void transpose_bias_kernel(int64_t n, int d, const float *__restrict__ w, int64_t ldw,
                                                              const float *__restrict__ bias, float *__restrict__ out, int64_t ldo)
 {
-    __shared__ float tile[128][33];
-    const int tid = threadIdx.x;
-    const int64_t i0 = (int64_t)blockIdx.x * 32;
-    for (int j0 = 0; j0 < d; j0 += 128) {
+    __shared__ float tile[64][65];                        // [j][i]
+    const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const int j0 = blockIdx.y * 64;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = (tid >> 3) + 32 * k, i4 = (tid & 7) * 4;
-            f4v v = f4v{0.f, 0.f, 0.f, 0.f};
-            if (j0 + j < d) {
-                const float *src = w + (int64_t)(j0 + j) * ldw + i0 + i4;
-                if (i0 + i4 + 3 < n && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0)) v = *(const f4v *)src;
-                else
-                    for (int q = 0; q < 4; ++q) if (i0 + i4 + q < n) v[q] = src[q];
-            }
-            tile[j][i4] = v[0]; tile[j][i4 + 1] = v[1]; tile[j][i4 + 2] = v[2]; tile[j][i4 + 3] = v[3];
+    for (int k = 0; k < 4; ++k) {
+        const int j = r + 16 * k;
+        f4v v = f4v{0.f, 0.f, 0.f, 0.f};
+        if (j0 + j < d) {
+            const float *src = w + (int64_t)(j0 + j) * ldw + i0 + c4;
+            if (VEC && i0 + c4 + 3 < n) v = *(const f4v *)src;
+            else
+                for (int q = 0; q < 4; ++q) if (i0 + c4 + q < n) v[q] = src[q];
         }
-        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = (tid >> 5) + 8 * k, j = (tid & 31) * 4;
-            if (i0 + i < n) {
-                float *dst = out + (i0 + i) * ldo + j0 + j;
-                for (int q = 0; q < 4; ++q)
-                    if (j0 + j + q < d) dst[q] = tile[j + q][i] + (bias ? bias[j0 + j + q] : 0.f);
-            }
-        }
-        __syncthreads();
+        for (int q = 0; q < 4; ++q) tile[j][c4 + q] = v[q];
+    }
+    __syncthreads();
+    f4v b = f4v{0.f, 0.f, 0.f, 0.f};
+    if (bias)
+        for (int q = 0; q < 4; ++q) if (j0 + c4 + q < d) b[q] = bias[j0 + c4 + q];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = r + 16 * k;
+        if (i0 + i >= n) continue;
+        f4v v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tile[c4 + q][i] + b[q];
+        float *dst = out + (i0 + i) * ldo + j0 + c4;
+        if (VEC && j0 + c4 + 3 < d) __builtin_nontemporal_store(v, (f4v *)dst);
+        else
+            for (int q = 0; q < 4; ++q) if (j0 + c4 + q < d) dst[q] = v[q];
     }
 }
 
@@ -2738,6 +2861,8 @@ extern "C" size_t ctgcn_ingest_workspace_bytes_(int64_t n, int64_t m);   // ctgc
 
 // shared with the other translation units of the library (not part of the public header)
 extern "C" int ctgcn_set_error_(int code, const char *msg) { return fail(code, "%s", msg); }
+extern "C" int ctgcn_split_rows_mapped_(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, void *p1, void *p2, float *scale,
+                                        const int32_t *group_map, int32_t group, void *stream);   // ctgcn_gemm.hip
 
 extern "C" {
 
@@ -2762,7 +2887,11 @@ int ctgcn_transpose_bias_f32(int64_t n, int32_t d, const float *w, int64_t ldw, 
     if (n < 0 || d < 1 || ldw < n || ldo < d) return fail(CTGCN_E_INVALID, "transpose_bias: bad sizes n=%lld d=%d", (long long)n, d);
     if (n == 0) return CTGCN_OK;
     if (!w || !out) return fail(CTGCN_E_INVALID, "transpose_bias: null pointer");
-    hipLaunchKernelGGL(transpose_bias_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, n, d, w, ldw, bias, out, ldo);
+    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((d + 63) / 64));
+    if (!(ldw & 3) && !(ldo & 3) && aligned16(w) && aligned16(out))
+        hipLaunchKernelGGL(transpose_bias_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, n, d, w, ldw, bias, out, ldo);
+    else
+        hipLaunchKernelGGL(transpose_bias_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, n, d, w, ldw, bias, out, ldo);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }
@@ -2802,6 +2931,72 @@ int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t
     if (n_long > 0 && long_threshold < 1) return fail(CTGCN_E_INVALID, "core_aggregate: long_threshold must be >= 1");
     const bool v4 = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(X) && aligned16(H);
     return launch_agg<true>(a, v4, (hipStream_t)stream);
+}
+
+size_t ctgcn_core_aggregate_split_workspace_bytes(int64_t n_rows, int32_t d, int32_t K, int32_t n_out, int32_t n_long)
+{
+    if (n_rows < 0 || d < 1 || K < 1 || n_out < 1 || n_long < 0) return 0;
+    return ctgcn_linear_workspace_bytes(n_rows * K, n_out, d) + ((size_t)n_long * K * d * 4 + 255) / 256 * 256;
+}
+
+int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr, const int32_t *col_idx,
+                                   const float *val, const uint8_t *slot, const float *X, int64_t ldx, uint32_t flags,
+                                   const int32_t *long_rows, int32_t n_long, int32_t long_threshold, int32_t n_out,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (n_rows < 0 || d <= 0 || ldx < d || n_out < 1) return fail(CTGCN_E_INVALID, "core_aggregate_split: bad sizes n=%lld d=%d ldx=%lld", (long long)n_rows, d, (long long)ldx);
+    if (K < 1 || K > CTGCN_MAX_SLOTS) return fail(CTGCN_E_INVALID, "core_aggregate_split: K=%d outside [1,%d]", K, CTGCN_MAX_SLOTS);
+    if (n_rows == 0) return CTGCN_OK;
+    if (!row_ptr || !X || !workspace) return fail(CTGCN_E_INVALID, "core_aggregate_split: null pointer");
+    if (!slot && K != 1) return fail(CTGCN_E_INVALID, "core_aggregate_split: slot tags required when K > 1");
+    if ((d & 3) || d > 512 || (ldx & 3) || !aligned16(X) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
+        return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: needs d %% 4 == 0, d <= 512, 16-byte aligned rows, 256-byte aligned workspace");
+    if (n_long < 0 || (n_long > 0 && (!long_rows || long_threshold < 1))) return fail(CTGCN_E_INVALID, "core_aggregate_split: bad hub row list");
+    if (workspace_bytes < ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, K, n_out, n_long))
+        return fail(CTGCN_E_WORKSPACE, "core_aggregate_split: workspace too small (ctgcn_core_aggregate_split_workspace_bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = n_rows * K;
+    const int32_t kp = (d + 63) / 64 * 64;                // the k padding of ctgcn_linear_f32
+    _Float16 *p1 = (_Float16 *)workspace, *p2 = p1 + (size_t)rows * kp;
+    float *scale = (float *)(p2 + (size_t)rows * kp);
+    float *hub = (float *)((char *)workspace + ctgcn_linear_workspace_bytes(rows, n_out, d));
+    AggArgs a{};
+    a.n = n_rows; a.d = d; a.K = K;
+    a.row_ptr = row_ptr; a.col = col_idx; a.val = val; a.slot = slot;
+    a.src = X; a.ldsrc = ldx; a.self = nullptr; a.out = hub; a.out_ld = (int64_t)K * d;
+    a.flags = flags; a.accumulate = 0;
+    a.long_rows = long_rows; a.n_long = n_long; a.long_thresh = long_threshold;
+    const AggPlan p = plan_for(d, true);
+    a.chunks = p.chunks;
+    a.passes = p.passes;
+    if (a.n_long > 0 && (size_t)K * p.lpr * 16 > HUB_LDS_BUDGET) a.n_long = 0;      // K*d too large for the hub kernel's LDS partials
+    if (a.n_long <= 0) { a.n_long = 0; a.long_thresh = 0x7fffffff; }
+    const int64_t blocks = (n_rows + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: grid too large");
+    if (p.chunks <= 64) hipLaunchKernelGGL((agg_fwd_split_kernel<1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp);
+    else hipLaunchKernelGGL((agg_fwd_split_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp);
+    HIP_TRY(hipGetLastError());
+    if (a.n_long > 0) {
+        // hub rows: the block-per-row kernel writes fp32 rows into the compact scratch, then they are split like any other rows
+        a.hub_compact = 1;
+        const size_t per_group = (size_t)K * p.lpr * 16;
+        int G = HUB_THREADS / p.lpr;
+        while (G > 1 && per_group * G > HUB_LDS_BUDGET) --G;
+        a.hub_groups = G;
+        const size_t lds = per_group * G;
+#define HUBCASE(L)                                                                                                                        \
+        if (p.lpr == L) {                                                                                                                 \
+            auto k = agg_fwd_hub_kernel<4, L, 4>;                                                                                        \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(k, dim3((unsigned)a.n_long), dim3(HUB_THREADS), lds, st, a);                                              \
+        }
+        HUBCASE(8) else HUBCASE(16) else HUBCASE(32) else HUBCASE(64)
+#undef HUBCASE
+        HIP_TRY(hipGetLastError());
+        const int rc = ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, long_rows, K, stream);
+        if (rc != CTGCN_OK) return rc;
+    }
+    return CTGCN_OK;
 }
 
 int ctgcn_core_aggregate_bwd_prep_f32(int64_t n_rows, int32_t d, int32_t K, const float *dH,

@@ -110,6 +110,12 @@ class CoreDiffusion(nn.Module):
 
     def forward(self, x, adj_list, out=None):
         """out (optional, inference): a [N, output_dim] view (unit column stride) that receives the result."""
+        if torch.is_tensor(x) and not x.is_sparse and x.is_cuda:
+            adj = as_core_adj(adj_list, x.device)
+            if ops.aggregate_split_ok(self.rnn, x, adj):
+                # inference, GRU input projection on the split GEMM (d_in != 128): the aggregation writes the GEMM's fp16 operand
+                # planes, the fp32 [N, K, input_dim] tensor is never materialised
+                return ops.core_diffusion_split(x, adj, self.rnn, self.norm, out=out)
         seq = self.aggregate(x, adj_list)            # [batch = N, seq = K, feat]
         return rnn_reduce_norm(self.rnn, self.norm, seq, reduce_sum=True, out=out)
 

@@ -404,6 +404,64 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
     return out
 
 
+def aggregate_split_enabled():
+    """CTGCN_AGG_SPLIT=0 keeps aggregation and GRU input projection apart (fp32 H in between) for A/B runs."""
+    import os
+    return linear_split_enabled() and os.environ.get("CTGCN_AGG_SPLIT", "1") != "0"
+
+
+def aggregate_split_ok(rnn, x, adj):
+    """Inference through a CoreDiffusion layer whose GRU input projection runs as the split GEMM (d_in != 128): the aggregation
+    kernel can hand the GEMM its fp16 planes directly (ctgcn_core_aggregate_split_f32)."""
+    if not aggregate_split_enabled() or x.dim() != 2 or not gru_fused_ok(rnn, x) or x.shape[0] != adj.n or x.device != adj.device:
+        return False
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in rnn.parameters())):
+        return False
+    d, hid = x.shape[1], rnn.hidden_size
+    if d == 128 or d % 4 or d < 32 or d > 512 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or adj.K < 1 or adj.n < 1:
+        return False
+    if adj.n * adj.K * (-(-d // 64) * 64 * 4 + 4) > _LINEAR_WS_MAX:
+        return False
+    return len(_row_chunks(_lib.load(), adj.n, adj.K, hid)) == 1
+
+
+def core_diffusion_split(x, adj, rnn, norm, out=None):
+    """LayerNorm(sum_k GRU(relu(cumulative A_k x))_k) — CoreDiffusion.forward (layers.py:41-62) for inference with d_in != 128:
+    aggregation -> fp16 planes (no fp32 H), split GEMM -> gate pre-activations, recurrence + sum + LayerNorm kernel."""
+    lib = _lib.load()
+    n, d = x.shape
+    K, hid = adj.K, rnn.hidden_size
+    n_out = 3 * hid
+    if out is None:
+        out = torch.empty(n, hid, dtype=torch.float32, device=x.device)
+    elif not (out.shape == (n, hid) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) % 2 == 0
+              and out.stride(0) >= hid and out.device == x.device):
+        raise ValueError("core_diffusion_split: out must be a [rows, %d] fp32 view with unit column stride" % hid)
+    bias, b_hn = _gru_bias(rnn, hid)
+    w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous()
+    ln_w = None if norm is None else norm.weight
+    ln_b = None if norm is None else norm.bias
+    eps = 0.0 if norm is None else float(norm.eps)
+    flags = adj.flags | _lib.F_RELU
+    with torch.cuda.device(x.device):
+        long_rows = adj.long_rows()
+        n_long = 0 if long_rows is None else long_rows.numel()
+        ws_bytes = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, d, K, n_out, n_long))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        with _timed("agg_fwd", n=n, d=d, K=K, nnz=adj.nnz, split=True):
+            check(lib.ctgcn_core_aggregate_split_f32(n, d, K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x), x.stride(0),
+                                                     flags, ptr(long_rows), n_long, adj.LONG_ROW, n_out, ptr(ws), ws_bytes, _stream()),
+                  "ctgcn_core_aggregate_split_f32")
+        gi_buf = _gi_buffer(n, K, hid, x.device)
+        with _timed("linear_split", rows=n * K, k=d, n_out=n_out, presplit=True):
+            check(lib.ctgcn_linear_presplit_f32(n * K, n_out, d, ptr(w_ih), w_ih.stride(0), ptr(bias), ptr(gi_buf), n_out, ptr(ws), ws_bytes,
+                                                _stream()), "ctgcn_linear_presplit_f32")
+        with _timed("gru_seq", rows=n, steps=K):
+            check(lib.ctgcn_gru_seq_f32(n, K, hid, ptr(gi_buf), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps, 1, ptr(out), out.stride(0),
+                                        None, forward_split_mode(), 0, _stream()), "ctgcn_gru_seq_f32")
+    return out
+
+
 def _accumulate_tn(out, a2d, b2d):
     """out[M,N] += a2d[R,M]^T @ b2d[R,N] for R >> M,N (weight gradients: R = rows*steps).  A plain TN GEMM with a
     384x128 output only fills a few dozen workgroups; splitting R into S batches (strided batched GEMM, no copies)

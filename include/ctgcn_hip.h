@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 10
+#define CTGCN_ABI_VERSION 11
 
 enum {
     CTGCN_OK = 0,
@@ -222,6 +222,26 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
 size_t ctgcn_linear_workspace_bytes(int64_t rows, int32_t n_out, int32_t k);
 int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
                      float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * CoreDiffusion aggregation (ctgcn_core_aggregate_f32: layers.py:41-48,58) whose only consumer is the GRU input projection of a
+ * layer with d_in != 128 (layers.py:59, nn.GRU(input_size = hid_dim = 500, ...)): instead of the fp32 H [n_rows, K, d] the kernel
+ * writes what ctgcn_linear_f32 would make of it - the per-row scales and the two fp16 planes of the n_rows*K operand rows
+ * (row = node*K + core) - straight into that GEMM's workspace, bit-identical to aggregate + ctgcn_linear_f32, without the
+ * write + read + write of the fp32 intermediate.  Inference only (nothing is kept for a backward pass).
+ *   d % 4 == 0, d <= 512, X 16-byte aligned, ldx % 4 == 0.
+ *   workspace: ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, K, n_out, n_long) bytes, 256-byte aligned; n_out is the
+ *   width of the projection that follows (its weight planes share the workspace); n_long hub rows pass through an fp32
+ *   scratch at the end of it.
+ * ctgcn_linear_presplit_f32(rows = n_rows*K, n_out, k = d, w, ...) then runs the GEMM on that workspace.
+ */
+size_t ctgcn_core_aggregate_split_workspace_bytes(int64_t n_rows, int32_t d, int32_t K, int32_t n_out, int32_t n_long);
+int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr, const int32_t *col_idx,
+                                   const float *val, const uint8_t *slot, const float *X, int64_t ldx, uint32_t flags,
+                                   const int32_t *long_rows, int32_t n_long, int32_t long_threshold, int32_t n_out,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+int ctgcn_linear_presplit_f32(int64_t rows, int32_t n_out, int32_t k, const float *w, int64_t ldw, const float *bias, float *y, int64_t ldy,
+                              void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Backward of the recurrence above (autograd of nn.GRU, layers.py:59 / models.py:249).  Inputs: the saved gates and

@@ -1,0 +1,111 @@
+"""ctgcn_core_aggregate_split_f32 + ctgcn_linear_presplit_f32 (the aggregation hands the split GEMM its fp16 planes) against the
+separate kernels (fp32 H, then ctgcn_linear_f32): bit-identical, including hub rows, padded widths and non-nested lists."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _layer(d, seed):
+    from ctgcn_amd import CoreDiffusion
+    torch.manual_seed(seed)
+    return CoreDiffusion(d, 128).to(_dev()).eval()
+
+
+def _nested_adj(n, m, max_core, seed, hub=0, with_mats=False):
+    from ctgcn_amd import CoreAdj
+    from ctgcn_amd.utils import symmetric_csr_from_rows
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+    if hub:
+        src = np.concatenate([np.zeros(hub, np.int64), src])
+        dst = np.concatenate([rng.choice(np.arange(1, n), hub, replace=False), dst])
+    csr = symmetric_csr_from_rows(src, dst, rng.integers(1, 5, len(src)) * 0.5, n)
+    kept = O.core_adj_list([O.kcore_matrices(csr)], 0, 1, 1, max_core=max_core)[0]
+    adj = CoreAdj.from_matrices(kept, device=_dev())
+    return (adj, kept) if with_mats else adj
+
+
+def _both(layer, x, adj, monkeypatch, out_view=False):
+    from ctgcn_amd import ops
+    names = []
+    ops.set_launch_timer(lambda name, s, e, meta: names.append((name, dict(meta))))
+    try:
+        with torch.no_grad():
+            monkeypatch.setenv("CTGCN_AGG_SPLIT", "1")
+            if out_view:
+                buf = torch.zeros(x.shape[0], 3, 128, device=x.device)
+                fused = layer(x, adj, out=buf[:, 1])
+                assert fused.data_ptr() == buf[:, 1].data_ptr() and float(buf[:, 0].abs().max()) == 0 and float(buf[:, 2].abs().max()) == 0
+            else:
+                fused = layer(x, adj)
+            used = [m for n_, m in names if n_ == "agg_fwd"]
+            assert used and used[-1].get("split"), "the fused aggregation did not run"
+            names.clear()
+            monkeypatch.setenv("CTGCN_AGG_SPLIT", "0")
+            plain = layer(x, adj)
+            assert not any(m.get("split") for n_, m in names if n_ == "agg_fwd")
+    finally:
+        ops.set_launch_timer(None)
+    torch.cuda.synchronize()
+    return fused, plain
+
+
+@pytest.mark.parametrize("d,n,m,max_core", [(500, 3000, 24000, 6), (64, 2000, 9000, 3), (256, 1500, 12000, 5), (260, 1200, 9000, 4),
+                                            (36, 900, 5000, 2), (512, 700, 6000, 8), (500, 5, 4, 1)])
+def test_fused_layer_is_bit_identical_to_the_separate_kernels(d, n, m, max_core, monkeypatch):
+    adj = _nested_adj(n, m, max_core, seed=d + n)
+    layer = _layer(d, d)
+    x = torch.randn(n, d, device=_dev()) * torch.rand(n, 1, device=_dev()).exp()
+    fused, plain = _both(layer, x, adj, monkeypatch)
+    assert torch.isfinite(fused).all()
+    assert torch.equal(fused, plain)
+
+
+def test_fused_layer_with_hub_rows_and_strided_output(monkeypatch):
+    from ctgcn_amd import CoreAdj
+    old = CoreAdj.LONG_ROW
+    try:
+        CoreAdj.LONG_ROW = 12
+        adj = _nested_adj(4000, 20000, 5, seed=3, hub=2500)
+        assert adj.long_rows() is not None and adj.long_rows().numel() > 10
+        layer = _layer(500, 1)
+        x = torch.randn(4000, 500, device=_dev())
+        fused, plain = _both(layer, x, adj, monkeypatch, out_view=True)
+        assert torch.equal(fused, plain)
+    finally:
+        CoreAdj.LONG_ROW = old
+
+
+def test_fused_layer_matches_the_cpu_oracle():
+    """fp64 CPU restatement of layers.py:41-62 on the same inputs; tolerance of the model parity tests (atol 1e-5 + rtol 1e-4)."""
+    from oracle import torch_path as TP
+    adj, kept = _nested_adj(800, 5000, 4, seed=11, with_mats=True)
+    layer = _layer(500, 5)
+    x = torch.randn(800, 500, device=_dev())
+    with torch.no_grad():
+        got = layer(x, adj).cpu()
+    sd = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+    ref = TP.core_diffusion(sd, "", x.cpu(), [TP.coo_like_reference(m) for m in kept])
+    assert torch.allclose(got, ref, atol=1e-5, rtol=1e-4), float((got - ref).abs().max())
+
+
+def test_training_and_width_128_keep_the_separate_path(monkeypatch):
+    from ctgcn_amd import ops
+    monkeypatch.setenv("CTGCN_AGG_SPLIT", "1")
+    adj = _nested_adj(500, 3000, 3, seed=2)
+    layer = _layer(500, 2)
+    x = torch.randn(500, 500, device=_dev(), requires_grad=True)
+    assert not ops.aggregate_split_ok(layer.rnn, x, adj)
+    layer(x, adj).sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    with torch.no_grad():
+        assert ops.aggregate_split_ok(layer.rnn, x.detach(), adj)
+        assert not ops.aggregate_split_ok(_layer(128, 3).rnn, torch.randn(500, 128, device=_dev()), adj)

@@ -14,14 +14,25 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -amdgpu-mfma-vgpr-form: MFMA accumulators in architectural VGPRs.  gru_layer_h2_kernel fills the AGPR half of the register
-    # file with pinned weight fragments; with the default (AGPR-form) accumulators every result crosses back through
-    # v_accvgpr_read before the gate math (24 % of that kernel's VALU instructions).  The other kernels use no AGPRs either way.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form", "-shared", "-fPIC", "-pthread",
-           "-o", OUT] + SRCS
+    # -amdgpu-mfma-vgpr-form (ctgcn_hip.hip only): MFMA accumulators in architectural VGPRs.  gru_layer_h2_kernel fills the AGPR half
+    # of the register file with pinned weight fragments; with the default (AGPR-form) accumulators every result crosses back through
+    # v_accvgpr_read before the gate math (24 % of that kernel's VALU instructions).  ctgcn_gemm.hip wants the opposite: the
+    # 256 x 128 GEMM tile keeps its 128 accumulator registers in the AGPR half and 246 operand / staging registers in the VGPR half.
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread"]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+        common.append("-Rpass-analysis=kernel-resource-usage")
+    objs, procs = [], []
+    for src in SRCS:
+        obj = os.path.splitext(src)[0] + ".o"
+        extra = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.path.basename(src) == "ctgcn_hip.hip" else []
+        procs.append((src, subprocess.Popen(common + extra + ["-c", src, "-o", obj])))
+        objs.append(obj)
+    for src, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, "hipcc -c " + src)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs)
+    for obj in objs:
+        os.remove(obj)
     return OUT
 
 

@@ -150,7 +150,58 @@ struct GemmArgs {
     int64_t ldy;
     int64_t mtiles;
     int32_t ntiles;
+#ifdef CTGCN_GEMM_TIMELINE
+    unsigned long long *timeline;   // diagnostic build (-DCTGCN_GEMM_TIMELINE): 8 words per block, see tools/gemm_timeline.py
+#endif
 };
+
+// Epilogue of both GEMM kernels: y = acc·sa[m]·sb[n] + bias[n] for the wave's NI x NJ tiles of 32 x 32 (D layout: lane l holds column
+// l & 31, rows 8 (v / 4) + 4 (l >> 5) + v % 4).  A tile that lies completely inside the matrix takes the straight-line path: all row
+// scales requested together, then 16 NI NJ stores back to back.  With a bounds test around every store the compiler branches around
+// each one and — not knowing which loads are still outstanding on which path — waits for vmcnt(0) before every store; stores
+// count in vmcnt on gfx9, so each waited for the previous one to complete: 64 serialised write round trips, 25 us of a
+// 46 us block life (per-block timeline with wall_clock64, 435 180 x 500 x 384).  Only edge tiles take the tested path.
+template <int NI, int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const f16v (&acc)[NI][NJ], int64_t mrow0, int ncol0, int lane, bool full)
+{
+    const int64_t mbase = mrow0 + 4 * (lane >> 5);
+    const int nbase = ncol0 + (lane & 31);
+    if (full) {
+        float sc[NI][16], sb[NJ], bs[NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) sc[i][v] = a.sa[mbase + i * 32 + 8 * (v / 4) + (v % 4)];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            sb[j] = a.sb[nbase + j * 32];
+            bs[j] = a.bias ? a.bias[nbase + j * 32] : 0.f;
+        }
+        float *yp = a.y + mbase * a.ldy + nbase;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float *row = yp + (int64_t)(i * 32 + 8 * (v / 4) + (v % 4)) * a.ldy;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) row[j * 32] = fmaf(acc[i][j][v], sc[i][v] * sb[j], bs[j]);
+            }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = nbase + j * 32;
+        if (n >= a.N) continue;
+        const float sb = a.sb[n], bs = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int64_t m = mbase + i * 32 + 8 * (v / 4) + (v % 4);
+                if (m < a.M) a.y[m * a.ldy + n] = fmaf(acc[i][j][v], a.sa[m] * sb, bs);
+            }
+    }
+}
 
 // 128 x 128 block tile, 4 waves (2 x 2) of 64 x 64 (2 x 2 MFMA tiles of 32 x 32), k steps of 32 = two MFMA k slabs of 16.
 // One wave is software-pipelined at half-step granularity (issue order pinned with sched_barrier; left alone the compiler
@@ -160,13 +211,15 @@ struct GemmArgs {
 //   phase B   request the fragments of slab 0 of tile kt+1 into the registers phase A just finished with; 12 MFMAs on
 //             slab 1, one global load of tile kt+3 behind each of the first eight.
 // One barrier per k step, two LDS stages, one set of fragment registers; global loads land 1.5 steps after their issue.
-// Where the time goes (435 180 x 500 x 384, kernel alone 0.94 ms; ingredients removed one at a time on the GPU): MFMAs
-// only 0.55 (of which the epilogue 0.18; the MFMA stream itself runs at the 1.93 PFLOP/s this chip sustains on
-// v_mfma_f32_32x32x16_f16 with real operands — tools/probes/mfma_peak_probe.hip — not the 2.5 of the data sheet),
-// + LDS traffic 0.70, + global loads 0.94; tile-contiguous global addresses instead of 64-byte row segments: 0.89.
-// Per k step and CU the matrix pipe needs ~1850 cycles, the LDS ~1350 (stores 830: ds_write_b128 moves 79 B/clk) and the
-// L1 fill ~1000: three resources of the same order that two resident blocks overlap only in part.  K = 500 is 16 k steps
-// per tile, so the prologue (exposed first loads) and the 64 KB epilogue of every block are a third of its life.
+// Where the time goes (435 180 x 500 x 384; per-block timeline of the -DCTGCN_GEMM_TIMELINE build, tools/gemm_timeline.py,
+// profiles/r02_gemm_timeline.txt.gz): kernel 0.77 ms, a block lives 35.5 us = prologue 5.5 (first loads, exposed) + k loop 25.0
+// (16 steps; the SIMD's MFMAs of two resident blocks need 11.7 us at the 2.1 GHz the chip holds here) + epilogue 5.1; the
+// first epilogue (a bounds test around every store) took 25 us of a 46 us life — see gemm_epilogue.  rocprofv3 counters of the
+// kernel: matrix pipe busy 36 % of CU cycles, LDS 25 % (no bank conflicts), HBM traffic = compulsory (0.96 GB read: the three N
+// tiles of a panel share its A tile in the XCD's L2, 109.8 M L2 requests, 88 % hits), average L1->L2 read latency 296 cycles.
+// The matrix pipe itself sustains 1.93 PFLOP/s on v_mfma_f32_32x32x16_f16 with real operands (tools/probes/mfma_peak_probe.hip),
+// not the 2.5 of the data sheet.  Measured and NOT faster: a 256 x 128 tile with 64 x 128 wave tiles at one wave per SIMD (1.09 vs
+// 1.08 ms per projection, slower on the short MLP shapes), tile-contiguous global addresses (-6 %), staggered block starts (0).
 __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 {
     constexpr int BM = 128;
@@ -181,6 +234,10 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
     const int nt = (int)(q % a.ntiles);
     const int64_t mp = (q / a.ntiles) * 8 + xcd;
     if (mp >= a.mtiles) return;
+#ifdef CTGCN_GEMM_TIMELINE
+    const unsigned long long T0 = wall_clock64();
+    unsigned long long T1 = 0, T2 = 0;
+#endif
     const int64_t m0 = mp * BM;
     const int n0 = nt * BN;
 
@@ -257,43 +314,39 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
         slab(1, [&](int t) { gload1(kt + 3, s, t); });
     };
 
+    // prologue: tiles 0 and 1 are requested together (one exposed memory latency, not two), tile 2 as soon as set 0 is in LDS
 #pragma unroll
     for (int i = 0; i < 8; ++i) gload1(0, 0, i);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) lstore1(0, 0, i);
-#pragma unroll
     for (int i = 0; i < 8; ++i) gload1(1, 1, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lstore1(0, 0, i);
 #pragma unroll
     for (int i = 0; i < 8; ++i) gload1(2, 0, i);
     __syncthreads();
     fread(0, 0);
+#ifdef CTGCN_GEMM_TIMELINE
+    T1 = wall_clock64();
+#endif
     for (int kt = 0; kt < nk; kt += 2) {                  // unrolled by two: each register set keeps its registers
         step(kt, 1);
         step(kt + 1, 0);
     }
 
-    // epilogue: D[i][j] of a 32 x 32 tile: lane l holds column j = l & 31, rows i = 8 (v / 4) + 4 (l >> 5) + v % 4.
-    // The 32 row scales a lane needs are requested together (clamped row: no branch between the loads).
-    float sc[2][16];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int v = 0; v < 16; ++v)
-            sc[i][v] = a.sa[min(m0 + wm * 64 + i * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4), a.M - 1)];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (n >= a.N) continue;
-        const float sb = a.sb[n], bs = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int64_t m = m0 + wm * 64 + i * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4);
-                if (m < a.M) a.y[m * a.ldy + n] = fmaf(acc[i][j][v], sc[i][v] * sb, bs);
-            }
-        }
+#ifdef CTGCN_GEMM_TIMELINE
+    T2 = wall_clock64();
+#endif
+    gemm_epilogue<2, 2>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, m0 + BM <= a.M && n0 + BN <= a.N);
+#ifdef CTGCN_GEMM_TIMELINE
+    if (a.timeline && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)");           // the block's stores have left
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *d = a.timeline + (size_t)blockIdx.x * 8;
+        d[0] = T0; d[1] = T1; d[2] = T2; d[3] = wall_clock64(); d[4] = ((unsigned long long)xcc << 32) | hw;
     }
+#endif
 }
 
 size_t align_up(size_t x, size_t al) { return (x + al - 1) / al * al; }
@@ -357,7 +410,28 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
     g.mtiles = (rows + 127) / 128;
     const int64_t blocks = (g.mtiles + 7) / 8 * 8 * g.ntiles;
     if (blocks > 0x7fffffffLL) return ctgcn_set_error_(CTGCN_E_INVALID, "linear: too many tiles for one launch; split the rows");
+#ifdef CTGCN_GEMM_TIMELINE
+    static const char *tl_file = getenv("CTGCN_GEMM_TIMELINE_FILE");
+    static int tl_calls = 0;
+    g.timeline = nullptr;
+    if (tl_file && ++tl_calls == 3) {            // the third call: clocks and caches are warm
+        (void)hipMalloc(&g.timeline, (size_t)blocks * 64);
+        (void)hipMemsetAsync(g.timeline, 0, (size_t)blocks * 64, st);
+    }
+#endif
     hipLaunchKernelGGL(gemm_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+#ifdef CTGCN_GEMM_TIMELINE
+    if (g.timeline) {
+        (void)hipStreamSynchronize(st);
+        unsigned long long *h = (unsigned long long *)malloc((size_t)blocks * 64);
+        (void)hipMemcpy(h, g.timeline, (size_t)blocks * 64, hipMemcpyDeviceToHost);
+        FILE *f = fopen(tl_file, "w");
+        for (int64_t i = 0; i < blocks; ++i) fprintf(f, "%lld %llu %llu %llu %llu %llu\n", (long long)i, h[i * 8], h[i * 8 + 1], h[i * 8 + 2], h[i * 8 + 3], h[i * 8 + 4]);
+        fclose(f);
+        free(h);
+        (void)hipFree(g.timeline);
+    }
+#endif
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

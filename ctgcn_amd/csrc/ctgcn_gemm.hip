@@ -56,7 +56,7 @@ __device__ __forceinline__ void h2_scale(float m, float &s, float &inv_s)
 template <bool VEC>
 __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_t K, int32_t Kp, const float *__restrict__ x, int64_t ldx,
                                                              _Float16 *__restrict__ p1, _Float16 *__restrict__ p2, float *__restrict__ scale,
-                                                             const int32_t *__restrict__ group_map, int32_t group)
+                                                             const int32_t *__restrict__ group_map, int32_t group, float residual_scale)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
                 for (int j = 0; j < 4; ++j) {
                     const float xs = keep[i][j] * inv;
                     a[j] = (_Float16)xs;
-                    b[j] = (_Float16)(xs - (float)a[j]);
+                    b[j] = (_Float16)((xs - (float)a[j]) * residual_scale);
                 }
                 *(h4v *)(d1 + k) = a;
                 *(h4v *)(d2 + k) = b;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
                 for (int j = 0; j < 4; ++j) {
                     const float xs = v[j] * inv;
                     a[j] = (_Float16)xs;
-                    b[j] = (_Float16)(xs - (float)a[j]);
+                    b[j] = (_Float16)((xs - (float)a[j]) * residual_scale);
                 }
             }
             *(h4v *)(d1 + k) = a;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
             if (k < K) {
                 const float xs = src[k] * inv;
                 a = (_Float16)xs;
-                b = (_Float16)(xs - (float)a);
+                b = (_Float16)((xs - (float)a) * residual_scale);
             }
             d1[k] = a;
             d2[k] = b;
@@ -364,20 +364,20 @@ size_t ctgcn_linear_workspace_bytes(int64_t rows, int32_t n_out, int32_t k)
 
 // planes of `rows` fp32 rows: [optionally remapped] split_rows launch
 static void launch_split(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, _Float16 *p1, _Float16 *p2, float *scale,
-                         const int32_t *group_map, int32_t group, hipStream_t st)
+                         const int32_t *group_map, int32_t group, float residual_scale, hipStream_t st)
 {
     const bool vec = !(k & 3) && !(ldx & 3) && !(reinterpret_cast<uintptr_t>(x) & 15u);
     const dim3 grid((unsigned)((rows + 3) / 4));
-    if (vec) hipLaunchKernelGGL(split_rows_h2_kernel<true>, grid, dim3(256), 0, st, rows, k, kp, x, ldx, p1, p2, scale, group_map, group);
-    else hipLaunchKernelGGL(split_rows_h2_kernel<false>, grid, dim3(256), 0, st, rows, k, kp, x, ldx, p1, p2, scale, group_map, group);
+    if (vec) hipLaunchKernelGGL(split_rows_h2_kernel<true>, grid, dim3(256), 0, st, rows, k, kp, x, ldx, p1, p2, scale, group_map, group, residual_scale);
+    else hipLaunchKernelGGL(split_rows_h2_kernel<false>, grid, dim3(256), 0, st, rows, k, kp, x, ldx, p1, p2, scale, group_map, group, residual_scale);
 }
 
 // internal (ctgcn_hip.hip: hub rows of ctgcn_core_aggregate_split_f32): source row r -> plane row group_map[r / group] * group + r % group
 int ctgcn_split_rows_mapped_(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, void *p1, void *p2, float *scale,
-                             const int32_t *group_map, int32_t group, void *stream)
+                             const int32_t *group_map, int32_t group, float residual_scale, void *stream)
 {
     if (rows <= 0) return CTGCN_OK;
-    launch_split(rows, k, kp, x, ldx, (_Float16 *)p1, (_Float16 *)p2, scale, group_map, group, (hipStream_t)stream);
+    launch_split(rows, k, kp, x, ldx, (_Float16 *)p1, (_Float16 *)p2, scale, group_map, group, residual_scale, (hipStream_t)stream);
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }
@@ -402,8 +402,8 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
     char *wsb = ws + align_up((size_t)rows * kp * 4 + (size_t)rows * 4, 256);
     _Float16 *b1 = (_Float16 *)wsb, *b2 = b1 + (size_t)n_out * kp;
     float *sb = (float *)(b2 + (size_t)n_out * kp);
-    if (x) launch_split(rows, k, kp, x, ldx, a1, a2, sa, nullptr, 1, st);
-    launch_split(n_out, k, kp, w, ldw, b1, b2, sb, nullptr, 1, st);
+    if (x) launch_split(rows, k, kp, x, ldx, a1, a2, sa, nullptr, 1, 1.f, st);
+    launch_split(n_out, k, kp, w, ldw, b1, b2, sb, nullptr, 1, 1.f, st);
     GemmArgs g{};
     g.M = rows; g.N = n_out; g.Kp = kp; g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.sa = sa; g.sb = sb; g.bias = bias; g.y = y; g.ldy = ldy;
     g.ntiles = (n_out + BN - 1) / BN;

@@ -1198,20 +1198,38 @@ __device__ __forceinline__ void h2_split(float xs, _Float16 &a, _Float16 &b)    
     a = (_Float16)xs;
     b = (_Float16)((xs - (float)a) * (float)RS);
 }
+// maximum over aligned groups of 32 (or 64) lanes, result in every lane: four DPP exchanges inside the 16-lane rows (quad swaps,
+// half-row and row mirrors: plain VALU, no LDS crossbar) and one (two) ds_bpermute across rows.  A slot closes for every (row, core)
+// pair — five dependent ds_bpermute round trips there cost the d = 128 aggregation 19 % (1.49 -> 1.77 ms per 1 M-row launch).
+template <int LPR>
+__device__ __forceinline__ float group_max(float m)       // m >= 0: its bit pattern orders like an unsigned integer (no NaN canonicalisation per step)
+{
+    uint32_t u = __float_as_uint(m);
+    auto dpp = [](uint32_t v, auto ctrl) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, true); };
+    u = max(u, dpp(u, std::integral_constant<int, 0xB1>{}));      // quad_perm [1,0,3,2]
+    u = max(u, dpp(u, std::integral_constant<int, 0x4E>{}));      // quad_perm [2,3,0,1]
+    u = max(u, dpp(u, std::integral_constant<int, 0x141>{}));     // row_half_mirror: lane i <-> 7 - i of its 8
+    u = max(u, dpp(u, std::integral_constant<int, 0x140>{}));     // row_mirror: lane i <-> 15 - i of its 16
+    u = max(u, (uint32_t)__shfl_xor((int)u, 16, 64));
+    if (LPR == 64) u = max(u, (uint32_t)__shfl_xor((int)u, 32, 64));
+    return __uint_as_float(u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // agg_fwd_split_kernel: the CoreDiffusion aggregation whose consumer is the split GEMM (ctgcn_gemm.hip) — the GRU input
 // projection of a layer with d_in != 128.  Same recurrence as agg_fwd_kernel, but ONE wave holds the whole feature row
 // (CH float4 chunks per lane, d <= 256 CH), so when a slot closes the row's maximum is a wave reduction away and the row
 // leaves as the GEMM's operand: per-row power-of-two scale + two fp16 planes [n K, kp] (exactly what split_rows_h2_kernel
-// would make of the fp32 row, bit for bit).  The fp32 H [n, K, d] is never written and never read back: per (row, slot)
+// would make of the fp32 row, bit for bit).  LPR lanes per row: 64 (d > 128: one wave per row) or 32 (d <= 128: two rows per wave,
+// the mapping of agg_fwd_kernel at d = 128).  The fp32 H [n, K, d] is never written and never read back: per (row, slot)
 // 4 d bytes written instead of 4 d written + 4 d read + 4 d written, and one pass over the entries instead of d / 256.
 // ------------------------------------------------------------------------------------------------
-template <int CH, int U>
-__global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2,
-                                                            float *__restrict__ scale, int32_t kp)
+template <int LPR, int CH, int U>
+__device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2,
+                                                   float *__restrict__ scale, int32_t kp, float residual_scale)
 {
-    const int lig = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lig = threadIdx.x & (LPR - 1);
+    const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
     if (row >= a.n) return;
     const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
     if (end - start > a.long_thresh) return;          // hub row: agg_fwd_hub_kernel into the compact scratch, split afterwards
@@ -1225,7 +1243,7 @@ __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Fl
     f4 R[CH], P[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        const int ch = c * 64 + lig;
+        const int ch = c * LPR + lig;
         live[c] = ch < a.chunks;
         foff[c] = live[c] ? (int64_t)ch * 4 : 0;      // dead lanes read chunk 0 (valid memory): every load unconditional
         R[c] = P[c] = vzero<4>();
@@ -1244,22 +1262,21 @@ __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Fl
             if (!live[c]) v[c] = vzero<4>();
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].y)), fmaxf(fabsf(v[c].z), fabsf(v[c].w))));
         }
-#pragma unroll
-        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        m = group_max<LPR>(m);
         float s, inv;
         h2_scale(m, s, inv);
         const int64_t orow = row * a.K + cur;
         if (lig == 0) scale[orow] = s;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int k = (c * 64 + lig) * 4;
+            const int k = (c * LPR + lig) * 4;
             if (k < kp) {                             // columns [d, kp) are written as zeros
                 const float xs[4] = {v[c].x * inv, v[c].y * inv, v[c].z * inv, v[c].w * inv};
                 h4v h1, h2;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     h1[j] = (_Float16)xs[j];
-                    h2[j] = (_Float16)(xs[j] - (float)h1[j]);
+                    h2[j] = (_Float16)((xs[j] - (float)h1[j]) * residual_scale);      // 1 (GEMM operand) or 2048 (GRU layer kernel's x planes)
                 }
                 __builtin_nontemporal_store(h1, (h4v *)(p1 + orow * kp + k));
                 __builtin_nontemporal_store(h2, (h4v *)(p2 + orow * kp + k));
@@ -1268,7 +1285,7 @@ __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Fl
         ++cur;
     };
 
-    for (int base = start; base < end; base += 64) {
+    for (int base = start; base < end; base += LPR) {
         const int my = base + lig;
         int c = 0, s = 0;
         float w = 0.f;
@@ -1277,7 +1294,7 @@ __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Fl
             w = a.val[my];
             s = slot ? (int)slot[my] : 0;
         }
-        const int cnt = min(64, end - base);
+        const int cnt = min(LPR, end - base);
         int j = 0;
         for (; j + U <= cnt; j += U) {
             f4 xv[U][CH];
@@ -1285,9 +1302,9 @@ __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Fl
             int sj[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int cj = __shfl(c, j + u, 64);
-                wj[u] = __shfl(w, j + u, 64);
-                sj[u] = __shfl(s, j + u, 64);
+                const int cj = __shfl(c, j + u, LPR);
+                wj[u] = __shfl(w, j + u, LPR);
+                sj[u] = __shfl(s, j + u, LPR);
 #pragma unroll
                 for (int q = 0; q < CH; ++q) xv[u][q] = *(const f4 *)(X + (int64_t)cj * a.ldsrc + foff[q]);
             }
@@ -1299,9 +1316,9 @@ __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Fl
             }
         }
         for (; j < cnt; ++j) {
-            const int cj = __shfl(c, j, 64);
-            const float w1 = __shfl(w, j, 64);
-            const int s1 = __shfl(s, j, 64);
+            const int cj = __shfl(c, j, LPR);
+            const float w1 = __shfl(w, j, LPR);
+            const int s1 = __shfl(s, j, LPR);
             f4 x1[CH];
 #pragma unroll
             for (int q = 0; q < CH; ++q) x1[q] = *(const f4 *)(X + (int64_t)cj * a.ldsrc + foff[q]);
@@ -1311,6 +1328,19 @@ __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Fl
         }
     }
     while (cur < a.K) close_slot();
+}
+
+template <int LPR, int CH, int U>
+__global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2,
+                                                            float *__restrict__ scale, int32_t kp, float residual_scale)
+{
+    agg_fwd_split_body<LPR, CH, U>(a, p1, p2, scale, kp, residual_scale);
+}
+// d <= 128: held to the 72 registers of seven waves per SIMD, like agg_fwd_kernel<4,32,4> (left alone the epilogue takes 74: six)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void agg_fwd_split32_kernel(
+    const AggArgs a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2, float *__restrict__ scale, int32_t kp, float residual_scale)
+{
+    agg_fwd_split_body<32, 1, 4>(a, p1, p2, scale, kp, residual_scale);
 }
 
 // 8 consecutive fp32 weights, already multiplied by 1/s, -> two fp16x8 fragments
@@ -1702,6 +1732,11 @@ struct LayerArgs {
     float eps;
     float *out;              // REDUCE: [rows, ldo]; else [rows, steps, 128]
     int64_t ldo;
+    const _Float16 *xp1, *xp2;   // PRESPLIT (gru_layer8_h2_kernel<true>): the fp16 planes [rows * steps, 128] and row scales of x,
+    const float *xps;            // as ctgcn_core_aggregate_split_f32 writes them (x is unused then)
+#ifdef CTGCN_LAYER_TIMELINE
+    unsigned long long *timeline;   // diagnostic build: per (block, wave) sums of the unit phases, see tools/layer_timeline.py
+#endif
 };
 
 // weight fragments of ONE 16-unit tile (tile16 = hidden units [16*tile16, 16*tile16+16)) of all three gates, as h2_load_weights
@@ -1980,6 +2015,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
 constexpr int L8_WL = 15;
 __device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : (c == 3 ? 12 + g : -1); }
 
+template <bool PRESPLIT>
 __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
 {
     __shared__ _Float16 Xs[2][2][16][PJ_PITCH];          // ring of two units: the two fp16 planes of 16 rows of x_t
@@ -2019,13 +2055,30 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     const int64_t ntiles = (a.rows + 15) / 16;
     const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
     const int sr = tid >> 5, sc = (tid & 31) * 4;         // staging role: 16 rows x 32 lanes x one float4
+    // PRESPLIT: the aggregation kernel already wrote x as fp16 planes + row scales (the same split, bit for bit): staging is a copy,
+    // the ~40 VALU instructions per unit of the max / scale / split leave this matrix-core-bound kernel for an HBM-bound one
+    h4v xq1 = {0, 0, 0, 0}, xq2 = {0, 0, 0, 0};
+    float xqs = 0.f;
     auto load_x = [&](int64_t tile, int t, f4v &v) {
         if (tile < ntiles) {
             const int64_t row = min(tile * 16 + sr, a.rows - 1);
-            v = *(const f4v *)(a.x + (row * S + t) * a.ldx + sc);
+            if (PRESPLIT) {
+                const int64_t rs_ = row * S + t;
+                xq1 = *(const h4v *)(a.xp1 + rs_ * GRU_H + sc);
+                xq2 = *(const h4v *)(a.xp2 + rs_ * GRU_H + sc);
+                xqs = a.xps[rs_];
+            } else {
+                v = *(const f4v *)(a.x + (row * S + t) * a.ldx + sc);
+            }
         }
     };
     auto stage_x = [&](int slot, const f4v v) {
+        if (PRESPLIT) {
+            if ((tid & 31) == 0) xscale[slot][sr] = xqs;
+            *(h4v *)(&Xs[slot][0][sr][sc]) = xq1;
+            *(h4v *)(&Xs[slot][1][sr][sc]) = xq2;
+            return;
+        }
         float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 #pragma unroll
         for (int d = 1; d < 32; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
@@ -2040,6 +2093,38 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
         }
         *(h4v *)(&Xs[slot][0][sr][sc]) = s0;
         *(h4v *)(&Xs[slot][1][sr][sc]) = s1;
+    };
+    // The same staging cut into slices that ride behind the MFMA groups of the running unit (one cross-lane step per slice: its
+    // LDS-crossbar latency passes under nine MFMAs instead of standing, five in a row, at the head of every unit where all
+    // eight waves wait for it together).  Slice 5 writes the planes of the NEXT unit and requests the x rows of the one after.
+    float sx_m = 0.f, sx_p = 0.f;                        // running row maximum, cross-lane value on its way
+    auto stage_slice = [&](int i, int slot, f4v &v, bool live, auto request_next) {
+        if (PRESPLIT) {
+            if (i == 5) {
+                if (live) stage_x(slot, v);
+                request_next();
+            }
+            return;
+        }
+        if (i == 0) sx_m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        else sx_m = fmaxf(sx_m, sx_p);                    // the exchange requested one slice (nine MFMAs) ago
+        if (i < 5) sx_p = __shfl_xor(sx_m, 1 << i);
+        if (i == 5) {
+            if (live) {
+                float scl, inv;
+                h2_scale(sx_m, scl, inv);
+                if ((tid & 31) == 0) xscale[slot][sr] = scl;
+                h4v s0, s1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 p, q;
+                    h2_split<2048>(v[j] * inv, p, q); s0[j] = p; s1[j] = q;
+                }
+                *(h4v *)(&Xs[slot][0][sr][sc]) = s0;
+                *(h4v *)(&Xs[slot][1][sr][sc]) = s1;
+            }
+            request_next();
+        }
     };
     auto next_unit = [&](int64_t &tile, int &t) {
         if (++t >= S) { t = 0; tile += gridDim.x; }
@@ -2056,21 +2141,43 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     __syncthreads();
 
     int slot = 0;
+#ifdef CTGCN_LAYER_TIMELINE
+    unsigned long long tl[6] = {0, 0, 0, 0, 0, 0};          // issue of the MFMA stream, gate math (incl. MFMA drain), publish, barrier, tile end, units
+    unsigned long long tp = wall_clock64();
+#define TL_MARK(i) { const unsigned long long now_ = wall_clock64(); tl[i] += now_ - tp; tp = now_; }
+#else
+#define TL_MARK(i)
+#endif
+    // h planes are double buffered: a unit publishes into Hs[pb] and reads Hs[pb ^ 1]; pb flips after every unit.  The last unit of a
+    // tile leaves the summed rows (fp32) in Hs[pb]; their LayerNorm is deferred into the NEXT tile's first unit, which publishes into
+    // the other buffer and has no h MFMAs — no barrier pair at the tile end (they were 10 % of the kernel: 237 of 2 260 ns per unit).
+    int pb = 0, ln_buf = 0, ln_last = -1;
+    int64_t ln_row0 = 0;
+    auto pending_layernorm = [&]() {
+        if (ln_last < 0) return;
+        for (int r = wave * 2; r < wave * 2 + 2; ++r)
+            if (r <= ln_last) gru_layernorm_row((const float *)&Hs[ln_buf][0][0][0] + r * GRU_PITCH, a.out + (ln_row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
+        ln_last = -1;
+    };
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * 16;
         const int last = (int)min((int64_t)16, a.rows - row0) - 1;
         f4v hprev = zero4, hsum = zero4;
         for (int t = 0; t < S; ++t) {
-            // ---- x of the next unit: registers -> planes of the other slot; request the unit after it
-            if (ptile < ntiles) stage_x(slot ^ 1, xr);
-            next_unit(ptile, pt);
-            load_x(ptile, pt, xr);
+            if (t == 0) pending_layernorm();
+            // ---- x of the next unit (registers -> planes of the other slot, then the request for the unit after it) is staged in
+            // slices behind this unit's MFMA groups: see stage_slice
+            const bool stage_live = ptile < ntiles;
+            auto request_next = [&]() {
+                next_unit(ptile, pt);
+                load_x(ptile, pt, xr);
+            };
             // ---- this unit
             const float rs = xscale[slot][col];
             f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};
             auto body = [&](auto with_h_tag) {
                 constexpr bool with_h = decltype(with_h_tag)::value;
-                const int hp = (t + 1) & 1;               // parity of step t-1
+                const int hp = pb ^ 1;                    // the buffer step t-1 published into
                 // issue order pinned as in gru_layer_h2_kernel: per k chunk the h planes and the residual-plane fragments are
                 // requested before the x MFMAs, the next chunk's x planes before the h MFMAs
                 h8v x1 = *(const h8v *)(&Xs[slot][0][col][8 * grp]);
@@ -2086,28 +2193,35 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     for (int g = 0; g < 3; ++g) wr[g] = Wl[wave][l8_lds_slot(1, c, g)][lane];
                     __builtin_amdgcn_sched_barrier(0);
                     // = CTGCN_H2_MFMA(Wi, c, x1, x2, acc0, acc1), LDS-resident fragments of the leading plane read on the spot
+                    // per accumulator the order of the terms is that of CTGCN_H2_MFMA (acc1: w1·x2 then w2·x1); the group fed from
+                    // LDS (w2 = wr, requested just above) goes last so that six MFMAs, not three, cover its latency
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
                         const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
                         acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x2, acc1[g], 0, 0, 0);
                     }
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], x1, acc1[g], 0, 0, 0);
-#pragma unroll
                     for (int g = 0; g < 3; ++g) {
                         const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
                         acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x1, acc0[g], 0, 0, 0);
                     }
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], x1, acc1[g], 0, 0, 0);
                     if (c < 3) {
                         __builtin_amdgcn_sched_barrier(0);
                         x1 = *(const h8v *)(&Xs[slot][0][col][(c + 1) * 32 + 8 * grp]);
                         x2 = *(const h8v *)(&Xs[slot][1][col][(c + 1) * 32 + 8 * grp]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (2 * c < 6) stage_slice(2 * c, slot ^ 1, xr, stage_live, request_next);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (with_h) { CTGCN_H2_MFMA1(Wh, c, h1, h2, ach) }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (2 * c + 1 < 6) stage_slice(2 * c + 1, slot ^ 1, xr, stage_live, request_next);
                 }
             };
             if (t > 0) body(std::true_type{}); else body(std::false_type{});
+            TL_MARK(0)
             f4v gi[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g)
@@ -2125,6 +2239,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             }
             hprev = h;
             hsum = t > 0 ? hsum + h : h;
+#ifdef CTGCN_LAYER_TIMELINE
+            asm volatile("" :: "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+#endif
+            TL_MARK(1)
             if (t + 1 < S) {                              // fp16x2 planes of h·2^14 for the next step (the buffer nobody reads in this unit)
                 h4v p, q;
 #pragma unroll
@@ -2133,19 +2251,29 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     h2_split<1>(h[j] * 16384.f, x, y);
                     p[j] = x; q[j] = y;
                 }
-                *(h4v *)(&Hs[t & 1][0][col][oc]) = p;
-                *(h4v *)(&Hs[t & 1][1][col][oc]) = q;
+                *(h4v *)(&Hs[pb][0][col][oc]) = p;
+                *(h4v *)(&Hs[pb][1][col][oc]) = q;
             } else {                                      // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
-                *(f4v *)((float *)&Hs[t & 1][0][0][0] + col * GRU_PITCH + oc) = hsum;
+                *(f4v *)((float *)&Hs[pb][0][0][0] + col * GRU_PITCH + oc) = hsum;
+                ln_buf = pb; ln_last = last; ln_row0 = row0;
             }
+            TL_MARK(2)
             __syncthreads();
+            TL_MARK(3)
+#ifdef CTGCN_LAYER_TIMELINE
+            ++tl[5];
+#endif
             slot ^= 1;
+            pb ^= 1;
         }
-        // ---- end of the tile: LayerNorm of the 16 summed rows, two per wave
-        for (int r = wave * 2; r < wave * 2 + 2; ++r)
-            if (r <= last) gru_layernorm_row((const float *)&Hs[(S - 1) & 1][0][0][0] + r * GRU_PITCH, a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
-        __syncthreads();       // the buffer is a plane buffer again in the next tile
+        TL_MARK(4)
     }
+    pending_layernorm();       // the block's last tile (its rows are visible: the last unit ended with a barrier)
+#ifdef CTGCN_LAYER_TIMELINE
+    if (a.timeline && lane == 0)
+        for (int i = 0; i < 6; ++i) a.timeline[((size_t)blockIdx.x * 8 + wave) * 6 + i] = tl[i];
+#endif
+#undef TL_MARK
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2862,7 +2990,7 @@ extern "C" size_t ctgcn_ingest_workspace_bytes_(int64_t n, int64_t m);   // ctgc
 // shared with the other translation units of the library (not part of the public header)
 extern "C" int ctgcn_set_error_(int code, const char *msg) { return fail(code, "%s", msg); }
 extern "C" int ctgcn_split_rows_mapped_(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, void *p1, void *p2, float *scale,
-                                        const int32_t *group_map, int32_t group, void *stream);   // ctgcn_gemm.hip
+                                        const int32_t *group_map, int32_t group, float residual_scale, void *stream);   // ctgcn_gemm.hip
 
 extern "C" {
 
@@ -2971,10 +3099,15 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
     a.passes = p.passes;
     if (a.n_long > 0 && (size_t)K * p.lpr * 16 > HUB_LDS_BUDGET) a.n_long = 0;      // K*d too large for the hub kernel's LDS partials
     if (a.n_long <= 0) { a.n_long = 0; a.long_thresh = 0x7fffffff; }
-    const int64_t blocks = (n_rows + 3) / 4;
+    const int rows_per_block = p.chunks <= 32 ? 8 : 4;
+    const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     if (blocks > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: grid too large");
-    if (p.chunks <= 64) hipLaunchKernelGGL((agg_fwd_split_kernel<1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp);
-    else hipLaunchKernelGGL((agg_fwd_split_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp);
+    // d = 128 feeds ctgcn_gru_layer_presplit_f32, whose x planes carry the residual times 2^11 (two accumulators, CTGCN_H2_MFMA);
+    // every other width feeds the GEMM (residual as is, one accumulator)
+    const float rsc = d == GRU_H ? 2048.f : 1.f;
+    if (p.chunks <= 32) hipLaunchKernelGGL(agg_fwd_split32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
+    else if (p.chunks <= 64) hipLaunchKernelGGL((agg_fwd_split_kernel<64, 1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
+    else hipLaunchKernelGGL((agg_fwd_split_kernel<64, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
     HIP_TRY(hipGetLastError());
     if (a.n_long > 0) {
         // hub rows: the block-per-row kernel writes fp32 rows into the compact scratch, then they are split like any other rows
@@ -2993,7 +3126,7 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
         HUBCASE(8) else HUBCASE(16) else HUBCASE(32) else HUBCASE(64)
 #undef HUBCASE
         HIP_TRY(hipGetLastError());
-        const int rc = ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, long_rows, K, stream);
+        const int rc = ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, long_rows, K, rsc, stream);
         if (rc != CTGCN_OK) return rc;
     }
     return CTGCN_OK;
@@ -3210,11 +3343,62 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
     static const int nw = [] { const char *e = getenv("CTGCN_GRU_LAYER_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
     if (nw == 8 && reduce_sum) {
         const int64_t nt8 = (rows + 15) / 16;
-        hipLaunchKernelGGL(gru_layer8_h2_kernel, dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+#ifdef CTGCN_LAYER_TIMELINE
+        const unsigned nb8 = (unsigned)(nt8 < cus ? nt8 : cus);
+        const char *tl_file = getenv("CTGCN_LAYER_TIMELINE_FILE");
+        a.timeline = nullptr;
+        if (tl_file) { (void)hipMalloc(&a.timeline, (size_t)nb8 * 8 * 6 * 8); (void)hipMemsetAsync(a.timeline, 0, (size_t)nb8 * 8 * 6 * 8, (hipStream_t)stream); }
+#endif
+        hipLaunchKernelGGL(gru_layer8_h2_kernel<false>, dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+#ifdef CTGCN_LAYER_TIMELINE
+        if (a.timeline) {
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            unsigned long long *h = (unsigned long long *)malloc((size_t)nb8 * 8 * 6 * 8);
+            (void)hipMemcpy(h, a.timeline, (size_t)nb8 * 8 * 6 * 8, hipMemcpyDeviceToHost);
+            FILE *f = fopen(tl_file, "w");          // rewritten by every call: the last call's numbers stay
+            for (unsigned i = 0; i < nb8 * 8; ++i) fprintf(f, "%u %u %llu %llu %llu %llu %llu %llu\n", i / 8, i % 8, h[i * 6], h[i * 6 + 1], h[i * 6 + 2], h[i * 6 + 3], h[i * 6 + 4], h[i * 6 + 5]);
+            fclose(f);
+            free(h);
+            (void)hipFree(a.timeline);
+        }
+#endif
     } else {
         if (reduce_sum) hipLaunchKernelGGL((gru_layer_h2_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gru_layer_h2_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     }
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, const void *planes, const float *w_ih, const float *w_hh,
+                                 const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
+                                 float *out, int64_t ld_out, void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit: only d_in = hidden = %d is built (got %d)", GRU_H, hidden);
+    if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_layer_presplit: bad sizes rows=%lld steps=%d", (long long)rows, steps);
+    if (rows == 0) return CTGCN_OK;
+    if (!planes || !w_ih || !w_hh || !out) return fail(CTGCN_E_INVALID, "gru_layer_presplit: null pointer");
+    if ((reinterpret_cast<uintptr_t>(planes) & 255u) || !aligned16(w_ih) || !aligned16(w_hh) || (reinterpret_cast<uintptr_t>(out) & 7u) ||
+        (ln_weight && (reinterpret_cast<uintptr_t>(ln_weight) & 7u)) || (ln_bias && (reinterpret_cast<uintptr_t>(ln_bias) & 7u)))
+        return fail(CTGCN_E_INVALID, "gru_layer_presplit: planes 256-byte, weights 16-byte, out / LayerNorm vectors 8-byte aligned");
+    const int64_t ldo = ld_out > 0 ? ld_out : GRU_H;
+    if (ld_out > 0 && (ld_out < GRU_H || (ld_out & 1))) return fail(CTGCN_E_INVALID, "gru_layer_presplit: ld_out must be even and >= %d", GRU_H);
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    LayerArgs a{};
+    a.rows = rows; a.steps = steps; a.x = nullptr; a.ldx = GRU_H; a.wih = w_ih; a.whh = w_hh; a.bias_gi = bias_gi; a.bhn = b_hn;
+    a.gamma = ln_weight; a.beta = ln_bias; a.eps = ln_eps; a.out = out; a.ldo = ldo;
+    // the layout ctgcn_core_aggregate_split_f32 writes for d = 128 (kp = 128): plane 1, plane 2, row scales
+    const size_t nrow = (size_t)rows * steps;
+    a.xp1 = (const _Float16 *)planes;
+    a.xp2 = a.xp1 + nrow * GRU_H;
+    a.xps = (const float *)(a.xp2 + nrow * GRU_H);
+#ifdef CTGCN_LAYER_TIMELINE
+    a.timeline = nullptr;
+#endif
+    const int64_t nt8 = (rows + 15) / 16;
+    hipLaunchKernelGGL(gru_layer8_h2_kernel<true>, dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

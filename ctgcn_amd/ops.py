@@ -410,24 +410,31 @@ def aggregate_split_enabled():
     return linear_split_enabled() and os.environ.get("CTGCN_AGG_SPLIT", "1") != "0"
 
 
+_AGG_SPLIT_MAX = 16 << 30     # bytes of fp16 planes the fused aggregation may write in one call (config 5: 4.1 GB per snapshot)
+
+
 def aggregate_split_ok(rnn, x, adj):
-    """Inference through a CoreDiffusion layer whose GRU input projection runs as the split GEMM (d_in != 128): the aggregation
-    kernel can hand the GEMM its fp16 planes directly (ctgcn_core_aggregate_split_f32)."""
+    """Inference through a CoreDiffusion layer: the aggregation kernel can hand its consumer fp16 planes + row scales instead of
+    fp32 rows (ctgcn_core_aggregate_split_f32) — the split GEMM of the GRU input projection when d_in != 128, the
+    register-resident GRU layer kernel (ctgcn_gru_layer_presplit_f32) when d_in = hidden = 128."""
     if not aggregate_split_enabled() or x.dim() != 2 or not gru_fused_ok(rnn, x) or x.shape[0] != adj.n or x.device != adj.device:
         return False
     if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in rnn.parameters())):
         return False
     d, hid = x.shape[1], rnn.hidden_size
-    if d == 128 or d % 4 or d < 32 or d > 512 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or adj.K < 1 or adj.n < 1:
+    if d % 4 or d < 32 or d > 512 or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or adj.K < 1 or adj.n < 1:
         return False
+    if d == hid:        # the layer kernel path
+        return layer_kernel_enabled(True) and adj.n * adj.K * (d * 4 + 4) <= _AGG_SPLIT_MAX and rnn.weight_ih_l0.is_contiguous()
     if adj.n * adj.K * (-(-d // 64) * 64 * 4 + 4) > _LINEAR_WS_MAX:
         return False
     return len(_row_chunks(_lib.load(), adj.n, adj.K, hid)) == 1
 
 
 def core_diffusion_split(x, adj, rnn, norm, out=None):
-    """LayerNorm(sum_k GRU(relu(cumulative A_k x))_k) — CoreDiffusion.forward (layers.py:41-62) for inference with d_in != 128:
-    aggregation -> fp16 planes (no fp32 H), split GEMM -> gate pre-activations, recurrence + sum + LayerNorm kernel."""
+    """LayerNorm(sum_k GRU(relu(cumulative A_k x))_k) — CoreDiffusion.forward (layers.py:41-62) for inference, no fp32 H:
+    aggregation -> fp16 planes + row scales, then  d_in = hidden = 128: the register-resident GRU layer kernel reads the planes;
+    d_in != 128: split GEMM -> gate pre-activations -> recurrence + sum + LayerNorm kernel."""
     lib = _lib.load()
     n, d = x.shape
     K, hid = adj.K, rnn.hidden_size
@@ -446,12 +453,18 @@ def core_diffusion_split(x, adj, rnn, norm, out=None):
     with torch.cuda.device(x.device):
         long_rows = adj.long_rows()
         n_long = 0 if long_rows is None else long_rows.numel()
-        ws_bytes = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, d, K, n_out, n_long))
+        layer = d == hid                                   # -> ctgcn_gru_layer_presplit_f32; its weights need no plane workspace
+        ws_bytes = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, d, K, 1 if layer else n_out, n_long))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
         with _timed("agg_fwd", n=n, d=d, K=K, nnz=adj.nnz, split=True):
             check(lib.ctgcn_core_aggregate_split_f32(n, d, K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x), x.stride(0),
-                                                     flags, ptr(long_rows), n_long, adj.LONG_ROW, n_out, ptr(ws), ws_bytes, _stream()),
-                  "ctgcn_core_aggregate_split_f32")
+                                                     flags, ptr(long_rows), n_long, adj.LONG_ROW, 1 if layer else n_out, ptr(ws), ws_bytes,
+                                                     _stream()), "ctgcn_core_aggregate_split_f32")
+        if layer:
+            with _timed("gru_layer", rows=n, steps=K, reduce_sum=True, presplit=True):
+                check(lib.ctgcn_gru_layer_presplit_f32(n, K, hid, ptr(ws), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
+                                                       ptr(out), out.stride(0), _stream()), "ctgcn_gru_layer_presplit_f32")
+            return out
         gi_buf = _gi_buffer(n, K, hid, x.device)
         with _timed("linear_split", rows=n * K, k=d, n_out=n_out, presplit=True):
             check(lib.ctgcn_linear_presplit_f32(n * K, n_out, d, ptr(w_ih), w_ih.stride(0), ptr(bias), ptr(gi_buf), n_out, ptr(ws), ws_bytes,

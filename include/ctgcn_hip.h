@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 11
+#define CTGCN_ABI_VERSION 12
 
 enum {
     CTGCN_OK = 0,
@@ -212,6 +212,17 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
                         float ln_eps, int reduce_sum, float *out, int64_t ld_out, void *stream);
 
 /*
+ * ctgcn_gru_layer_f32 (sum-over-steps form) on an input that ctgcn_core_aggregate_split_f32 already wrote as fp16 planes + row scales
+ * (d = hidden = 128: `planes` = that call's workspace for n_rows = rows, K = steps).  The aggregation (HBM-bound) does the per-row
+ * max / scale / split, this matrix-core-bound kernel only copies the planes into LDS: the whole CoreDiffusion layer of
+ * layers.py:41-62 in two kernels, x [rows, steps, 128] never exists in fp32.  Bit-identical to ctgcn_core_aggregate_f32 +
+ * ctgcn_gru_layer_f32.  Inference only.
+ */
+int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, const void *planes, const float *w_ih, const float *w_hh,
+                                 const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
+                                 float *out, int64_t ld_out, void *stream);
+
+/*
  * Dense  y[rows, n_out] = x[rows, k]·w[n_out, k]^T + bias  (bias [n_out] may be NULL) in fp32-accurate fp16x2 split arithmetic on the
  * matrix cores (CTGCN_SPLIT_F16X2: operand rows scaled by a power of two and written as two fp16 terms, three
  * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation) - the GRU input projection for d_in != 128 (layers.py:59 with
@@ -229,7 +240,7 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
  * writes what ctgcn_linear_f32 would make of it - the per-row scales and the two fp16 planes of the n_rows*K operand rows
  * (row = node*K + core) - straight into that GEMM's workspace, bit-identical to aggregate + ctgcn_linear_f32, without the
  * write + read + write of the fp32 intermediate.  Inference only (nothing is kept for a backward pass).
- *   d % 4 == 0, d <= 512, X 16-byte aligned, ldx % 4 == 0.
+ *   d % 4 == 0, d <= 512, X 16-byte aligned, ldx % 4 == 0.  d = 128 feeds ctgcn_gru_layer_presplit_f32 instead of the GEMM.
  *   workspace: ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, K, n_out, n_long) bytes, 256-byte aligned; n_out is the
  *   width of the projection that follows (its weight planes share the workspace); n_long hub rows pass through an fp32
  *   scratch at the end of it.

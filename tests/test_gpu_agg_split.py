@@ -1,5 +1,6 @@
-"""ctgcn_core_aggregate_split_f32 + ctgcn_linear_presplit_f32 (the aggregation hands the split GEMM its fp16 planes) against the
-separate kernels (fp32 H, then ctgcn_linear_f32): bit-identical, including hub rows, padded widths and non-nested lists."""
+"""ctgcn_core_aggregate_split_f32 (the aggregation writes fp16 planes + row scales instead of fp32 rows) feeding
+ctgcn_linear_presplit_f32 (d_in != 128) or ctgcn_gru_layer_presplit_f32 (d_in = 128), against the separate kernels (fp32 H, then
+ctgcn_linear_f32 / ctgcn_gru_layer_f32): bit-identical, including hub rows, padded widths and ragged tiles."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -59,7 +60,8 @@ def _both(layer, x, adj, monkeypatch, out_view=False):
 
 
 @pytest.mark.parametrize("d,n,m,max_core", [(500, 3000, 24000, 6), (64, 2000, 9000, 3), (256, 1500, 12000, 5), (260, 1200, 9000, 4),
-                                            (36, 900, 5000, 2), (512, 700, 6000, 8), (500, 5, 4, 1)])
+                                            (36, 900, 5000, 2), (512, 700, 6000, 8), (500, 5, 4, 1),
+                                            (128, 3001, 24000, 6), (128, 70001, 400000, 8), (128, 7, 9, 1), (128, 17, 40, 2)])
 def test_fused_layer_is_bit_identical_to_the_separate_kernels(d, n, m, max_core, monkeypatch):
     adj = _nested_adj(n, m, max_core, seed=d + n)
     layer = _layer(d, d)
@@ -76,20 +78,22 @@ def test_fused_layer_with_hub_rows_and_strided_output(monkeypatch):
         CoreAdj.LONG_ROW = 12
         adj = _nested_adj(4000, 20000, 5, seed=3, hub=2500)
         assert adj.long_rows() is not None and adj.long_rows().numel() > 10
-        layer = _layer(500, 1)
-        x = torch.randn(4000, 500, device=_dev())
-        fused, plain = _both(layer, x, adj, monkeypatch, out_view=True)
-        assert torch.equal(fused, plain)
+        for d in (500, 128):
+            layer = _layer(d, 1)
+            x = torch.randn(4000, d, device=_dev())
+            fused, plain = _both(layer, x, adj, monkeypatch, out_view=True)
+            assert torch.equal(fused, plain)
     finally:
         CoreAdj.LONG_ROW = old
 
 
-def test_fused_layer_matches_the_cpu_oracle():
-    """fp64 CPU restatement of layers.py:41-62 on the same inputs; tolerance of the model parity tests (atol 1e-5 + rtol 1e-4)."""
+@pytest.mark.parametrize("d", [500, 128])
+def test_fused_layer_matches_the_cpu_oracle(d):
+    """CPU restatement of layers.py:41-62 on the same inputs; tolerance of the model parity tests (atol 1e-5 + rtol 1e-4)."""
     from oracle import torch_path as TP
     adj, kept = _nested_adj(800, 5000, 4, seed=11, with_mats=True)
-    layer = _layer(500, 5)
-    x = torch.randn(800, 500, device=_dev())
+    layer = _layer(d, 5)
+    x = torch.randn(800, d, device=_dev())
     with torch.no_grad():
         got = layer(x, adj).cpu()
     sd = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
@@ -97,7 +101,7 @@ def test_fused_layer_matches_the_cpu_oracle():
     assert torch.allclose(got, ref, atol=1e-5, rtol=1e-4), float((got - ref).abs().max())
 
 
-def test_training_and_width_128_keep_the_separate_path(monkeypatch):
+def test_training_keeps_the_separate_path_and_the_switches_work(monkeypatch):
     from ctgcn_amd import ops
     monkeypatch.setenv("CTGCN_AGG_SPLIT", "1")
     adj = _nested_adj(500, 3000, 3, seed=2)
@@ -108,4 +112,10 @@ def test_training_and_width_128_keep_the_separate_path(monkeypatch):
     assert x.grad is not None and torch.isfinite(x.grad).all()
     with torch.no_grad():
         assert ops.aggregate_split_ok(layer.rnn, x.detach(), adj)
-        assert not ops.aggregate_split_ok(_layer(128, 3).rnn, torch.randn(500, 128, device=_dev()), adj)
+        l128, x128 = _layer(128, 3), torch.randn(500, 128, device=_dev())
+        assert ops.aggregate_split_ok(l128.rnn, x128, adj)
+        monkeypatch.setenv("CTGCN_GRU_LAYER", "0")          # no layer kernel -> nothing consumes planes at width 128
+        assert not ops.aggregate_split_ok(l128.rnn, x128, adj)
+        monkeypatch.delenv("CTGCN_GRU_LAYER")
+        monkeypatch.setenv("CTGCN_AGG_SPLIT", "0")
+        assert not ops.aggregate_split_ok(l128.rnn, x128, adj) and not ops.aggregate_split_ok(layer.rnn, x.detach(), adj)

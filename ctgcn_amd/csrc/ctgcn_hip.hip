@@ -1510,7 +1510,8 @@ template <bool REDUCE, bool SAVE>
 __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
 {
     __shared__ _Float16 Hs[2][2][GRU_BM][PJ_PITCH];
-    __shared__ float sbuf[GRU_BM][GRU_PITCH];      // REDUCE: running sum over steps; otherwise: fp32 h_t staged for the row-wise LayerNorm / store
+    __shared__ float sbuf_[REDUCE ? 1 : 2][GRU_BM][GRU_PITCH];   // REDUCE: running sum over steps; otherwise fp32 h_t staged for the row-wise
+    float(*const sbuf)[GRU_PITCH] = sbuf_[0];                     // LayerNorm / store, double buffered by step parity (emitted during the next step)
     __shared__ float wscale[4][GRU_H];             // rows 0-2: product scales of the three gates, row 3: b_hn
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 15, grp = lane >> 4;
@@ -1556,7 +1557,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
             *(h4v *)(&Hs[buf][1][r_][oc]) = q;
         };
         // gate math for the lane's 4 hidden units of one row; ac: the accumulators of h_{t-1}·W_hh^T, still to be multiplied by csc
-        auto gates = [&](const f4v gr, const f4v gz, const f4v gn, const f4v (&ac)[3], const f4v hold, int t, int r_) {
+        auto gates = [&](const f4v gr, const f4v gz, const f4v gn, const f4v (&ac)[3], const f4v hold, int t, int r_) {     // t: the step of this h
             const f4v csc[3] = {*(const f4v *)(&wscale[0][oc]), *(const f4v *)(&wscale[1][oc]), *(const f4v *)(&wscale[2][oc])};
             const f4v b_hn = *(const f4v *)(&wscale[3][oc]);
             f4v h, rv, zv, nv, an;
@@ -1568,7 +1569,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
                 nv[j] = gru_tanh(fmaf(rv[j], an[j], gn[j]));
                 h[j] = nv[j] + zv[j] * (hold[j] - nv[j]);
             }
-            if (!REDUCE) *(f4v *)(&sbuf[r_][oc]) = h;
+            if (!REDUCE) *(f4v *)(&sbuf_[REDUCE ? 0 : (t & 1)][r_][oc]) = h;
             if (SAVE && r_ <= last) {
                 float *gp = a.gates + ((row0 + r_) * steps + t) * (4 * GRU_H) + oc;
                 *(f4v *)gp = rv; *(f4v *)(gp + GRU_H) = zv; *(f4v *)(gp + 2 * GRU_H) = nv; *(f4v *)(gp + 3 * GRU_H) = an;
@@ -1588,13 +1589,13 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
             if (REDUCE) *(f4v *)(&sbuf[rt * 16 + col][oc]) = h;
         }
         __syncthreads();
-        auto emit_step = [&](int t) {      // per-step output: LayerNorm (or plain copy) of the staged fp32 rows, 512 B per row
+        // per-step output: LayerNorm (or plain copy) of the staged fp32 rows of step t, 512 B per row.  No barrier of its own: it runs
+        // behind the first barrier of step t + 1 (all 64 rows of step t are staged by then), and the buffer is next written by the
+        // gate math of step t + 2, two barriers later
+        auto emit_step = [&](int t) {
             for (int r = wave; r <= last; r += 8)
-                gru_layernorm_row(sbuf[r], a.out + ((row0 + r) * steps + t) * GRU_H, lane, a.gamma, a.beta, a.eps);
-            __syncthreads();               // the next step's gate math overwrites sbuf
+                gru_layernorm_row(sbuf_[REDUCE ? 0 : (t & 1)][r], a.out + ((row0 + r) * steps + t) * GRU_H, lane, a.gamma, a.beta, a.eps);
         };
-        if (!REDUCE) emit_step(0);
-
         // Software pipeline over the row tiles of a step: the gate math of tile rt-1 is issued among tile rt's MFMAs, and
         // the GI operands of a row tile are requested TWO units (row tile x step) before its MFMAs start — a full step
         // before its gate math — into four statically indexed buffers (the loaded HBM latency exceeds one step's MFMAs).
@@ -1650,27 +1651,36 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
             }
             __syncthreads();
         } else {
-        for (int t = 1; t < steps; ++t) {
-            const int pb = (t - 1) & 1, cb = t & 1;
+            // The same rolling pipeline for the per-step form (temporal GRU: LayerNorm(h_t) of every step is an output).  It used to
+            // drain at every step: all four gate blocks, barrier, LayerNorm of 64 rows, barrier — 9.5 ms per 1 M x 16 call against an
+            // HBM bound of 5.8.  Now the rows of step t-1 leave while step t multiplies.
             f4v acc[2][3];
+            for (int t = 1; t < steps; ++t) {
+                const int pb = (t - 1) & 1, cb = t & 1;
 #pragma unroll
-            for (int rt = 0; rt <= GRU_RT; ++rt) {
-                const int cur = rt & 1, prv = cur ^ 1;
-                if (rt < GRU_RT) {
+                for (int rt = 0; rt < GRU_RT; ++rt) {
+                    const int cur = rt & 1, prv = cur ^ 1;
                     if (rt + 2 < GRU_RT) load_gi(t, rt + 2);
                     else if (t + 1 < steps) load_gi(t + 1, rt + 2 - GRU_RT);
                     mfma_unit(pb, rt, acc[cur]);
-                }
-                if (rt > 0) {
-                    const int rp = rt - 1;
-                    const f4v h = gates(gq[rp][0], gq[rp][1], gq[rp][2], acc[prv], hreg[rp], t, rp * 16 + col);
-                    hreg[rp] = h;
-                    publish(cb, rp * 16 + col, h);
+                    if (rt > 0 || t > 1) {
+                        const int rp = rt > 0 ? rt - 1 : GRU_RT - 1;          // the previous unit's row tile ...
+                        const int wb = rt > 0 ? cb : pb;                      // ... the plane buffer of ITS step ...
+                        const int ts = rt > 0 ? t : t - 1;                    // ... and that step
+                        const f4v h = gates(gq[rp][0], gq[rp][1], gq[rp][2], acc[prv], hreg[rp], ts, rp * 16 + col);
+                        hreg[rp] = h;
+                        publish(wb, rp * 16 + col, h);
+                    }
+                    if (rt & 1) __syncthreads();
+                    if (rt == 1) emit_step(t - 1);                            // its last row tile finished in unit (t, 0), before that barrier
                 }
             }
+            if (steps > 1) {                                                  // drain: row tile 3 of the last step
+                const int rp = GRU_RT - 1;
+                gates(gq[rp][0], gq[rp][1], gq[rp][2], acc[1], hreg[rp], steps - 1, rp * 16 + col);
+            }
             __syncthreads();
-            emit_step(t);
-        }
+            emit_step(steps - 1);
         }
         if (REDUCE)
             for (int r = wave; r <= last; r += 8)

@@ -368,16 +368,35 @@ def main():
                                              "frac": round(pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     if fused:
         # projection + recurrence in one kernel: 2*128*384 flops per row-step for the projection, the same for every step but the first
-        flops = sum(m["rows"] * (2 * m["steps"] - 1) * 2.0 * 128 * 384 for _, m in fused)
-        ms = sum(t for t, _ in fused)
-        hbm = sum(m["rows"] * (m["steps"] * 512.0 + 512.0) for _, m in fused)       # H tile in, one output row out
-        fr = {"kernel": "gru_layer8_h2_kernel (CoreDiffusion GRU: input projection + recurrence + sum over cores + LayerNorm in one kernel, "
-                        "both weight matrices resident on the CU — registers + 120 KB of LDS, 8 waves — the projection consumed from the MFMA "
-                        "accumulators; fp16x2 split)",
-              "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
-              "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
-              "compulsory_hbm_GBps": round(hbm / (ms * 1e-3) / 1e9, 1), "launches_timed": len(fused),
-              "ms_per_step_rank0": round(ms / roof_steps, 3)}
+        def layer_obj(group, name, per_step):
+            flops = sum(m["rows"] * (2 * m["steps"] - 1) * 2.0 * 128 * 384 for _, m in group)
+            ms = sum(t for t, _ in group)
+            # compulsory traffic: the x rows in (as fp32 or as two fp16 planes: 512 B per row-step either way), one output row out —
+            # per step for the temporal form, whose LayerNorm pass reads and writes every row once more
+            hbm = sum(m["rows"] * (m["steps"] * 512.0 + (3 * m["steps"] * 512.0 if per_step else 512.0)) for _, m in group)
+            return {"kernel": name, "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
+                    "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
+                    # tools/probes/mfma_peak_probe.hip: v_mfma_f32_16x16x32_f16 sustains 2.15-2.3 PFLOP/s with real operands on this
+                    # chip (clock 2.0-2.1 GHz under load), not the 2.5 of the data sheet
+                    "frac_of_sustained_mfma_rate_2200": round(flops / (ms * 1e-3) / 1e12 / (2200.0 / 3.0), 4),
+                    "compulsory_hbm_GBps": round(hbm / (ms * 1e-3) / 1e9, 1), "launches_timed": len(group),
+                    "ms_per_step_rank0": round(ms / roof_steps, 3)}
+        red = [(t, m) for t, m in fused if m.get("reduce_sum", True)]
+        seqf = [(t, m) for t, m in fused if not m.get("reduce_sum", True)]
+        fr = None
+        if red:
+            pres = any(m.get("presplit") for _, m in red)
+            fr = layer_obj(red, "gru_layer8_h2_kernel (CoreDiffusion GRU: input projection + recurrence + sum over cores + LayerNorm in one "
+                                "kernel, both weight matrices resident on the CU — registers + 120 KB of LDS, 8 waves — the projection "
+                                "consumed from the MFMA accumulators; fp16x2 split%s)"
+                                % ("; x arrives as fp16 planes + row scales written by the aggregation kernel" if pres else ""), False)
+        if seqf:
+            tl = layer_obj(seqf, "gru_layer8_h2_kernel<per step> + layernorm_rows_kernel (temporal GRU: the same kernel leaving the raw h_t of "
+                                 "every step, then LayerNorm of the rows in place)", True)
+            if fr is None:
+                fr = tl
+            else:
+                fr["temporal_layer"] = tl
         if roof_mfma is None:
             roof_mfma = fr
         else:

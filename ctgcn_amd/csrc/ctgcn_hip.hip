@@ -745,10 +745,8 @@ struct GruArgs {
 __device__ __forceinline__ float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
 __device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008f)); }
 
-__device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src, float *__restrict__ dst, int lane,
-                                                  const float *gamma, const float *beta, float eps)
+__device__ __forceinline__ float2 gru_layernorm_vals(float2 v, int lane, const float *gamma, const float *beta, float eps)
 {
-    float2 v = *(const float2 *)(src + lane * 2);
     if (gamma) {
         float s = v.x + v.y;
         for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
@@ -762,7 +760,22 @@ __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src,
         v.x = dx * rstd * g.x + b.x;
         v.y = dy * rstd * g.y + b.y;
     }
-    *(float2 *)(dst + lane * 2) = v;
+    return v;
+}
+__device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src, float *__restrict__ dst, int lane,
+                                                  const float *gamma, const float *beta, float eps)
+{
+    *(float2 *)(dst + lane * 2) = gru_layernorm_vals(*(const float2 *)(src + lane * 2), lane, gamma, beta, eps);
+}
+// LayerNorm of rows of 128 floats in place, one wave per row: the second half of the per-step form of gru_layer8_h2_kernel, whose
+// eight waves each hold 16 of a row's 128 values and have no LDS left to exchange row statistics (8.2 GB read + written per 1M x 16)
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(int64_t rows, float *data, const float *gamma, const float *beta, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float2 *p = (float2 *)(data + row * GRU_H) + lane;
+    *p = gru_layernorm_vals(*p, lane, gamma, beta, eps);
 }
 
 template <bool REDUCE, bool SAVE>
@@ -2025,7 +2038,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
 constexpr int L8_WL = 15;
 __device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : (c == 3 ? 12 + g : -1); }
 
-template <bool PRESPLIT>
+template <bool PRESPLIT, bool REDUCE>
 __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
 {
     __shared__ _Float16 Xs[2][2][16][PJ_PITCH];          // ring of two units: the two fp16 planes of 16 rows of x_t
@@ -2174,7 +2187,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
         const int last = (int)min((int64_t)16, a.rows - row0) - 1;
         f4v hprev = zero4, hsum = zero4;
         for (int t = 0; t < S; ++t) {
-            if (t == 0) pending_layernorm();
+            if (REDUCE && t == 0) pending_layernorm();
             // ---- x of the next unit (registers -> planes of the other slot, then the request for the unit after it) is staged in
             // slices behind this unit's MFMA groups: see stage_slice
             const bool stage_live = ptile < ntiles;
@@ -2248,7 +2261,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 h[j] = nv + zv * (hprev[j] - nv);
             }
             hprev = h;
-            hsum = t > 0 ? hsum + h : h;
+            if (REDUCE) hsum = t > 0 ? hsum + h : h;
+            else if (col <= last) *(f4v *)(a.out + ((row0 + col) * S + t) * GRU_H + oc) = h;      // raw h_t; layernorm_rows_kernel follows
 #ifdef CTGCN_LAYER_TIMELINE
             asm volatile("" :: "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
 #endif
@@ -2263,7 +2277,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 }
                 *(h4v *)(&Hs[pb][0][col][oc]) = p;
                 *(h4v *)(&Hs[pb][1][col][oc]) = q;
-            } else {                                      // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
+            } else if (REDUCE) {                          // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
                 *(f4v *)((float *)&Hs[pb][0][0][0] + col * GRU_PITCH + oc) = hsum;
                 ln_buf = pb; ln_last = last; ln_row0 = row0;
             }
@@ -2278,7 +2292,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
         }
         TL_MARK(4)
     }
-    pending_layernorm();       // the block's last tile (its rows are visible: the last unit ended with a barrier)
+    if (REDUCE) pending_layernorm();       // the block's last tile (its rows are visible: the last unit ended with a barrier)
 #ifdef CTGCN_LAYER_TIMELINE
     if (a.timeline && lane == 0)
         for (int i = 0; i < 6; ++i) a.timeline[((size_t)blockIdx.x * 8 + wave) * 6 + i] = tl[i];
@@ -3359,7 +3373,7 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
         a.timeline = nullptr;
         if (tl_file) { (void)hipMalloc(&a.timeline, (size_t)nb8 * 8 * 6 * 8); (void)hipMemsetAsync(a.timeline, 0, (size_t)nb8 * 8 * 6 * 8, (hipStream_t)stream); }
 #endif
-        hipLaunchKernelGGL(gru_layer8_h2_kernel<false>, dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((gru_layer8_h2_kernel<false, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
 #ifdef CTGCN_LAYER_TIMELINE
         if (a.timeline) {
             (void)hipStreamSynchronize((hipStream_t)stream);
@@ -3372,6 +3386,18 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
             (void)hipFree(a.timeline);
         }
 #endif
+    } else if (nw == 8) {
+        // per-step form (temporal GRU): the 8-wave kernel leaves the raw h_t, a row-per-wave pass normalises them in place
+        const int64_t nt8 = (rows + 15) / 16;
+#ifdef CTGCN_LAYER_TIMELINE
+        a.timeline = nullptr;
+#endif
+        hipLaunchKernelGGL((gru_layer8_h2_kernel<false, false>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+        if (ln_weight) {
+            const int64_t nrow = rows * steps;
+            if ((nrow + 3) / 4 > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "gru_layer: too many rows for one LayerNorm launch");
+            hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, (hipStream_t)stream, nrow, out, ln_weight, ln_bias, ln_eps);
+        }
     } else {
         if (reduce_sum) hipLaunchKernelGGL((gru_layer_h2_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gru_layer_h2_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -3408,7 +3434,7 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
     a.timeline = nullptr;
 #endif
     const int64_t nt8 = (rows + 15) / 16;
-    hipLaunchKernelGGL(gru_layer8_h2_kernel<true>, dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -261,14 +261,16 @@ def split_mfma_enabled():
 
 def layer_kernel_enabled(reduce_sum=True):
     """ctgcn_gru_layer_f32: input projection and recurrence of a GRU with d_in = hidden = 128 in one kernel, both weight matrices
-    resident in the register file, the projection consumed from the MFMA accumulators (never materialised).  Bit-identical to
+    resident on the CU (registers + LDS), the projection consumed from the MFMA accumulators (never materialised).  Bit-identical to
     the projection + recurrence kernel pair (tests/test_gpu_gru.py) at 1/7 of its HBM traffic.
-    CTGCN_GRU_LAYER = 1 (default): used where it is faster — the sum-over-steps form of CoreDiffusion (4.6 vs 6.4 ms per
-    1M x 8 call); the per-step form of the temporal GRU keeps the pair (15.6 vs 16.5 ms per 1M x 16 call).  all: both forms.  0: never.
-    CTGCN_GRU_LAYER_WAVES=4 selects the 4-wave build of the sum form (one wave per SIMD, 5.2 ms)."""
+    CTGCN_GRU_LAYER = 1 (default): both forms — the sum-over-steps form of CoreDiffusion (4.2-4.6 vs 6.4 ms per 1M x 8 call) and the
+    per-step form of the temporal GRU (raw h_t from the 8-wave kernel + a LayerNorm pass: 14.3 vs 15.7 ms per 1M x 16 call).
+    sum: the sum form only.  0: never.  CTGCN_GRU_LAYER_WAVES=4 selects the 4-wave builds (one wave per SIMD: 5.2 / 16.5 ms)."""
     import os
     mode = os.environ.get("CTGCN_GRU_LAYER", "1")
-    return mode == "all" or (mode != "0" and bool(reduce_sum))
+    if mode == "0":
+        return False
+    return bool(reduce_sum) or mode != "sum"
 
 
 def forward_split_mode():

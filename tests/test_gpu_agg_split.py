@@ -87,6 +87,29 @@ def test_fused_layer_with_hub_rows_and_strided_output(monkeypatch):
         CoreAdj.LONG_ROW = old
 
 
+@pytest.mark.parametrize("d", [500, 128, 96])
+def test_fused_layer_on_general_matrix_lists(d, monkeypatch):
+    """not nested, asymmetric, no unit diagonal (what a caller may pass instead of the loader's k-core list), with a dense hub row"""
+    from ctgcn_amd import CoreAdj
+    rng = np.random.default_rng(d)
+    n, mats = 700, []
+    for j in range(4):
+        m = sp.random(n, n, density=0.02, random_state=10 * d + j, format="lil", dtype=np.float32)
+        m[5, :] = rng.standard_normal(n)
+        mats.append(m.tocsr())
+    old = CoreAdj.LONG_ROW
+    try:
+        CoreAdj.LONG_ROW = 64
+        adj = CoreAdj.from_matrices(mats, device=_dev(), self_loop=False)
+        assert not adj.nested and adj.long_rows() is not None
+        layer = _layer(d, 7)
+        x = torch.randn(n, d, device=_dev())
+        fused, plain = _both(layer, x, adj, monkeypatch)
+        assert torch.isfinite(fused).all() and torch.equal(fused, plain)
+    finally:
+        CoreAdj.LONG_ROW = old
+
+
 @pytest.mark.parametrize("d", [500, 128])
 def test_fused_layer_matches_the_cpu_oracle(d):
     """CPU restatement of layers.py:41-62 on the same inputs; tolerance of the model parity tests (atol 1e-5 + rtol 1e-4)."""

@@ -441,6 +441,12 @@ AggPlan plan_for(int d, bool vec4_ok)
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// CUs a persistent kernel (one block per CU) may count on: the device's, or fewer when the caller runs it on a stream with a CU mask
+// (ctgcn_set_persistent_cus: the snapshot pipeline gives the HBM-bound aggregation its own few CUs next to the matrix-core kernels)
+int g_persistent_cus = 0;
+int persistent_cus(int device_cus) { return g_persistent_cus > 0 && g_persistent_cus < device_cus ? g_persistent_cus : device_cus; }
+
+
 constexpr size_t HUB_LDS_BUDGET = 144 * 1024;
 
 template <bool FWD, int VEC, int LPR>
@@ -3013,6 +3019,7 @@ extern "C" size_t ctgcn_ingest_workspace_bytes_(int64_t n, int64_t m);   // ctgc
 
 // shared with the other translation units of the library (not part of the public header)
 extern "C" int ctgcn_set_error_(int code, const char *msg) { return fail(code, "%s", msg); }
+extern "C" void ctgcn_set_persistent_cus(int cus) { g_persistent_cus = cus; }
 extern "C" int ctgcn_split_rows_mapped_(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, void *p1, void *p2, float *scale,
                                         const int32_t *group_map, int32_t group, float residual_scale, void *stream);   // ctgcn_gemm.hip
 
@@ -3317,6 +3324,7 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
     const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 8-wave block per CU
     if (split_bf16 == 2 && a.reduce_sum)
@@ -3358,6 +3366,7 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
     const int64_t ntiles = (rows + LY_BM - 1) / LY_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 4-wave block per CU (one wave per SIMD, 512 registers)
     LayerArgs a{};
@@ -3422,6 +3431,7 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
     LayerArgs a{};
     a.rows = rows; a.steps = steps; a.x = nullptr; a.ldx = GRU_H; a.wih = w_ih; a.whh = w_hh; a.bias_gi = bias_gi; a.bhn = b_hn;
     a.gamma = ln_weight; a.beta = ln_bias; a.eps = ln_eps; a.out = out; a.ldo = ldo;
@@ -3453,6 +3463,7 @@ int ctgcn_gru_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
     const int64_t ntiles = (rows + GRUB_BM - 1) / GRUB_BM;       // both variants use 32-row tiles
     int64_t blocks = ntiles < cus ? ntiles : cus;
     if (bias_partial) {
@@ -3486,6 +3497,7 @@ int ctgcn_gru_input_proj_f32(int64_t rows, int32_t d_in, int32_t hidden, const f
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
     const int64_t ntiles = (rows + PJ_BM - 1) / PJ_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;
     if (split_mode == 2)
@@ -3509,6 +3521,7 @@ int ctgcn_gru_input_grad_f32(int64_t rows, int32_t d_in, int32_t hidden, const f
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
     const int64_t ntiles = (rows + GBX_BM - 1) / GBX_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;
     hipLaunchKernelGGL(gru_dx_x3_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
@@ -3547,6 +3560,7 @@ int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float 
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
     const int64_t ntiles = (rows + LSTM_BM - 1) / LSTM_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;
     if (a.reduce_sum)

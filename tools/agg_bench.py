@@ -17,6 +17,20 @@ def alg_bytes(n, nnz, K, d):
     return nnz * (4 * d + 9) + n * K * 4 * d + 4 * (n + 1)
 
 
+def split_aggregate(x, adj):
+    from ctgcn_amd import _lib
+    lib = _lib.load()
+    n, d = x.shape
+    lr = adj.long_rows()
+    nl = 0 if lr is None else lr.numel()
+    wsb = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, d, adj.K, 1, nl))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.ctgcn_core_aggregate_split_f32(n, d, adj.K, _lib.ptr(adj.row_ptr), _lib.ptr(adj.col), _lib.ptr(adj.val), _lib.ptr(adj.slot),
+                                                  _lib.ptr(x), x.stride(0), adj.flags | _lib.F_RELU, _lib.ptr(lr), nl, adj.LONG_ROW, 1, _lib.ptr(ws),
+                                                  wsb, torch.cuda.current_stream().cuda_stream), "ctgcn_core_aggregate_split_f32")
+    return ws
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--snapshots", default="15")
@@ -25,6 +39,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--max-core", type=int, default=8)
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--split", action="store_true", help="ctgcn_core_aggregate_split_f32 (fp16 planes + row scales out) instead of the fp32 H")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     which = [int(s) for s in a.snapshots.split(",")]
@@ -33,13 +48,14 @@ def main():
         rp, col, val = graphs[t]
         adj, core, files = CoreAdj.from_graph(rp, col, val, max_core=a.max_core)
         x = torch.randn(a.nodes, a.d, device=dev)
+        run = (lambda: split_aggregate(x, adj)) if a.split else (lambda: ops.core_aggregate(x, adj))
         for _ in range(2):
-            h = ops.core_aggregate(x, adj)
+            h = run()
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(a.iters):
-            h = ops.core_aggregate(x, adj)
+            h = run()
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / a.iters

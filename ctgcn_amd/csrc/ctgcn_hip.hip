@@ -50,6 +50,7 @@ int fail(int code, const char *fmt, ...)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+
 template <int VEC> struct vec_of;
 template <> struct vec_of<4> { using type = f4; };
 template <> struct vec_of<1> { using type = float; };

@@ -778,11 +778,16 @@ __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src,
 // eight waves each hold 16 of a row's 128 values and have no LDS left to exchange row statistics (8.2 GB read + written per 1M x 16)
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(int64_t rows, float *data, const float *gamma, const float *beta, float eps)
 {
+    constexpr int RPW = 4;                                 // rows per wave: four independent load -> reduce -> store chains in flight
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    float2 *p = (float2 *)(data + row * GRU_H) + lane;
-    *p = gru_layernorm_vals(*p, lane, gamma, beta, eps);
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    float2 v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+        if (row0 + i < rows) v[i] = *((const float2 *)(data + (row0 + i) * GRU_H) + lane);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+        if (row0 + i < rows) *((float2 *)(data + (row0 + i) * GRU_H) + lane) = gru_layernorm_vals(v[i], lane, gamma, beta, eps);
 }
 
 template <bool REDUCE, bool SAVE>
@@ -3405,8 +3410,8 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
         hipLaunchKernelGGL((gru_layer8_h2_kernel<false, false>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
         if (ln_weight) {
             const int64_t nrow = rows * steps;
-            if ((nrow + 3) / 4 > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "gru_layer: too many rows for one LayerNorm launch");
-            hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, (hipStream_t)stream, nrow, out, ln_weight, ln_bias, ln_eps);
+            if ((nrow + 15) / 16 > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "gru_layer: too many rows for one LayerNorm launch");
+            hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, (hipStream_t)stream, nrow, out, ln_weight, ln_bias, ln_eps);
         }
     } else {
         if (reduce_sum) hipLaunchKernelGGL((gru_layer_h2_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

@@ -94,8 +94,9 @@ def kcore_bytes(n, nnz):
 def agg_kernel_name(d, split=False):
     chunks = (d + 3) // 4
     if split:
-        return ("agg_fwd_split_kernel<%d,4> (CoreDiffusion fused nested-core SpMM, d=%d, one pass; rows leave as the split GEMM's fp16 "
-                "operand planes + row scales, 4d B per row like the fp32 rows they replace)" % (-(-chunks // 64), d))
+        kern = "agg_fwd_split32_kernel" if chunks <= 32 else "agg_fwd_split_kernel<64,%d,4>" % (-(-chunks // 64))
+        return ("%s (CoreDiffusion fused nested-core SpMM, d=%d, one pass; rows leave as fp16 operand planes + row scales for the %s, "
+                "4d B per row like the fp32 rows they replace)" % (kern, d, "GRU layer kernel" if d == 128 else "split GEMM"))
     lpr = 8
     while lpr < 64 and lpr < chunks:
         lpr <<= 1

@@ -1214,9 +1214,10 @@ __device__ __forceinline__ void h2_scale(float m, float &s, float &inv_s)
     s = __uint_as_float((uint32_t)(e - 14) << 23);
     inv_s = __uint_as_float((uint32_t)(268 - e) << 23);
 }
-// RS = residual scale: 2048 (two accumulators, exact down to fp16's subnormals) or 1 (one accumulator: the residual of an
-// element below 2^-18 of its row's maximum loses bits — an absolute error of 2^-40 of that maximum; used by the recurrence,
-// whose operands are bounded, measured 1.2e-7 vs 3.0e-7 for an fp32 chain)
+// RS = residual scale.  Every forward kernel uses RS = 1: the three products of a term pair go into ONE fp32 accumulator (the residual of
+// an element below 2^-18 of its row's maximum loses bits — an absolute error of 2^-40 of that maximum; measured 1.2e-7 vs 3.0e-7
+// for an fp32 chain).  RS = 2048 (residual exact down to fp16's subnormals, needs a second accumulator and one more FMA per output)
+// was the first form of the x·W_ih products; it cost the matrix-core-bound layer kernel 12 VALU instructions per unit.
 template <int RS>
 __device__ __forceinline__ void h2_split(float xs, _Float16 &a, _Float16 &b)     // xs = x / s
 {
@@ -1301,7 +1302,7 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     h1[j] = (_Float16)xs[j];
-                    h2[j] = (_Float16)((xs[j] - (float)h1[j]) * residual_scale);      // 1 (GEMM operand) or 2048 (GRU layer kernel's x planes)
+                    h2[j] = (_Float16)((xs[j] - (float)h1[j]) * residual_scale);      // 1 for both consumers (kept as a parameter: the split is defined by (scale, residual scale))
                 }
                 __builtin_nontemporal_store(h1, (h4v *)(p1 + orow * kp + k));
                 __builtin_nontemporal_store(h2, (h4v *)(p2 + orow * kp + k));
@@ -1405,12 +1406,8 @@ __device__ __forceinline__ void h2_load_weights(const float *w, int wave, int co
         for (int c = 0; c < 4; ++c) h2_split_x8<RS>(row + c * 32 + 8 * grp, inv, Wf[0][c][g], Wf[1][c][g]);
     }
 }
-// the three products of one k chunk for the three gates: acc1 += W1·x2 + W2·x1 (weight 2^-11), acc0 += W1·x1
-#define CTGCN_H2_MFMA(WF, C, X1, X2, A0, A1)                                                                             \
-    _Pragma("unroll") for (int g = 0; g < 3; ++g) A1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[0][C][g], X2, A1[g], 0, 0, 0); \
-    _Pragma("unroll") for (int g = 0; g < 3; ++g) A1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[1][C][g], X1, A1[g], 0, 0, 0); \
-    _Pragma("unroll") for (int g = 0; g < 3; ++g) A0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[0][C][g], X1, A0[g], 0, 0, 0);
-// one-accumulator form (residuals not rescaled), small terms first
+// the three products of one k chunk for the three gates in ONE fp32 accumulator, small terms first: W1·x2, W2·x1 (both 2^-11 of the
+// third), W1·x1; the residual planes are unscaled (RS = 1, see h2_split)
 #define CTGCN_H2_MFMA1(WF, C, X1, X2, A)                                                                                 \
     _Pragma("unroll") for (int g = 0; g < 3; ++g) A[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[0][C][g], X2, A[g], 0, 0, 0); \
     _Pragma("unroll") for (int g = 0; g < 3; ++g) A[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[1][C][g], X1, A[g], 0, 0, 0); \
@@ -1427,7 +1424,7 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
     const int col = lane & 15, grp = lane >> 4;
 
     h8v Wf[2][4][3];      // [split][k chunk][gate]
-    h2_load_weights<2048>(a.w, wave, col, grp, Wf, wscale);
+    h2_load_weights<1>(a.w, wave, col, grp, Wf, wscale);
     __syncthreads();
     // transposed product: D[m = out column][n = X row]; a lane ends up with output columns 16w + 4*grp .. +3 of X row (lane & 15)
     const int oc = wave * 16 + 4 * grp;
@@ -1472,7 +1469,7 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 _Float16 p, q;
-                h2_split<2048>(v[i][j] * inv, p, q);
+                h2_split<1>(v[i][j] * inv, p, q);
                 s0[j] = p; s1[j] = q;
             }
             _Float16 *dst = &As[buf][0][idx >> 5][(idx & 31) * 4];
@@ -1496,12 +1493,12 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
         const int tstep = S > 0 ? (int)(tile - nt * S) : 0;
 #pragma unroll
         for (int rt = 0; rt < PJ_BM / 16; ++rt) {
-            f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4};
+            f4v acc0[3] = {zero4, zero4, zero4};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const h8v x1 = *(const h8v *)(&As[buf][0][rt * 16 + col][c * 32 + 8 * grp]);
                 const h8v x2 = *(const h8v *)(&As[buf][1][rt * 16 + col][c * 32 + 8 * grp]);
-                CTGCN_H2_MFMA(Wf, c, x1, x2, acc0, acc1)
+                CTGCN_H2_MFMA1(Wf, c, x1, x2, acc0)
             }
             const int r_ = rt * 16 + col;
             const float rs = rscale[buf][r_];
@@ -1520,7 +1517,7 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
             }
             if (valid) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g) *(f4v *)(o + g * gstep) = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (wsc[g] * rs) + bias[g];
+                for (int g = 0; g < 3; ++g) *(f4v *)(o + g * gstep) = acc0[g] * (wsc[g] * rs) + bias[g];
             }
         }
         if (next < ntiles) stage_tile(buf ^ 1, stage);
@@ -1824,7 +1821,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
     h8v Wi[UTW][2][4][3], Wh[UTW][2][4][3];              // [unit tile][split][k chunk][gate]
 #pragma unroll
     for (int ut = 0; ut < UTW; ++ut) {
-        h2_load_weight_tile<2048>(a.wih, wave * UTW + ut, col, grp, Wi[ut], wsc_ih);
+        h2_load_weight_tile<1>(a.wih, wave * UTW + ut, col, grp, Wi[ut], wsc_ih);
         h2_load_weight_tile<1>(a.whh, wave * UTW + ut, col, grp, Wh[ut], csc_hh);
     }
     // Register-file placement: MFMA A operands may live in the accumulator half (AGPRs) of the unified file, everything the
@@ -1886,7 +1883,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 _Float16 p, q;
-                h2_split<2048>(v[i][j] * inv, p, q); s0[j] = p; s1[j] = q;
+                h2_split<1>(v[i][j] * inv, p, q); s0[j] = p; s1[j] = q;
             }
             *(h4v *)(&Xs[slot][0][sr][sc + 4 * i]) = s0;
             *(h4v *)(&Xs[slot][1][sr][sc + 4 * i]) = s1;
@@ -1945,7 +1942,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
                 const float rs = xscale[slot][col];
 #pragma unroll
                 for (int ut = 0; ut < UTW; ++ut) {
-                    f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};
+                    f4v acc0[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};
                     // Issue order is pinned with sched_barriers (left alone, the scheduler sinks every ds_read to just before its
                     // first use and waits with lgkmcnt(0): one exposed LDS latency per three MFMAs, and a single wave per SIMD has
                     // nobody to cover it).  Per k chunk: the h planes and the LDS-resident weight fragments are requested before
@@ -1970,12 +1967,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
                                 h2 = *(const h8v *)(&Hs[1][r_][c * 32 + 8 * grp]);
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            // = CTGCN_H2_MFMA(Wi[ut], c, x1, x2, acc0, acc1)
+                            // = CTGCN_H2_MFMA1(Wi[ut], c, x1, x2, acc0)
 #pragma unroll
-                            for (int g = 0; g < 3; ++g) acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wi[ut][0][c][g], xa2, acc1[g], 0, 0, 0);
+                            for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wi[ut][0][c][g], xa2, acc0[g], 0, 0, 0);
 #pragma unroll
                             for (int g = 0; g < 3; ++g)
-                                acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ly_lds_slot<NW>(ut, 1, c, g) >= 0 ? wl[g] : Wi[ut][1][c][g], xa1, acc1[g], 0, 0, 0);
+                                acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ly_lds_slot<NW>(ut, 1, c, g) >= 0 ? wl[g] : Wi[ut][1][c][g], xa1, acc0[g], 0, 0, 0);
 #pragma unroll
                             for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wi[ut][0][c][g], xa1, acc0[g], 0, 0, 0);
                             if (c < 3) {
@@ -1999,7 +1996,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
                     f4v gi[3];
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
-                        gi[g] = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
+                        gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
                     const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
                     const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
                     const f4v hprev = t > 0 ? *(const f4v *)(&hold[r_][oc]) : zero4;
@@ -2067,7 +2064,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     const int S = a.steps;
 
     h8v Wi[2][4][3], Wh[2][4][3];                        // [split][k chunk][gate]
-    h2_load_weight_tile<2048>(a.wih, wave, col, grp, Wi, wsc_ih);
+    h2_load_weight_tile<1>(a.wih, wave, col, grp, Wi, wsc_ih);
     h2_load_weight_tile<1>(a.whh, wave, col, grp, Wh, csc_hh);
 #pragma unroll
     for (int sp = 0; sp < 2; ++sp)
@@ -2124,7 +2121,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             _Float16 p, q;
-            h2_split<2048>(v[j] * inv, p, q); s0[j] = p; s1[j] = q;
+            h2_split<1>(v[j] * inv, p, q); s0[j] = p; s1[j] = q;
         }
         *(h4v *)(&Xs[slot][0][sr][sc]) = s0;
         *(h4v *)(&Xs[slot][1][sr][sc]) = s1;
@@ -2153,7 +2150,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     _Float16 p, q;
-                    h2_split<2048>(v[j] * inv, p, q); s0[j] = p; s1[j] = q;
+                    h2_split<1>(v[j] * inv, p, q); s0[j] = p; s1[j] = q;
                 }
                 *(h4v *)(&Xs[slot][0][sr][sc]) = s0;
                 *(h4v *)(&Xs[slot][1][sr][sc]) = s1;
@@ -2209,7 +2206,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             };
             // ---- this unit
             const float rs = xscale[slot][col];
-            f4v acc0[3] = {zero4, zero4, zero4}, acc1[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};
+            f4v acc0[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};
             auto body = [&](auto with_h_tag) {
                 constexpr bool with_h = decltype(with_h_tag)::value;
                 const int hp = pb ^ 1;                    // the buffer step t-1 published into
@@ -2227,21 +2224,20 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
 #pragma unroll
                     for (int g = 0; g < 3; ++g) wr[g] = Wl[wave][l8_lds_slot(1, c, g)][lane];
                     __builtin_amdgcn_sched_barrier(0);
-                    // = CTGCN_H2_MFMA(Wi, c, x1, x2, acc0, acc1), LDS-resident fragments of the leading plane read on the spot
-                    // per accumulator the order of the terms is that of CTGCN_H2_MFMA (acc1: w1·x2 then w2·x1); the group fed from
-                    // LDS (w2 = wr, requested just above) goes last so that six MFMAs, not three, cover its latency
+                    // = CTGCN_H2_MFMA1(Wi, c, x1, x2, acc0): one accumulator, small terms first (w1·x2, w2·x1, then w1·x1); LDS-resident
+                    // fragments of the leading plane are read on the spot
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
                         const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
-                        acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x2, acc1[g], 0, 0, 0);
+                        acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x2, acc0[g], 0, 0, 0);
                     }
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], x1, acc0[g], 0, 0, 0);
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
                         const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
                         acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x1, acc0[g], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) acc1[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], x1, acc1[g], 0, 0, 0);
                     if (c < 3) {
                         __builtin_amdgcn_sched_barrier(0);
                         x1 = *(const h8v *)(&Xs[slot][0][col][(c + 1) * 32 + 8 * grp]);
@@ -2260,7 +2256,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             f4v gi[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g)
-                gi[g] = (acc0[g] + acc1[g] * (1.f / 2048.f)) * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
+                gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
             const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
             const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
             f4v h;
@@ -3139,9 +3135,8 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
     const int rows_per_block = p.chunks <= 32 ? 8 : 4;
     const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     if (blocks > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: grid too large");
-    // d = 128 feeds ctgcn_gru_layer_presplit_f32, whose x planes carry the residual times 2^11 (two accumulators, CTGCN_H2_MFMA);
-    // every other width feeds the GEMM (residual as is, one accumulator)
-    const float rsc = d == GRU_H ? 2048.f : 1.f;
+    // the residual plane is unscaled for every consumer (GRU layer kernel and GEMM both add the three products in one accumulator)
+    const float rsc = 1.f;
     if (p.chunks <= 32) hipLaunchKernelGGL(agg_fwd_split32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
     else if (p.chunks <= 64) hipLaunchKernelGGL((agg_fwd_split_kernel<64, 1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
     else hipLaunchKernelGGL((agg_fwd_split_kernel<64, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);

@@ -2045,19 +2045,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
 // LayerNorm.  Sum-over-steps form only.  Same arithmetic as the other two paths (bit-identical).
 // ------------------------------------------------------------------------------------------------
 constexpr int L8_WL = 15;
+constexpr int L8_PITCH = 128;                            // halfs per plane row, no padding
+// half index of element k of row r (r < 16): 16-byte segment k / 8 goes to segment (k / 8) ^ r
+__device__ __forceinline__ int l8_off(int r, int k) { return ((((k >> 3) ^ r) & 15) << 3) | (k & 7); }
 __device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : (c == 3 ? 12 + g : -1); }
 
 template <bool PRESPLIT, bool REDUCE>
 __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
 {
-    __shared__ _Float16 Xs[2][2][16][PJ_PITCH];          // ring of two units: the two fp16 planes of 16 rows of x_t
-    __shared__ _Float16 Hs[2][2][16][PJ_PITCH];          // [step parity][plane]: h_t·2^14 (after the last step: the summed rows in fp32)
+    // x and h planes: 16 rows of 128 halfs, unpadded; the 16-byte segment q of row r is stored at segment q ^ r (l8_off).  Every access
+    // pattern of the kernel is then conflict-free: the MFMA operand reads (ds_read_b128: lane = (row, k group) — with the 8-half row
+    // padding of the other GRU kernels rows 11 and 12 met in one bank group: SQ_LDS_BANK_CONFLICT was 26 % of the LDS cycles), the
+    // staging writes (32 lanes along a row) and the publish writes (16 rows at one column block).  It also frees 2 KB of LDS.
+    __shared__ _Float16 Xs[2][2][16][L8_PITCH];          // ring of two units: the two fp16 planes of 16 rows of x_t
+    __shared__ _Float16 Hs[2][2][16][L8_PITCH];          // [step parity][plane]: h_t·2^14 (after the last step: the summed rows in fp32)
     __shared__ float xscale[2][16];
     __shared__ float wsc_ih[3][GRU_H];
     __shared__ float csc_hh[4][GRU_H];                   // rows 0-2: product scales of the three gates, row 3: b_hn
     __shared__ float bias_s[3][GRU_H];
     __shared__ h8v Wl[8][L8_WL][64];
-    static_assert(sizeof(_Float16) * 2 * 16 * PJ_PITCH >= sizeof(float) * 16 * GRU_PITCH, "a plane buffer must hold 16 fp32 rows");
+    static_assert(sizeof(_Float16) * 2 * 16 * L8_PITCH >= sizeof(float) * 16 * GRU_H, "a plane buffer must hold 16 fp32 rows");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int col = lane & 15, grp = lane >> 4;
     const int oc = wave * 16 + 4 * grp;
@@ -2107,8 +2114,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     auto stage_x = [&](int slot, const f4v v) {
         if (PRESPLIT) {
             if ((tid & 31) == 0) xscale[slot][sr] = xqs;
-            *(h4v *)(&Xs[slot][0][sr][sc]) = xq1;
-            *(h4v *)(&Xs[slot][1][sr][sc]) = xq2;
+            *(h4v *)(&Xs[slot][0][sr][l8_off(sr, sc)]) = xq1;
+            *(h4v *)(&Xs[slot][1][sr][l8_off(sr, sc)]) = xq2;
             return;
         }
         float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
@@ -2123,8 +2130,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             _Float16 p, q;
             h2_split<1>(v[j] * inv, p, q); s0[j] = p; s1[j] = q;
         }
-        *(h4v *)(&Xs[slot][0][sr][sc]) = s0;
-        *(h4v *)(&Xs[slot][1][sr][sc]) = s1;
+        *(h4v *)(&Xs[slot][0][sr][l8_off(sr, sc)]) = s0;
+        *(h4v *)(&Xs[slot][1][sr][l8_off(sr, sc)]) = s1;
     };
     // The same staging cut into slices that ride behind the MFMA groups of the running unit (one cross-lane step per slice: its
     // LDS-crossbar latency passes under nine MFMAs instead of standing, five in a row, at the head of every unit where all
@@ -2152,8 +2159,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     _Float16 p, q;
                     h2_split<1>(v[j] * inv, p, q); s0[j] = p; s1[j] = q;
                 }
-                *(h4v *)(&Xs[slot][0][sr][sc]) = s0;
-                *(h4v *)(&Xs[slot][1][sr][sc]) = s1;
+                *(h4v *)(&Xs[slot][0][sr][l8_off(sr, sc)]) = s0;
+                *(h4v *)(&Xs[slot][1][sr][l8_off(sr, sc)]) = s1;
             }
             request_next();
         }
@@ -2188,7 +2195,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     auto pending_layernorm = [&]() {
         if (ln_last < 0) return;
         for (int r = wave * 2; r < wave * 2 + 2; ++r)
-            if (r <= ln_last) gru_layernorm_row((const float *)&Hs[ln_buf][0][0][0] + r * GRU_PITCH, a.out + (ln_row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
+            if (r <= ln_last) gru_layernorm_row((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H, a.out + (ln_row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
         ln_last = -1;
     };
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -2212,14 +2219,14 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 const int hp = pb ^ 1;                    // the buffer step t-1 published into
                 // issue order pinned as in gru_layer_h2_kernel: per k chunk the h planes and the residual-plane fragments are
                 // requested before the x MFMAs, the next chunk's x planes before the h MFMAs
-                h8v x1 = *(const h8v *)(&Xs[slot][0][col][8 * grp]);
-                h8v x2 = *(const h8v *)(&Xs[slot][1][col][8 * grp]);
+                h8v x1 = *(const h8v *)(&Xs[slot][0][col][l8_off(col, 8 * grp)]);
+                h8v x2 = *(const h8v *)(&Xs[slot][1][col][l8_off(col, 8 * grp)]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     h8v h1, h2, wr[3];
                     if (with_h) {
-                        h1 = *(const h8v *)(&Hs[hp][0][col][c * 32 + 8 * grp]);
-                        h2 = *(const h8v *)(&Hs[hp][1][col][c * 32 + 8 * grp]);
+                        h1 = *(const h8v *)(&Hs[hp][0][col][l8_off(col, c * 32 + 8 * grp)]);
+                        h2 = *(const h8v *)(&Hs[hp][1][col][l8_off(col, c * 32 + 8 * grp)]);
                     }
 #pragma unroll
                     for (int g = 0; g < 3; ++g) wr[g] = Wl[wave][l8_lds_slot(1, c, g)][lane];
@@ -2240,8 +2247,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     }
                     if (c < 3) {
                         __builtin_amdgcn_sched_barrier(0);
-                        x1 = *(const h8v *)(&Xs[slot][0][col][(c + 1) * 32 + 8 * grp]);
-                        x2 = *(const h8v *)(&Xs[slot][1][col][(c + 1) * 32 + 8 * grp]);
+                        x1 = *(const h8v *)(&Xs[slot][0][col][l8_off(col, (c + 1) * 32 + 8 * grp)]);
+                        x2 = *(const h8v *)(&Xs[slot][1][col][l8_off(col, (c + 1) * 32 + 8 * grp)]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (2 * c < 6) stage_slice(2 * c, slot ^ 1, xr, stage_live, request_next);
@@ -2283,10 +2290,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     h2_split<1>(h[j] * 16384.f, x, y);
                     p[j] = x; q[j] = y;
                 }
-                *(h4v *)(&Hs[pb][0][col][oc]) = p;
-                *(h4v *)(&Hs[pb][1][col][oc]) = q;
+                *(h4v *)(&Hs[pb][0][col][l8_off(col, oc)]) = p;
+                *(h4v *)(&Hs[pb][1][col][l8_off(col, oc)]) = q;
             } else if (REDUCE) {                          // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
-                *(f4v *)((float *)&Hs[pb][0][0][0] + col * GRU_PITCH + oc) = hsum;
+                *(f4v *)((float *)&Hs[pb][0][0][0] + col * GRU_H + oc) = hsum;
                 ln_buf = pb; ln_last = last; ln_row0 = row0;
             }
             TL_MARK(2)

@@ -240,7 +240,8 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
  * writes what ctgcn_linear_f32 would make of it - the per-row scales and the two fp16 planes of the n_rows*K operand rows
  * (row = node*K + core) - straight into that GEMM's workspace, bit-identical to aggregate + ctgcn_linear_f32, without the
  * write + read + write of the fp32 intermediate.  Inference only (nothing is kept for a backward pass).
- *   d % 4 == 0, d <= 512, X 16-byte aligned, ldx % 4 == 0.  d = 128 feeds ctgcn_gru_layer_presplit_f32 instead of the GEMM.
+ *   d % 4 == 0, d <= 512, X 16-byte aligned, ldx % 4 == 0.  The same planes serve both consumers (one split
+ *   definition: scale 2^(e-14), leading term fp16(x/s), residual fp16(x/s - leading)); at d = 128 that is ctgcn_gru_layer_presplit_f32.
  *   workspace: ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, K, n_out, n_long) bytes, 256-byte aligned; n_out is the
  *   width of the projection that follows (its weight planes share the workspace); n_long hub rows pass through an fp32
  *   scratch at the end of it.

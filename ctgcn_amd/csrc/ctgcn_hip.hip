@@ -2045,17 +2045,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
 // ------------------------------------------------------------------------------------------------
 // gru_layer8_h2_kernel: the same fusion with EIGHT waves per block — two per SIMD, so that one wave's LDS / MFMA-result
 // latency is covered by the other instead of by hand-placed loads.  256 registers per wave; wave w owns hidden units
-// [16w, 16w+16) of both matrices = 48 fragments: W_hh (24) pinned to AGPRs, 15 fragments of W_ih (the whole residual plane +
-// chunk 3 of the leading plane) in LDS (120 KB), 9 in VGPRs.  That much LDS for weights forces 16-row tiles: one unit per step,
+// [16w, 16w+16) of both matrices = 48 fragments: W_hh (24) + 8 of W_ih pinned to AGPRs, the 12 fragments of W_ih's residual plane in
+// LDS (96 KB), 4 in VGPRs (15 in LDS until the x products went to one accumulator and freed 12 registers: 4.36 -> 4.28 ms; with 9
+// in LDS the allocator starts reloading from scratch inside the unit: 4.33).  That much LDS for weights forces 16-row tiles: one unit per step,
 // h planes double buffered by step parity (published right after the gate math), a lane owns ONE (row, 4 hidden units) patch
 // for the whole tile, so h_{t-1} and the running sum stay in registers; the sum goes through the idle x slot for the final
 // LayerNorm.  Sum-over-steps form only.  Same arithmetic as the other two paths (bit-identical).
 // ------------------------------------------------------------------------------------------------
-constexpr int L8_WL = 15;
+constexpr int L8_WL = 12;
 constexpr int L8_PITCH = 128;                            // halfs per plane row, no padding
 // half index of element k of row r (r < 16): 16-byte segment k / 8 goes to segment (k / 8) ^ r
 __device__ __forceinline__ int l8_off(int r, int k) { return ((((k >> 3) ^ r) & 15) << 3) | (k & 7); }
-__device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : (c == 3 ? 12 + g : -1); }
+__device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : -1; }
 
 template <bool PRESPLIT, bool REDUCE>
 __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
@@ -2236,7 +2237,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                         h2 = *(const h8v *)(&Hs[hp][1][col][l8_off(col, c * 32 + 8 * grp)]);
                     }
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) wr[g] = Wl[wave][l8_lds_slot(1, c, g)][lane];
+                    for (int g = 0; g < 3; ++g) wr[g] = l8_lds_slot(1, c, g) >= 0 ? Wl[wave][l8_lds_slot(1, c, g) < 0 ? 0 : l8_lds_slot(1, c, g)][lane] : Wi[1][c][g];
                     __builtin_amdgcn_sched_barrier(0);
                     // = CTGCN_H2_MFMA1(Wi, c, x1, x2, acc0): one accumulator, small terms first (w1·x2, w2·x1, then w1·x1); LDS-resident
                     // fragments of the leading plane are read on the spot

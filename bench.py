@@ -372,9 +372,9 @@ def main():
         def layer_obj(group, name, per_step):
             flops = sum(m["rows"] * (2 * m["steps"] - 1) * 2.0 * 128 * 384 for _, m in group)
             ms = sum(t for t, _ in group)
-            # compulsory traffic: the x rows in (as fp32 or as two fp16 planes: 512 B per row-step either way), one output row out —
-            # per step for the temporal form, whose LayerNorm pass reads and writes every row once more
-            hbm = sum(m["rows"] * (m["steps"] * 512.0 + (3 * m["steps"] * 512.0 if per_step else 512.0)) for _, m in group)
+            # compulsory traffic: the x rows in (as fp32 or as two fp16 planes: 512 B per row-step either way), one output row out
+            # (per step for the temporal form)
+            hbm = sum(m["rows"] * (m["steps"] * 512.0 + (m["steps"] * 512.0 if per_step else 512.0)) for _, m in group)
             return {"kernel": name, "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
                     # tools/probes/mfma_peak_probe.hip: v_mfma_f32_16x16x32_f16 sustains 2.15-2.3 PFLOP/s with real operands on this
@@ -392,8 +392,8 @@ def main():
                                 "consumed from the MFMA accumulators; fp16x2 split%s)"
                                 % ("; x arrives as fp16 planes + row scales written by the aggregation kernel" if pres else ""), False)
         if seqf:
-            tl = layer_obj(seqf, "gru_layer8_h2_kernel<per step> + layernorm_rows_kernel (temporal GRU: the same kernel leaving the raw h_t of "
-                                 "every step, then LayerNorm of the rows in place)", True)
+            tl = layer_obj(seqf, "gru_layer8_h2_kernel<per step> (temporal GRU: the same kernel emitting LayerNorm(h_t) of every step through an "
+                                 "fp32 staging buffer in LDS)", True)
             if fr is None:
                 fr = tl
             else:

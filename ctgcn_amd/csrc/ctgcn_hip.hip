@@ -774,21 +774,6 @@ __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src,
 {
     *(float2 *)(dst + lane * 2) = gru_layernorm_vals(*(const float2 *)(src + lane * 2), lane, gamma, beta, eps);
 }
-// LayerNorm of rows of 128 floats in place, one wave per row: the second half of the per-step form of gru_layer8_h2_kernel, whose
-// eight waves each hold 16 of a row's 128 values and have no LDS left to exchange row statistics (8.2 GB read + written per 1M x 16)
-__global__ __launch_bounds__(256) void layernorm_rows_kernel(int64_t rows, float *data, const float *gamma, const float *beta, float eps)
-{
-    constexpr int RPW = 4;                                 // rows per wave: four independent load -> reduce -> store chains in flight
-    const int lane = threadIdx.x & 63;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
-    float2 v[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i)
-        if (row0 + i < rows) v[i] = *((const float2 *)(data + (row0 + i) * GRU_H) + lane);
-#pragma unroll
-    for (int i = 0; i < RPW; ++i)
-        if (row0 + i < rows) *((float2 *)(data + (row0 + i) * GRU_H) + lane) = gru_layernorm_vals(v[i], lane, gamma, beta, eps);
-}
 
 template <bool REDUCE, bool SAVE>
 __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
@@ -2072,6 +2057,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     __shared__ float csc_hh[4][GRU_H];                   // rows 0-2: product scales of the three gates, row 3: b_hn
     __shared__ float bias_s[3][GRU_H];
     __shared__ h8v Wl[8][L8_WL][64];
+    // per-step form: h_t of the unit's 16 rows in fp32, double buffered by unit parity; the rows leave (LayerNorm, 512-byte stores) at the
+    // start of the NEXT unit, two per wave — the staging the kernel pair uses, so the outputs are the pair's bit for bit
+    __shared__ float hrow[REDUCE ? 1 : 2][REDUCE ? 1 : 16][GRU_PITCH];
     static_assert(sizeof(_Float16) * 2 * 16 * L8_PITCH >= sizeof(float) * 16 * GRU_H, "a plane buffer must hold 16 fp32 rows");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int col = lane & 15, grp = lane >> 4;
@@ -2200,6 +2188,14 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     // the other buffer and has no h MFMAs — no barrier pair at the tile end (they were 10 % of the kernel: 237 of 2 260 ns per unit).
     int pb = 0, ln_buf = 0, ln_last = -1;
     int64_t ln_row0 = 0;
+    int em_buf = 0, em_last = -1, em_t = 0;                // per-step form: the unit whose rows are still to be emitted
+    int64_t em_row0 = 0;
+    auto pending_rows = [&]() {
+        if (em_last < 0) return;
+        for (int r = wave * 2; r < wave * 2 + 2; ++r)
+            if (r <= em_last) gru_layernorm_row(hrow[REDUCE ? 0 : em_buf][REDUCE ? 0 : r], a.out + ((em_row0 + r) * S + em_t) * GRU_H, lane, a.gamma, a.beta, a.eps);
+        em_last = -1;
+    };
     auto pending_layernorm = [&]() {
         if (ln_last < 0) return;
         for (int r = wave * 2; r < wave * 2 + 2; ++r)
@@ -2212,6 +2208,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
         f4v hprev = zero4, hsum = zero4;
         for (int t = 0; t < S; ++t) {
             if (REDUCE && t == 0) pending_layernorm();
+            if (!REDUCE) pending_rows();                   // the previous unit's rows (staged before its barrier)
             // ---- x of the next unit (registers -> planes of the other slot, then the request for the unit after it) is staged in
             // slices behind this unit's MFMA groups: see stage_slice
             const bool stage_live = ptile < ntiles;
@@ -2285,7 +2282,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             }
             hprev = h;
             if (REDUCE) hsum = t > 0 ? hsum + h : h;
-            else if (col <= last) *(f4v *)(a.out + ((row0 + col) * S + t) * GRU_H + oc) = h;      // raw h_t; layernorm_rows_kernel follows
+            else {
+                *(f4v *)(&hrow[REDUCE ? 0 : pb][REDUCE ? 0 : col][oc]) = h;
+                em_buf = pb; em_last = last; em_t = t; em_row0 = row0;
+            }
 #ifdef CTGCN_LAYER_TIMELINE
             asm volatile("" :: "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
 #endif
@@ -2316,6 +2316,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
         TL_MARK(4)
     }
     if (REDUCE) pending_layernorm();       // the block's last tile (its rows are visible: the last unit ended with a barrier)
+    else pending_rows();
 #ifdef CTGCN_LAYER_TIMELINE
     if (a.timeline && lane == 0)
         for (int i = 0; i < 6; ++i) a.timeline[((size_t)blockIdx.x * 8 + wave) * 6 + i] = tl[i];
@@ -3414,17 +3415,13 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
         }
 #endif
     } else if (nw == 8) {
-        // per-step form (temporal GRU): the 8-wave kernel leaves the raw h_t, a row-per-wave pass normalises them in place
+        // per-step form (temporal GRU): LayerNorm(h_t) of every unit leaves through an fp32 staging buffer in LDS (free since the
+        // weights take 96 instead of 120 KB), two rows per wave, during the next unit
         const int64_t nt8 = (rows + 15) / 16;
 #ifdef CTGCN_LAYER_TIMELINE
         a.timeline = nullptr;
 #endif
         hipLaunchKernelGGL((gru_layer8_h2_kernel<false, false>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
-        if (ln_weight) {
-            const int64_t nrow = rows * steps;
-            if ((nrow + 15) / 16 > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "gru_layer: too many rows for one LayerNorm launch");
-            hipLaunchKernelGGL(layernorm_rows_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, (hipStream_t)stream, nrow, out, ln_weight, ln_bias, ln_eps);
-        }
     } else {
         if (reduce_sum) hipLaunchKernelGGL((gru_layer_h2_kernel<true, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((gru_layer_h2_kernel<false, 4>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

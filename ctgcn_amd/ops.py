@@ -264,7 +264,7 @@ def layer_kernel_enabled(reduce_sum=True):
     resident on the CU (registers + LDS), the projection consumed from the MFMA accumulators (never materialised).  Bit-identical to
     the projection + recurrence kernel pair (tests/test_gpu_gru.py) at 1/7 of its HBM traffic.
     CTGCN_GRU_LAYER = 1 (default): both forms — the sum-over-steps form of CoreDiffusion (4.2-4.6 vs 6.4 ms per 1M x 8 call) and the
-    per-step form of the temporal GRU (raw h_t from the 8-wave kernel + a LayerNorm pass: 14.3 vs 15.7 ms per 1M x 16 call).
+    per-step form of the temporal GRU (LayerNorm(h_t) emitted per unit through an LDS staging buffer: 11.8-12.4 vs 15.7 ms per 1M x 16 call).
     sum: the sum form only.  0: never.  CTGCN_GRU_LAYER_WAVES=4 selects the 4-wave builds (one wave per SIMD: 5.2 / 16.5 ms)."""
     import os
     mode = os.environ.get("CTGCN_GRU_LAYER", "1")

@@ -22,17 +22,24 @@ def build(force=False, verbose=False):
     if verbose:
         common.append("-Rpass-analysis=kernel-resource-usage")
     objs, procs = [], []
-    for src in SRCS:
-        obj = os.path.splitext(src)[0] + ".o"
-        extra = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.path.basename(src) == "ctgcn_hip.hip" else []
-        procs.append((src, subprocess.Popen(common + extra + ["-c", src, "-o", obj])))
-        objs.append(obj)
-    for src, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, "hipcc -c " + src)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs)
-    for obj in objs:
-        os.remove(obj)
+    try:
+        for src in SRCS:
+            obj = os.path.splitext(src)[0] + ".o"
+            extra = ["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.path.basename(src) == "ctgcn_hip.hip" else []
+            objs.append(obj)
+            procs.append((src, subprocess.Popen(common + extra + ["-c", src, "-o", obj])))
+        failed = [(src, pr.returncode) for src, pr in procs if pr.wait() != 0]
+        if failed:
+            raise subprocess.CalledProcessError(failed[0][1], "hipcc -c " + failed[0][0])
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs)
+    finally:
+        for _, pr in procs:         # a failed spawn leaves the earlier compiles running: do not orphan them
+            if pr.poll() is None:
+                pr.kill()
+                pr.wait()
+        for obj in objs:
+            if os.path.exists(obj):
+                os.remove(obj)
     return OUT
 
 

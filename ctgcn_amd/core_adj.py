@@ -39,6 +39,7 @@ class CoreAdj(object):
         self._t = None                                           # transposed arrays, built on demand when not symmetric
         self._moved = {}                                         # copies on other devices (as_core_adj: moved once, not per call)
         self._long = {}                                          # cached hub-row lists (forward / transposed)
+        self._plan = None                                        # cached row plan of the inference path (row_plan)
         assert 0 <= self.K <= _lib.MAX_SLOTS
 
     # ------------------------------------------------------------------ list-like surface
@@ -98,6 +99,56 @@ class CoreAdj(object):
             idx = torch.nonzero((rp[1:] - rp[:-1]) > self.LONG_ROW).flatten().to(torch.int32)
             self._long[key] = idx if idx.numel() else None
         return self._long[key]
+
+    # ------------------------------------------------------------------ repeated rows of H (inference path)
+    PLAN_TILE = 16      # sequences per tile of the GRU layer kernel (gru_layer8_h2_kernel)
+
+    def row_plan(self):
+        """Row plan for ctgcn_core_aggregate_split_f32 + ctgcn_gru_layer_presplit_f32, or None (K > 32).
+
+        layers.py:41-48: res_j = res_{j-1} + A_j x, so as long as no entry of row v has arrived (slots below the row's first tag f;
+        nested lists: f = K - capped core number) H[v, 0..f-1] is the same row relu(x_v) f times, and the GRU multiplies it by W_ih f
+        times (layers.py:58-59).  The plan lets the kernels write and multiply it once:
+          order      int32[n]   matrix row handled at position p.  Rows with equal repeat patterns are neighbours, so that the 16
+                                sequences of a GRU tile share one pattern; inside a pattern rows go by falling degree (the two rows of a
+                                wave and the eight of a block are equally long, and the long blocks of a launch start first).
+          tile_mask  int32[ceil(n / 16)]  bit j set = slot j carries a new row for at least one of the tile's positions (bit 0 always)
+          inverse    int32[n]   position of matrix row v (hub rows are looked up here)
+        Static per graph: built once on the device, cached."""
+        if self.K > 32 or self.n == 0:
+            return None
+        if self._plan is None:
+            dev, n, K = self.device, self.n, self.K
+            rp = self.row_ptr.long()
+            deg = rp[1:] - rp[:-1]
+            bit = torch.ones(K, dtype=torch.int64, device=dev) << torch.arange(K, dtype=torch.int64, device=dev)
+            if self.nested:
+                # entries are sorted by (row, slot): the first entry of a row carries its smallest tag; every later slot adds P != 0
+                first = torch.full((n,), K, dtype=torch.int64, device=dev)
+                has = deg > 0
+                first[has] = self.slot[rp[:-1][has]].long()
+                mask = ((torch.arange(K, dtype=torch.int64, device=dev)[None, :] >= first[:, None]) * bit[None, :]).sum(1) | 1
+            else:
+                rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+                present = torch.zeros(n * K, dtype=torch.bool, device=dev)
+                present[rows * K + self.slot.long()] = True
+                mask = (present.view(n, K) * bit[None, :]).sum(1) | 1
+            o1 = torch.argsort(deg, descending=True, stable=True)
+            order = o1[torch.argsort(mask[o1], descending=True, stable=True)]
+            T = self.PLAN_TILE
+            ntiles = -(-n // T)
+            padded = torch.ones(ntiles * T, dtype=torch.int64, device=dev)
+            padded[:n] = mask[order]
+            tiles = padded.view(ntiles, T)
+            tmask = torch.zeros(ntiles, dtype=torch.int64, device=dev)
+            for j in range(K):
+                tmask |= ((tiles >> j) & 1).any(1).long() << j
+            inverse = torch.empty(n, dtype=torch.int64, device=dev)
+            inverse[order] = torch.arange(n, device=dev)
+            self._plan = dict(order=order.to(torch.int32).contiguous(), tile_mask=tmask.to(torch.int32).contiguous(),
+                              inverse=inverse.to(torch.int32).contiguous(),
+                              new_rows=int(sum(int(((tmask >> j) & 1).sum()) for j in range(K))) * T)   # (position, slot) rows written per layer (incl. tile padding)
+        return self._plan
 
     # ------------------------------------------------------------------ transposed view (backward pass)
     def transposed(self):

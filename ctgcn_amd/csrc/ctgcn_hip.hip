@@ -88,6 +88,12 @@ struct AggArgs {
     int32_t long_thresh;
     int32_t hub_groups;    // lane groups of the hub block that share one long row
     int32_t hub_compact;   // fwd hub kernel: write hub row i of long_rows to out row i (a compact scratch) instead of its own row
+    // agg_fwd_split*_kernel with the GRU layer kernel as consumer (d = 128): rows are processed in `order` (position p takes matrix row
+    // order[p], its K output rows are rows p K .. p K + K - 1 of the planes) and slot j of position p is only written when bit j of
+    // tmask[p / 16] is set — a row whose first entry is tagged f has H[row, 0] = ... = H[row, f - 1] (nothing but the self loop has arrived),
+    // the consumer multiplies the repeated row by W_ih once.  Both null: natural order, every slot written.
+    const int32_t *order;
+    const uint32_t *tmask;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1240,8 +1246,11 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
                                                    float *__restrict__ scale, int32_t kp, float residual_scale)
 {
     const int lig = threadIdx.x & (LPR - 1);
-    const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
-    if (row >= a.n) return;
+    const int64_t pos = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
+    if (pos >= a.n) return;
+    const int64_t row = a.order ? (int64_t)a.order[pos] : pos;
+    // the block's 256 / LPR positions lie in one 16-position tile: a scalar load
+    const uint32_t need = a.tmask ? a.tmask[((int64_t)blockIdx.x * (256 / LPR)) >> 4] : 0xffffffffu;
     const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
     if (end - start > a.long_thresh) return;          // hub row: agg_fwd_hub_kernel into the compact scratch, split afterwards
     const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0;
@@ -1269,6 +1278,10 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
         for (int c = 0; c < CH; ++c) {
             R[c] += P[c];
             if (!nested) P[c] = vzero<4>();
+        }
+        if (!((need >> (cur & 31)) & 1)) { ++cur; return; }      // a repeat of the previous slot's row that the consumer never reads
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
             v[c] = relu ? vmax0(R[c]) : R[c];
             if (!live[c]) v[c] = vzero<4>();
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].y)), fmaxf(fabsf(v[c].z), fabsf(v[c].w))));
@@ -1276,7 +1289,7 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
         m = group_max<LPR>(m);
         float s, inv;
         h2_scale(m, s, inv);
-        const int64_t orow = row * a.K + cur;
+        const int64_t orow = pos * a.K + cur;
         if (lig == 0) scale[orow] = s;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -1758,6 +1771,11 @@ struct LayerArgs {
     int64_t ldo;
     const _Float16 *xp1, *xp2;   // PRESPLIT (gru_layer8_h2_kernel<true>): the fp16 planes [rows * steps, 128] and row scales of x,
     const float *xps;            // as ctgcn_core_aggregate_split_f32 writes them (x is unused then)
+    // PRESPLIT + REDUCE: the plan ctgcn_core_aggregate_split_f32 wrote the planes under (both null: natural order, every step present).
+    // order[p] = output row of sequence p; bit t of tmask[tile] clear = x_t of all 16 sequences of the tile repeats x_{t-1} (not stored):
+    // the x·W_ih products of step t-1 are kept, the step costs the h·W_hh half only.  Bit 0 is always set; steps <= 32.
+    const int32_t *order;
+    const uint32_t *tmask;
 #ifdef CTGCN_LAYER_TIMELINE
     unsigned long long *timeline;   // diagnostic build: per (block, wave) sums of the unit phases, see tools/layer_timeline.py
 #endif
@@ -2061,6 +2079,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     // start of the NEXT unit, two per wave — the staging the kernel pair uses, so the outputs are the pair's bit for bit
     __shared__ float hrow[REDUCE ? 1 : 2][REDUCE ? 1 : 16][GRU_PITCH];
     static_assert(sizeof(_Float16) * 2 * 16 * L8_PITCH >= sizeof(float) * 16 * GRU_H, "a plane buffer must hold 16 fp32 rows");
+    constexpr bool DEDUP = PRESPLIT && REDUCE;           // the aggregation's row plan (LayerArgs::order / tmask) only exists on that path
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int col = lane & 15, grp = lane >> 4;
     const int oc = wave * 16 + 4 * grp;
@@ -2161,14 +2180,23 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             request_next();
         }
     };
+    // units that need x: all of them, or (DEDUP) the steps whose tmask bit is set — the x pipeline below runs over those only
+    auto tile_mask = [&](int64_t tile) -> uint32_t {
+        if (DEDUP) return (a.tmask && tile < ntiles) ? a.tmask[tile] : 0xffffffffu;
+        return 0xffffffffu;
+    };
+    uint32_t pmask = 0xffffffffu;                          // mask of the tile the x pipeline is at
     auto next_unit = [&](int64_t &tile, int &t) {
-        if (++t >= S) { t = 0; tile += gridDim.x; }
+        do {
+            if (++t >= S) { t = 0; tile += gridDim.x; if (DEDUP) pmask = tile_mask(tile); }
+        } while (DEDUP && !((pmask >> t) & 1));
     };
 
     if ((int64_t)blockIdx.x >= ntiles) return;
     f4v xr;
     int64_t ptile = blockIdx.x;                           // unit whose x sits in xr
     int pt = 0;
+    if (DEDUP) pmask = tile_mask(ptile);
     load_x(ptile, pt, xr);
     stage_x(0, xr);
     next_unit(ptile, pt);
@@ -2199,14 +2227,20 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     auto pending_layernorm = [&]() {
         if (ln_last < 0) return;
         for (int r = wave * 2; r < wave * 2 + 2; ++r)
-            if (r <= ln_last) gru_layernorm_row((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H, a.out + (ln_row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
+            if (r <= ln_last) {
+                const int64_t orow = (DEDUP && a.order) ? (int64_t)a.order[ln_row0 + r] : ln_row0 + r;
+                gru_layernorm_row((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H, a.out + orow * a.ldo, lane, a.gamma, a.beta, a.eps);
+            }
         ln_last = -1;
     };
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * 16;
         const int last = (int)min((int64_t)16, a.rows - row0) - 1;
         f4v hprev = zero4, hsum = zero4;
+        const uint32_t tmask = tile_mask(tile);
+        f4v gi[3] = {zero4, zero4, zero4};               // x_t·W_ih + b of the last step that brought a new x (kept over its repeats)
         for (int t = 0; t < S; ++t) {
+            const bool fresh = !DEDUP || ((tmask >> t) & 1);
             if (REDUCE && t == 0) pending_layernorm();
             if (!REDUCE) pending_rows();                   // the previous unit's rows (staged before its barrier)
             // ---- x of the next unit (registers -> planes of the other slot, then the request for the unit after it) is staged in
@@ -2217,7 +2251,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 load_x(ptile, pt, xr);
             };
             // ---- this unit
-            const float rs = xscale[slot][col];
             f4v acc0[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};
             auto body = [&](auto with_h_tag) {
                 constexpr bool with_h = decltype(with_h_tag)::value;
@@ -2263,12 +2296,23 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     if (2 * c + 1 < 6) stage_slice(2 * c + 1, slot ^ 1, xr, stage_live, request_next);
                 }
             };
-            if (t > 0) body(std::true_type{}); else body(std::false_type{});
-            TL_MARK(0)
-            f4v gi[3];
+            if (fresh) {
+                const float rs = xscale[slot][col];
+                if (t > 0) body(std::true_type{}); else body(std::false_type{});
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
+                for (int g = 0; g < 3; ++g)
+                    gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
+            } else {
+                // x_t = x_{t-1} for the whole tile: gi stands, only h_{t-1}·W_hh is new (t > 0: bit 0 of a mask is always set)
+                const int hp = pb ^ 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const h8v h1 = *(const h8v *)(&Hs[hp][0][col][l8_off(col, c * 32 + 8 * grp)]);
+                    const h8v h2 = *(const h8v *)(&Hs[hp][1][col][l8_off(col, c * 32 + 8 * grp)]);
+                    CTGCN_H2_MFMA1(Wh, c, h1, h2, ach)
+                }
+            }
+            TL_MARK(0)
             const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
             const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
             f4v h;
@@ -2310,7 +2354,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
 #ifdef CTGCN_LAYER_TIMELINE
             ++tl[5];
 #endif
-            slot ^= 1;
+            if (fresh) slot ^= 1;
             pb ^= 1;
         }
         TL_MARK(4)
@@ -3119,6 +3163,7 @@ size_t ctgcn_core_aggregate_split_workspace_bytes(int64_t n_rows, int32_t d, int
 int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr, const int32_t *col_idx,
                                    const float *val, const uint8_t *slot, const float *X, int64_t ldx, uint32_t flags,
                                    const int32_t *long_rows, int32_t n_long, int32_t long_threshold, int32_t n_out,
+                                   const int32_t *row_order, const uint32_t *tile_mask, const int32_t *long_rows_pos,
                                    void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n_rows < 0 || d <= 0 || ldx < d || n_out < 1) return fail(CTGCN_E_INVALID, "core_aggregate_split: bad sizes n=%lld d=%d ldx=%lld", (long long)n_rows, d, (long long)ldx);
@@ -3129,6 +3174,10 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
     if ((d & 3) || d > 512 || (ldx & 3) || !aligned16(X) || (reinterpret_cast<uintptr_t>(workspace) & 255u))
         return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: needs d %% 4 == 0, d <= 512, 16-byte aligned rows, 256-byte aligned workspace");
     if (n_long < 0 || (n_long > 0 && (!long_rows || long_threshold < 1))) return fail(CTGCN_E_INVALID, "core_aggregate_split: bad hub row list");
+    if ((row_order == nullptr) != (tile_mask == nullptr)) return fail(CTGCN_E_INVALID, "core_aggregate_split: row_order and tile_mask come together");
+    if (row_order && (K > 32 || d != 128 || n_out != 1))
+        return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: a row plan needs K <= 32 and the GRU layer kernel as consumer (d = 128, n_out = 1)");
+    if (row_order && n_long > 0 && !long_rows_pos) return fail(CTGCN_E_INVALID, "core_aggregate_split: hub rows under a row plan need their positions");
     if (workspace_bytes < ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, K, n_out, n_long))
         return fail(CTGCN_E_WORKSPACE, "core_aggregate_split: workspace too small (ctgcn_core_aggregate_split_workspace_bytes)");
     hipStream_t st = (hipStream_t)stream;
@@ -3143,6 +3192,7 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
     a.src = X; a.ldsrc = ldx; a.self = nullptr; a.out = hub; a.out_ld = (int64_t)K * d;
     a.flags = flags; a.accumulate = 0;
     a.long_rows = long_rows; a.n_long = n_long; a.long_thresh = long_threshold;
+    a.order = row_order; a.tmask = tile_mask;
     const AggPlan p = plan_for(d, true);
     a.chunks = p.chunks;
     a.passes = p.passes;
@@ -3176,7 +3226,8 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
         HUBCASE(8) else HUBCASE(16) else HUBCASE(32) else HUBCASE(64)
 #undef HUBCASE
         HIP_TRY(hipGetLastError());
-        const int rc = ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, long_rows, K, rsc, stream);
+        // (hub rows leave with all K slots, whatever the tile mask says: the extra rows are never read)
+        const int rc = ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, row_order ? long_rows_pos : long_rows, K, rsc, stream);
         if (rc != CTGCN_OK) return rc;
     }
     return CTGCN_OK;
@@ -3432,9 +3483,11 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
 
 int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, const void *planes, const float *w_ih, const float *w_hh,
                                  const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                                 float *out, int64_t ld_out, void *stream)
+                                 float *out, int64_t ld_out, const int32_t *row_order, const uint32_t *tile_mask, void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit: only d_in = hidden = %d is built (got %d)", GRU_H, hidden);
+    if ((row_order == nullptr) != (tile_mask == nullptr)) return fail(CTGCN_E_INVALID, "gru_layer_presplit: row_order and tile_mask come together");
+    if (row_order && steps > 32) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit: a row plan needs steps <= 32");
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_layer_presplit: bad sizes rows=%lld steps=%d", (long long)rows, steps);
     if (rows == 0) return CTGCN_OK;
     if (!planes || !w_ih || !w_hh || !out) return fail(CTGCN_E_INVALID, "gru_layer_presplit: null pointer");
@@ -3455,6 +3508,7 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
     a.xp1 = (const _Float16 *)planes;
     a.xp2 = a.xp1 + nrow * GRU_H;
     a.xps = (const float *)(a.xp2 + nrow * GRU_H);
+    a.order = row_order; a.tmask = tile_mask;
 #ifdef CTGCN_LAYER_TIMELINE
     a.timeline = nullptr;
 #endif

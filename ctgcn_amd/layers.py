@@ -145,7 +145,7 @@ class MLP(nn.Module):
                 return layer.weight.t() + layer.bias if layer.bias is not None else layer.weight.t().contiguous()
             out = torch.sparse.mm(h, layer.weight.t())
             return out if layer.bias is None else out + layer.bias
-        needs_grad = torch.is_grad_enabled() and (h.requires_grad or layer.weight.requires_grad)
+        needs_grad = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in layer.parameters()))
         if not needs_grad and h.dim() == 2 and ops.linear_split_ok(h, layer.weight):
             return ops.linear_split(h, layer.weight, layer.bias)     # fp32-accurate split GEMM on the 16-bit matrix cores (inference)
         return layer(h)

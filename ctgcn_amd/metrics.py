@@ -30,6 +30,8 @@ class NegativeSamplingLoss(nn.Module):
         self.neg_sample_num = neg_num
         self.Q = Q
         self.seed = seed                            # None: a fresh stream per call (the reference reseeds from the OS)
+        self.shared_base = None                     # snapshot_parallel.share_loss_seed: one entropy-drawn stream for all ranks of a job
+        self._shared_calls = 0
         self._cache = {}
 
     def _device_inputs(self, i, device):
@@ -62,7 +64,13 @@ class NegativeSamplingLoss(nn.Module):
         pos_idx = torch.empty(sample_num, dtype=torch.int64, device=device)
         neg_idx = torch.empty(num, dtype=torch.int64, device=device)
         scratch = torch.empty(num, dtype=torch.int64, device=device)
-        seed = (_seed_base + next(_seed_counter) * 0x9E3779B97F4A7C15) if self.seed is None else (self.seed * 1000003 + i)
+        if self.seed is not None:
+            seed = self.seed * 1000003 + i
+        elif self.shared_base is not None:          # every rank makes the same sequence of calls: the same draws everywhere
+            self._shared_calls += 1
+            seed = self.shared_base + self._shared_calls * 0x9E3779B97F4A7C15
+        else:
+            seed = _seed_base + next(_seed_counter) * 0x9E3779B97F4A7C15
         with torch.cuda.device(device):
             check(_lib.load().ctgcn_neg_sampling_indices(batch.numel(), ptr(batch), ptr(pairs.row_ptr), ptr(pairs.col), num, table.numel(),
                                                          ptr(table), ctypes.c_uint64(seed & (2 ** 64 - 1)), ptr(offsets), ptr(node_idx),

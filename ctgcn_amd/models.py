@@ -140,38 +140,51 @@ class CTGCN(nn.Module):
         return cache[1]
 
     def _branches_use_own_kernels(self, x_list):
+        """The verdict is cached on what it depends on — the inputs' KIND (identity or not, checked by layers._is_identity, whose own cache
+        keeps the tensor alive), shape, strides and alignment — never on id(x): a recycled id with another tensor must not reuse it."""
         from . import ops
-        key = (ops.forward_split_mode(), ops.linear_split_enabled()) + tuple(
-            (id(x), x.is_sparse, tuple(x.shape)) if torch.is_tensor(x) else None for x in x_list)
+        from .layers import _is_identity
+
+        def kind(x):
+            if not torch.is_tensor(x):
+                return None
+            if x.is_sparse:
+                return ("sparse", _is_identity(x), tuple(x.shape))
+            return ("dense", tuple(x.shape), tuple(x.stride()), x.data_ptr() % 16, x.dtype, x.device)
+        key = (ops.forward_split_mode(), ops.linear_split_enabled()) + tuple(kind(x) for x in x_list)
         cache = getattr(self, "_own_kernel_cache", None)
         if cache is None or cache[0] != key:
             cache = self._own_kernel_cache = (key, self._branches_use_own_kernels_uncached(x_list))
         return cache[1]
 
     def _branches_use_own_kernels_uncached(self, x_list):
+        """Decided by the dispatch predicates the branch itself uses (ops.linear_split_ok on the real first operand, on a probe row of
+        the right width for the layers behind it — outputs of this library's kernels are fresh contiguous tensors)."""
         from . import ops
         from .layers import _is_identity
         if self.rnn_type != 'GRU' or self.output_dim != 128 or ops.forward_split_mode() != 2 or not ops.linear_split_enabled():
             return False
         for t, x in enumerate(x_list):
-            if not torch.is_tensor(x):
+            if not torch.is_tensor(x) or not x.is_cuda:
                 return False
             mlp = self.mlp_list[t]
             layers = [mlp.linear] if mlp.layer_num == 1 else list(mlp.linears)
             if x.is_sparse:
-                if not _is_identity(x):
+                if not _is_identity(x) or layers[0].weight.dtype != torch.float32:
                     return False                                # generic sparse features: torch.sparse.mm
                 layers = layers[1:]                             # Linear(I) = W^T + b: transpose kernel
+                h = None
                 width = mlp.output_dim if mlp.layer_num == 1 else mlp.hidden_dim
             else:
-                width = x.shape[1]
-            for lin in layers:                                  # dense Linear layers must qualify for ctgcn_linear_f32
-                if width < 32 or lin.weight.dtype != torch.float32 or not lin.weight.is_cuda:
+                h, width = x, x.shape[1]
+            for lin in layers:                                  # dense Linear layers must be taken by ctgcn_linear_f32 (MLP._apply_linear)
+                probe = h if h is not None else torch.empty(1, width, dtype=torch.float32, device=x.device)
+                if probe.dim() != 2 or not ops.linear_split_ok(probe, lin.weight):
                     return False
-                width = lin.weight.shape[0]
+                h, width = None, lin.weight.shape[0]
             for cd in self.duffision_list[t].diffusion_list:    # CoreDiffusion GRU input width: 128 (resident-weight kernels) or split-GEMM-able
-                if cd.input_dim != 128 and cd.input_dim < 32:
-                    return False
+                if cd.input_dim % 4 or cd.input_dim < 32 or cd.input_dim > 512 or not cd.rnn.weight_ih_l0.is_contiguous():
+                    return False                                # ops.aggregate_split_ok would send it to the fp32 H + library path
         return True
 
     def forward(self, x_list, adj_list):

@@ -433,9 +433,52 @@ def aggregate_split_ok(rnn, x, adj):
     return len(_row_chunks(_lib.load(), adj.n, adj.K, hid)) == 1
 
 
+def row_plan_enabled():
+    """CTGCN_DEDUP=0: the inference path writes and multiplies every (node, core) row of H, repeated or not (A/B runs)."""
+    import os
+    return os.environ.get("CTGCN_DEDUP", "1") != "0"
+
+
+def aggregate_split_planes(x, adj, n_out, plan=None, ws=None):
+    """ctgcn_core_aggregate_split_f32: relu(cumulative A_k x) as fp16 planes + row scales in a workspace (returned).  n_out = width of
+    the GEMM that follows (1: the GRU layer kernel).  plan = adj.row_plan() (layer-kernel consumer only): repeated rows are not written."""
+    lib = _lib.load()
+    n, d = x.shape
+    flags = adj.flags | _lib.F_RELU
+    long_rows = adj.long_rows()
+    n_long = 0 if long_rows is None else long_rows.numel()
+    ws_bytes = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, d, adj.K, n_out, n_long))
+    if ws is None:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    long_pos = plan["inverse"][long_rows.long()].contiguous() if (plan is not None and n_long) else None
+    with _timed("agg_fwd", n=n, d=d, K=adj.K, nnz=adj.nnz, split=True, rows_written=(plan["new_rows"] if plan is not None else n * adj.K)):
+        check(lib.ctgcn_core_aggregate_split_f32(n, d, adj.K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x), x.stride(0),
+                                                 flags, ptr(long_rows), n_long, adj.LONG_ROW, n_out,
+                                                 ptr(plan["order"]) if plan is not None else None, ptr(plan["tile_mask"]) if plan is not None else None,
+                                                 ptr(long_pos), ptr(ws), ws_bytes, _stream()), "ctgcn_core_aggregate_split_f32")
+    return ws, ws_bytes
+
+
+def gru_layer_presplit(ws, n, K, rnn, norm, out, plan=None):
+    """ctgcn_gru_layer_presplit_f32 on the planes aggregate_split_planes(x, adj, 1, plan) wrote: LayerNorm(sum_k GRU(H)_k) -> out."""
+    lib = _lib.load()
+    hid = rnn.hidden_size
+    bias, b_hn = _gru_bias(rnn, hid)
+    w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous()
+    ln_w = None if norm is None else norm.weight
+    ln_b = None if norm is None else norm.bias
+    eps = 0.0 if norm is None else float(norm.eps)
+    with _timed("gru_layer", rows=n, steps=K, reduce_sum=True, presplit=True, new_rows=(plan["new_rows"] if plan is not None else n * K)):
+        check(lib.ctgcn_gru_layer_presplit_f32(n, K, hid, ptr(ws), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
+                                               ptr(out), out.stride(0), ptr(plan["order"]) if plan is not None else None,
+                                               ptr(plan["tile_mask"]) if plan is not None else None, _stream()), "ctgcn_gru_layer_presplit_f32")
+    return out
+
+
 def core_diffusion_split(x, adj, rnn, norm, out=None):
     """LayerNorm(sum_k GRU(relu(cumulative A_k x))_k) — CoreDiffusion.forward (layers.py:41-62) for inference, no fp32 H:
-    aggregation -> fp16 planes + row scales, then  d_in = hidden = 128: the register-resident GRU layer kernel reads the planes;
+    aggregation -> fp16 planes + row scales, then  d_in = hidden = 128: the register-resident GRU layer kernel reads the planes
+    (under the graph's row plan: rows of H that repeat the row before are neither written nor multiplied by W_ih again);
     d_in != 128: split GEMM -> gate pre-activations -> recurrence + sum + LayerNorm kernel."""
     lib = _lib.load()
     n, d = x.shape
@@ -446,27 +489,17 @@ def core_diffusion_split(x, adj, rnn, norm, out=None):
     elif not (out.shape == (n, hid) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) % 2 == 0
               and out.stride(0) >= hid and out.device == x.device):
         raise ValueError("core_diffusion_split: out must be a [rows, %d] fp32 view with unit column stride" % hid)
-    bias, b_hn = _gru_bias(rnn, hid)
-    w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous()
-    ln_w = None if norm is None else norm.weight
-    ln_b = None if norm is None else norm.bias
-    eps = 0.0 if norm is None else float(norm.eps)
-    flags = adj.flags | _lib.F_RELU
     with torch.cuda.device(x.device):
-        long_rows = adj.long_rows()
-        n_long = 0 if long_rows is None else long_rows.numel()
-        layer = d == hid                                   # -> ctgcn_gru_layer_presplit_f32; its weights need no plane workspace
-        ws_bytes = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, d, K, 1 if layer else n_out, n_long))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-        with _timed("agg_fwd", n=n, d=d, K=K, nnz=adj.nnz, split=True):
-            check(lib.ctgcn_core_aggregate_split_f32(n, d, K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x), x.stride(0),
-                                                     flags, ptr(long_rows), n_long, adj.LONG_ROW, 1 if layer else n_out, ptr(ws), ws_bytes,
-                                                     _stream()), "ctgcn_core_aggregate_split_f32")
-        if layer:
-            with _timed("gru_layer", rows=n, steps=K, reduce_sum=True, presplit=True):
-                check(lib.ctgcn_gru_layer_presplit_f32(n, K, hid, ptr(ws), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
-                                                       ptr(out), out.stride(0), _stream()), "ctgcn_gru_layer_presplit_f32")
-            return out
+        if d == hid:                                       # -> ctgcn_gru_layer_presplit_f32; its weights need no plane workspace
+            plan = adj.row_plan() if row_plan_enabled() else None
+            ws, _ = aggregate_split_planes(x, adj, 1, plan)
+            return gru_layer_presplit(ws, n, K, rnn, norm, out, plan)
+        bias, b_hn = _gru_bias(rnn, hid)
+        w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous()
+        ln_w = None if norm is None else norm.weight
+        ln_b = None if norm is None else norm.bias
+        eps = 0.0 if norm is None else float(norm.eps)
+        ws, ws_bytes = aggregate_split_planes(x, adj, n_out)
         gi_buf = _gi_buffer(n, K, hid, x.device)
         with _timed("linear_split", rows=n * K, k=d, n_out=n_out, presplit=True):
             check(lib.ctgcn_linear_presplit_f32(n * K, n_out, d, ptr(w_ih), w_ih.stride(0), ptr(bias), ptr(gi_buf), n_out, ptr(ws), ws_bytes,

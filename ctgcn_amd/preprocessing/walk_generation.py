@@ -14,7 +14,9 @@ from ..walks import negative_table, random_walk_corpus
 
 
 class WalkGenerator(object):
-    def __init__(self, base_path, origin_folder, walk_pair_folder, node_freq_folder, node_file, walk_time=100, walk_length=5):
+    def __init__(self, base_path, origin_folder, walk_pair_folder, node_freq_folder, node_file, walk_time=100, walk_length=5, seed=None):
+        """seed=None (the reference's behaviour: numpy's unseeded global RNG, random_walk.py:8-69): every snapshot and every run draws a
+        fresh walk stream from OS entropy.  seed=int: reproducible, snapshot i of a run uses seed + i."""
         self.base_path = base_path
         self.origin_base_path = os.path.abspath(os.path.join(base_path, origin_folder))
         self.walk_pair_base_path = os.path.abspath(os.path.join(base_path, walk_pair_folder))
@@ -24,7 +26,8 @@ class WalkGenerator(object):
         self.node2idx = dict(zip(self.full_node_list, range(len(self.full_node_list))))
         self.walk_time = walk_time
         self.walk_length = walk_length
-        self.seed = 0
+        self.seed = seed
+        self._calls = 0
         check_and_make_path(self.walk_pair_base_path)
         check_and_make_path(self.node_freq_base_path)
 
@@ -34,7 +37,9 @@ class WalkGenerator(object):
         dev = torch.device(device)
         row_ptr, col, val = ops.edges_to_csr(torch.from_numpy(src.astype(np.int32)).to(dev), torch.from_numpy(dst.astype(np.int32)).to(dev),
                                              torch.from_numpy(w.astype(np.float32)).to(dev), n)
-        pairs, freq = random_walk_corpus(row_ptr, col, val, self.walk_length, self.walk_time, weighted=weighted, seed=self.seed)
+        seed = int.from_bytes(os.urandom(8), "little") >> 1 if self.seed is None else int(self.seed) + self._calls
+        self._calls += 1
+        pairs, freq = random_walk_corpus(row_ptr, col, val, self.walk_length, self.walk_time, weighted=weighted, seed=seed)
         stem = f_name.split('.')[0]
         with open(os.path.join(self.node_freq_base_path, stem + '.json'), 'w') as fp:
             json.dump(negative_table(freq).tolist(), fp)

@@ -84,6 +84,18 @@ def shard_ctgcn(model, num_nodes, costs=None, assignment=None, group=None, excha
     return plan
 
 
+def share_loss_seed(loss, group=None, src=0):
+    """Give every rank's NegativeSamplingLoss(seed=None) the same draw stream (see the module docstring: the replicated-loss convention
+    of gather_output=True needs identical samples on every rank): rank `src` draws a base from OS entropy and broadcasts it."""
+    import os
+    group = group if group is not None else dist.group.WORLD
+    base = [int.from_bytes(os.urandom(7), "little")]
+    dist.broadcast_object_list(base, src=src, group=group)
+    loss.shared_base = int(base[0])
+    loss._shared_calls = 0
+    return loss.shared_base
+
+
 def owned_parameters(model):
     """Parameters this rank must optimise: its snapshots' mlp/CDN weights + the replicated temporal head."""
     rank = dist.get_rank(model.process_group)
@@ -202,6 +214,10 @@ def ctgcn_forward_sharded(model, x_list, adj_list):
     while len(rows) < plan.per:                      # uneven T/world: empty slot, never read back
         rows.append(torch.zeros(plan.n_pad, d, dtype=ref.dtype, device=ref.device))
     local = torch.stack(rows)                        # [per, n_pad, d]
+    if needs_grad and not local.requires_grad:
+        # a rank that owns no snapshot (T < world) has nothing upstream of the exchange, but the transposed collective in backward is
+        # collective too: without a graph node here this rank would skip it and the others would wait for ever
+        local.requires_grad_(True)
 
     order = [plan.slot_of[t] for t in range(plan.T)]
     lo, hi = plan.node_range(rank)
@@ -224,6 +240,20 @@ def ctgcn_forward_sharded(model, x_list, adj_list):
     return out, [trans_local.get(t) for t in range(plan.T)]
 
 
+def _slot_moves(plan, device):
+    """per exchange slot s: (time indices of the ranks' s-th snapshots, the ranks that have one (None = the first `count`), count)"""
+    moves = []
+    for s_ in range(plan.per):
+        owners = [w_ for w_ in range(plan.world) if s_ < len(plan.assignment[w_])]
+        if not owners:
+            moves.append(None)
+            continue
+        times = torch.tensor([plan.assignment[w_][s_] for w_ in owners], device=device)
+        leading = owners == list(range(len(owners)))
+        moves.append((times, None if leading else torch.tensor(owners, device=device), len(owners)))
+    return moves
+
+
 def _forward_sharded_pipelined(model, x_list, adj_list):
     """Inference form of the all-to-all exchange, overlapped with compute: slot s of every rank (its s-th snapshot) is
     exchanged by its own asynchronous all-to-all as soon as it is computed, on the collective's stream, while the next
@@ -235,8 +265,18 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
     mine = plan.assignment[rank]
     p0 = next(model.rnn.parameters())
     d = model.output_dim
-    send = torch.zeros(plan.per, plan.n_pad, d, dtype=p0.dtype, device=p0.device)        # pad rows / empty slots stay 0
-    recv = torch.empty(plan.per, plan.world, plan.n_slice, d, dtype=p0.dtype, device=p0.device)
+    lo, hi = plan.node_range(rank)
+    # exchange buffers live on the model: allocating and zeroing (T/G) N d floats three times per forward cost the single-rank RCCL run
+    # 27 of 232 ms (profiles/r02_bench_1gpu_forced_dist.json).  Pad rows and empty slots of `send` are zeroed once and never written.
+    key = (plan.per, plan.n_pad, plan.world, plan.n_slice, plan.T, hi - lo, d, p0.dtype, p0.device)
+    buf = getattr(model, "_exchange_buffers", None)
+    if buf is None or buf[0] != key:
+        buf = model._exchange_buffers = (key,
+                                         torch.zeros(plan.per, plan.n_pad, d, dtype=p0.dtype, device=p0.device),
+                                         torch.empty(plan.per, plan.world, plan.n_slice, d, dtype=p0.dtype, device=p0.device),
+                                         torch.empty(hi - lo, plan.T, d, dtype=p0.dtype, device=p0.device),
+                                         _slot_moves(plan, p0.device))
+    _, send, recv, seq, moves = buf
     works, trans_local = [], {}
     for s_ in range(plan.per):
         if s_ < len(mine):
@@ -246,14 +286,14 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
                 send[s_, : plan.n].copy_(h)
             trans_local[t] = tr
         works.append(dist.all_to_all_single(recv[s_].view(plan.world * plan.n_slice, d), send[s_], group=group, async_op=True))
-    for w in works:
-        w.wait()
-    lo, hi = plan.node_range(rank)
-    # recv[s][w] = snapshot assignment[w][s] on my node slice -> [nodes, T, d] in time order (the temporal GRU's input layout)
-    seq = torch.empty(hi - lo, plan.T, d, dtype=p0.dtype, device=p0.device)
-    for t in range(plan.T):
-        w_, s_ = divmod(plan.slot_of[t], plan.per)
-        seq[:, t] = recv[s_, w_, : hi - lo]
+    # recv[s][w] = snapshot assignment[w][s] on my node slice -> [nodes, T, d] in time order (the temporal GRU's input layout); slot s is
+    # moved as soon as ITS all-to-all has landed (one strided copy per slot: the ranks' s-th snapshots), under the later slots' exchange
+    for s_ in range(plan.per):
+        works[s_].wait()
+        if moves[s_] is not None:
+            times, owners, count = moves[s_]
+            src = recv[s_, :count, : hi - lo] if owners is None else recv[s_, owners, : hi - lo]
+            seq.index_copy_(1, times, src.transpose(0, 1))
     out = model.temporal_head(seq)                                                          # [T, my nodes, d]
     if model.shard_gather_output:
         padded = torch.nn.functional.pad(out, (0, 0, 0, plan.n_slice - (hi - lo))) if hi - lo < plan.n_slice else out

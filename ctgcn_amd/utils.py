@@ -63,7 +63,7 @@ def _node_index(node2idx):
     identity (the cache entry keeps the dict alive, so the id cannot be recycled)."""
     hit = _index_cache.get(id(node2idx))
     if hit is None or hit[0] is not node2idx:
-        if len(_index_cache) > 8:
+        if len(_index_cache) >= 3:        # a run has one node list (DataLoader, StructureInfoGenerator and WalkGenerator each hold a dict of it)
             _index_cache.clear()
         vals = np.fromiter(node2idx.values(), dtype=np.int64, count=len(node2idx))
         if not np.array_equal(vals, np.arange(len(vals))):
@@ -145,8 +145,22 @@ def symmetric_csr_from_rows(src, dst, w, n):
     return m
 
 
+_dict_cache = {}
+
+
+def _node_dict(full_node_list):
+    """name -> index dict of a node list, ONE per list object (callers pass the same list for every snapshot file; a fresh dict per call
+    also missed _node_index's identity cache and rebuilt the Arrow name array per file).  The entry keeps the list alive (its id cannot
+    be recycled) and is dropped when the list changed length."""
+    hit = _dict_cache.get(id(full_node_list))
+    if hit is None or hit[0] is not full_node_list or len(hit[1]) != len(full_node_list):
+        if len(_dict_cache) >= 2:
+            _dict_cache.clear()
+        hit = _dict_cache[id(full_node_list)] = (full_node_list, dict(zip(full_node_list, range(len(full_node_list)))))
+    return hit[1]
+
+
 def get_sp_adj_mat(file_path, full_node_list, sep='\t'):
     """Same result as the reference's get_sp_adj_mat (utils.py:35-58), returned as scipy COO."""
-    node2idx = dict(zip(full_node_list, range(len(full_node_list))))
-    src, dst, w = read_edge_rows(file_path, node2idx, sep)
+    src, dst, w = read_edge_rows(file_path, _node_dict(full_node_list), sep)
     return symmetric_csr_from_rows(src, dst, w, len(full_node_list)).tocoo()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 12
+#define CTGCN_ABI_VERSION 13
 
 enum {
     CTGCN_OK = 0,
@@ -217,10 +217,14 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
  * max / scale / split, this matrix-core-bound kernel only copies the planes into LDS: the whole CoreDiffusion layer of
  * layers.py:41-62 in two kernels, x [rows, steps, 128] never exists in fp32.  Bit-identical to ctgcn_core_aggregate_f32 +
  * ctgcn_gru_layer_f32.  Inference only.
+ *   row_order / tile_mask (both or neither; steps <= 32): the row plan the aggregation call was given (see there).  Sequence p of the
+ *   planes is written to out row row_order[p]; a step whose tile_mask bit is clear re-uses the x·W_ih products of the step before
+ *   (its x row is the same row again: layers.py:41-48 with no entry of that slot or below in any of the tile's 16 rows) and costs the
+ *   h·W_hh half only.  Same products in the same order: results are bit-identical to the call without a plan.
  */
 int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, const void *planes, const float *w_ih, const float *w_hh,
                                  const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                                 float *out, int64_t ld_out, void *stream);
+                                 float *out, int64_t ld_out, const int32_t *row_order, const uint32_t *tile_mask, void *stream);
 
 /*
  * Dense  y[rows, n_out] = x[rows, k]·w[n_out, k]^T + bias  (bias [n_out] may be NULL) in fp32-accurate fp16x2 split arithmetic on the
@@ -246,11 +250,19 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
  *   width of the projection that follows (its weight planes share the workspace); n_long hub rows pass through an fp32
  *   scratch at the end of it.
  * ctgcn_linear_presplit_f32(rows = n_rows*K, n_out, k = d, w, ...) then runs the GEMM on that workspace.
+ *   Row plan (row_order, tile_mask: both or neither; only with the GRU layer kernel as consumer: d = 128, n_out = 1, K <= 32).
+ *   A node whose first stored entry is tagged f has H[v, 0] = ... = H[v, f-1] = relu(x_v) (only the self loop has arrived): rows the
+ *   reference computes, stacks and multiplies by W_ih f times (layers.py:41-48,58-59).  With a plan, operand rows p K .. p K + K - 1
+ *   belong to matrix row row_order[p] (a permutation that puts rows with equal repeat patterns next to each other, so that the 16
+ *   sequences of a GRU tile share one), and slot j of position p is only WRITTEN when bit j of tile_mask[p / 16] is set (bit 0 always
+ *   is; a clear bit j promises that slot j repeats slot j - 1 for all 16 positions of the tile).  long_rows_pos[i] = position of hub
+ *   row long_rows[i] (required when n_long > 0).  The planes' layout does not change - skipped rows are holes nobody reads.
  */
 size_t ctgcn_core_aggregate_split_workspace_bytes(int64_t n_rows, int32_t d, int32_t K, int32_t n_out, int32_t n_long);
 int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr, const int32_t *col_idx,
                                    const float *val, const uint8_t *slot, const float *X, int64_t ldx, uint32_t flags,
                                    const int32_t *long_rows, int32_t n_long, int32_t long_threshold, int32_t n_out,
+                                   const int32_t *row_order, const uint32_t *tile_mask, const int32_t *long_rows_pos,
                                    void *workspace, size_t workspace_bytes, void *stream);
 int ctgcn_linear_presplit_f32(int64_t rows, int32_t n_out, int32_t k, const float *w, int64_t ldw, const float *bias, float *y, int64_t ldy,
                               void *workspace, size_t workspace_bytes, void *stream);

@@ -72,6 +72,8 @@ def run(rank, world, port, T, n, exchange, results):
         model.shard_gather_output = True
         with torch.no_grad():
             full, _ = model(x_list, adj_list)
+            again, _ = model(x_list, adj_list)                 # second inference forward: the cached exchange buffers are reused
+        assert torch.equal(full, again)
         err_full = (full - ref_out).abs().max().item()
         # training on the gathered output (replicated-loss convention: every rank computes the SAME loss on the full
         # [T, N, d]): parameter gradients must equal the reference's, not world x them

@@ -142,3 +142,93 @@ def test_training_keeps_the_separate_path_and_the_switches_work(monkeypatch):
         monkeypatch.delenv("CTGCN_GRU_LAYER")
         monkeypatch.setenv("CTGCN_AGG_SPLIT", "0")
         assert not ops.aggregate_split_ok(l128.rnn, x128, adj) and not ops.aggregate_split_ok(layer.rnn, x.detach(), adj)
+
+
+# ------------------------------------------------------------------ row plan: repeated rows of H are written / multiplied once
+def _sparse_core_adj(n, seed, max_core=6):
+    """mostly low-core nodes (many repeated leading rows), some isolated ones, a few dense ones"""
+    from ctgcn_amd import CoreAdj
+    from ctgcn_amd.utils import symmetric_csr_from_rows
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    m = max(n // 2, 4)
+    src, dst = rng.integers(0, n, m), (rng.integers(0, n, m) + 1 + np.arange(m) % 2) % n
+    dense = rng.choice(n, min(n, max(8, n // 50)), replace=False)
+    src = np.concatenate([src, rng.choice(dense, 12 * len(dense))])
+    dst = np.concatenate([dst, rng.choice(dense, 12 * len(dense))])
+    csr = symmetric_csr_from_rows(src, dst, np.ones(len(src)), n)
+    kept = O.core_adj_list([O.kcore_matrices(csr)], 0, 1, 1, max_core=max_core)[0]
+    return CoreAdj.from_matrices(kept, device=_dev()), kept
+
+
+@pytest.mark.parametrize("n", [5000, 70001, 33, 16, 3])
+def test_row_plan_skips_repeated_rows_and_changes_no_bit(n, monkeypatch):
+    """CTGCN_DEDUP=1 (default) vs 0: same outputs bit for bit; the planes hold exactly the rows the tile masks name (holes untouched),
+    and those rows are the plain path's rows at their planned positions."""
+    from ctgcn_amd import ops
+    adj, _ = _sparse_core_adj(n, seed=n)
+    plan = adj.row_plan()
+    K = adj.K
+    assert plan is not None and plan["new_rows"] <= -(-n // 16) * 16 * K
+    if n >= 5000:
+        assert plan["new_rows"] < 0.8 * n * K, "this graph was built to have repeated rows"
+    order = plan["order"].long()
+    assert torch.equal(torch.sort(order).values, torch.arange(n, device=_dev()))
+    layer = _layer(128, 1)
+    x = torch.randn(n, 128, device=_dev())
+    with torch.no_grad():
+        monkeypatch.setenv("CTGCN_DEDUP", "1")
+        with_plan = layer(x, adj)
+        monkeypatch.setenv("CTGCN_DEDUP", "0")
+        without = layer(x, adj)
+    assert torch.isfinite(with_plan).all() and torch.equal(with_plan, without)
+    # the planes themselves
+    ws_plain, nbytes = ops.aggregate_split_planes(x, adj, 1)
+    ws_plan = torch.full((nbytes,), 0x7b, dtype=torch.uint8, device=_dev())
+    ops.aggregate_split_planes(x, adj, 1, plan, ws=ws_plan)
+    torch.cuda.synchronize()
+    rows = n * K
+    def views(ws):
+        p = ws[: rows * 128 * 4].view(torch.int16).view(2, rows, 128)
+        s = ws[rows * 128 * 4: rows * 128 * 4 + rows * 4].view(torch.int32)
+        return p, s
+    (pa, sa), (pb, sb) = views(ws_plain), views(ws_plan)
+    tm = plan["tile_mask"].long()
+    pos = torch.arange(n, device=_dev())
+    written = ((tm[pos // 16][:, None] >> torch.arange(K, device=_dev())[None, :]) & 1).bool()          # [position, slot]
+    src = (order[:, None] * K + torch.arange(K, device=_dev())[None, :])                                # plain row of (position, slot)
+    dst = (pos[:, None] * K + torch.arange(K, device=_dev())[None, :])
+    assert torch.equal(pb[:, dst[written]], pa[:, src[written]]) and torch.equal(sb[dst[written]], sa[src[written]])
+    hole = ~written
+    assert bool((pb[:, dst[hole]] == 0x7b7b).all()) and bool((sb[dst[hole]] == 0x7b7b7b7b).all()), "a row the plan skips was written"
+    # and a skipped row really is a repeat: the plain planes of slot j equal those of slot j - 1
+    j_hole = torch.nonzero(hole)
+    if j_hole.numel():
+        p_, j_ = j_hole[:, 0], j_hole[:, 1]
+        assert bool((j_ > 0).all())
+        assert torch.equal(pa[:, order[p_] * K + j_], pa[:, order[p_] * K + j_ - 1])
+
+
+def test_row_plan_with_hub_rows_general_lists_and_k1(monkeypatch):
+    from ctgcn_amd import CoreAdj
+    old = CoreAdj.LONG_ROW
+    try:
+        CoreAdj.LONG_ROW = 12
+        adj, _ = _sparse_core_adj(6000, seed=5)
+        assert adj.long_rows() is not None and adj.long_rows().numel() > 10
+        cases = [adj]
+        # not nested: slots without entries repeat the row before them anywhere in the list
+        mats = [sp.random(900, 900, density=0.002 * (1 + j % 2), random_state=j, format="csr", dtype=np.float32) for j in range(5)]
+        cases.append(CoreAdj.from_matrices(mats, device=_dev(), self_loop=False))
+        cases.append(CoreAdj.from_matrices([mats[0]], device=_dev(), self_loop=True))
+        for a in cases:
+            layer = _layer(128, 2)
+            x = torch.randn(a.n, 128, device=_dev())
+            with torch.no_grad():
+                monkeypatch.setenv("CTGCN_DEDUP", "1")
+                got = layer(x, a)
+                monkeypatch.setenv("CTGCN_DEDUP", "0")
+                want = layer(x, a)
+            assert torch.isfinite(got).all() and torch.equal(got, want)
+    finally:
+        CoreAdj.LONG_ROW = old

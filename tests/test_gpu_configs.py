@@ -8,10 +8,17 @@ these sizes (10^8 output values, hub rows that sum hundreds of 500-wide terms, d
 three SELU layers, three stacked recurrences) the fp32 CPU path ITSELF is further than that from the exact result on a small
 fraction of the entries (facebook shape: 3.7e-4 worst).  The oracle is therefore also evaluated in float64 and the HIP path is
 held to the fp32 reference path's OWN distance from that exact result:
-  (a) the fraction of entries outside rtol 1e-4 / atol 1e-5 of the float64 result is at most twice the fp32 CPU path's
+  (a) the fraction of entries outside rtol 1e-4 / atol 1e-5 of the float64 result is at most FRAC_SLACK x the fp32 CPU path's
       fraction (+ 1e-6), and against the fp32 oracle itself the HIP output is nowhere further than 5e-4;
-  (b) the worst HIP error against float64 is at most twice the fp32 CPU path's worst error (+ 2e-6).
-Observed errors are printed per case."""
+  (b) the worst HIP error against float64 is at most WORST_SLACK x the fp32 CPU path's worst error (+ 2e-6).
+Observed errors are printed per case and written to gpurun_out/parity_errors/<case>.json (committed copy of a full run:
+profiles/r03_parity_errors.json).
+
+Config 5 (1 M nodes) is held to the same rule at FULL size (test_config5_full_size_matches_cpu_oracle): snapshots 3 and 15 of the
+16-snapshot window, max_core 8, through the inference path (aggregation -> fp16 planes -> register-resident GRU layer kernel), the
+autograd forward (fp32 rows) and the hub-row kernels (LONG_ROW forced low)."""
+import json
+import os
 import time
 
 import numpy as np
@@ -20,6 +27,38 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+FRAC_SLACK = 1.25       # observed <= 1.16 (profiles/r03_parity_errors.json)
+WORST_SLACK = 1.5       # observed <= 1.28: the single worst of 2e8 entries (an extreme-value statistic; round 2 allowed 2.0)
+
+
+def _record(case, **numbers):
+    """observed errors -> gpurun_out/parity_errors/<case>.json (scratch; a full run is committed as profiles/r03_parity_errors.json)"""
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_errors")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, case + ".json"), "w") as f:
+            json.dump({k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in numbers.items()}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _compare(case, got, want, want64, extra=None):
+    """the rule of the module docstring on full output arrays; returns the observed numbers"""
+    err = np.abs(got - want)
+    tol64 = 1e-4 * np.abs(want64) + 1e-5
+    d_hip, d_cpu = np.abs(got - want64), np.abs(want - want64)
+    bad_hip, bad_cpu = float((d_hip > tol64).mean()), float((d_cpu > tol64).mean())
+    err_hip64, err_cpu64 = float(d_hip.max()), float(d_cpu.max())
+    obs = dict(max_err_vs_fp32_oracle=float(err.max()), mean_err_vs_fp32_oracle=float(err.mean()), max_err_hip_vs_fp64=err_hip64,
+               max_err_cpu_fp32_vs_fp64=err_cpu64, frac_outside_hip=bad_hip, frac_outside_cpu_fp32=bad_cpu,
+               rule="rtol 1e-4 atol 1e-5 vs fp64; slack %.2f / %.2f" % (FRAC_SLACK, WORST_SLACK), shape=list(got.shape))
+    obs.update(extra or {})
+    print("%s: vs fp32 oracle max |err| %.3e mean %.3e; vs fp64 oracle: max HIP %.3e / fp32 CPU path %.3e, fraction outside rtol 1e-4 atol 1e-5 "
+          "HIP %.2e / fp32 CPU path %.2e" % (case, err.max(), err.mean(), err_hip64, err_cpu64, bad_hip, bad_cpu))
+    _record(case, **obs)
+    assert bad_hip <= FRAC_SLACK * bad_cpu + 1e-6 and err.max() <= 5e-4, obs
+    assert err_hip64 <= WORST_SLACK * err_cpu64 + 2e-6, obs
+    return obs
 
 CASES = {
     # name: nodes, edges, T, cumulative, max_core, hid, model, trans, diff, act, features
@@ -97,12 +136,84 @@ def test_baseline_config_shapes_match_cpu_oracle(case):
     got = got.cpu().numpy()
     want, want64 = want.numpy(), want64.numpy()
     assert got.shape == want.shape == (c["T"], c["n"], 128)
-    err = np.abs(got - want)
-    tol64 = 1e-4 * np.abs(want64) + 1e-5
-    bad_hip, bad_cpu = (np.abs(got - want64) > tol64).mean(), (np.abs(want - want64) > tol64).mean()
-    err_hip64, err_cpu64 = np.abs(got - want64).max(), np.abs(want - want64).max()
-    print("%s: vs fp32 oracle max |err| %.3e mean %.3e; vs fp64 oracle: max HIP %.3e / fp32 CPU path %.3e, fraction outside rtol 1e-4 atol 1e-5 "
-          "HIP %.2e / fp32 CPU path %.2e (oracle fp32 %.0fs, fp64 %.0fs)" % (case, err.max(), err.mean(), err_hip64, err_cpu64, bad_hip, bad_cpu,
-                                                                        t1 - t0, time.time() - t1))
-    assert bad_hip <= 2 * bad_cpu + 1e-6 and err.max() <= 5e-4
-    assert err_hip64 <= 2 * err_cpu64 + 2e-6
+    _compare(case, got, want, want64, dict(oracle_fp32_s=t1 - t0, oracle_fp64_s=time.time() - t1))
+
+
+# ------------------------------------------------------------------------------------------ config 5 at full size
+C5 = dict(n=1_000_000, edges=8_000_000, T=16, max_core=8, pick=(3, 15))
+
+
+@pytest.fixture(scope="module")
+def config5():
+    """Snapshots 3 and 15 of bench.py's synthetic-1m window (same generator, same seed), the device-route CoreAdj of each, the
+    reference-shaped COO lists, a seeded CTGCN-C(1 M one-hot, 128, 128, 1, 2, T = 2) and the CPU oracle's fp32 / fp64 outputs."""
+    import ctgcn_amd
+    from ctgcn_amd.helper import core_adj_from_scipy
+    from ctgcn_amd.synth import snapshot_rows
+    from oracle import oracle as O, torch_path as TP
+    import scipy.sparse as sp
+    n, K = C5["n"], C5["max_core"]
+    u, v, picks = snapshot_rows(n, C5["edges"], C5["T"], cumulative=True)
+    graphs = []
+    for t in C5["pick"]:
+        uu, vv = u[picks[t]], v[picks[t]]
+        a = sp.coo_matrix((np.ones(2 * len(uu)), (np.concatenate([uu, vv]), np.concatenate([vv, uu]))), shape=(n, n)).tocsr()
+        a.sort_indices()
+        graphs.append(a)
+    adj, ref_adj = [], []
+    for g in graphs:
+        core = O.core_numbers(g)
+        a, core_dev, _ = core_adj_from_scipy(g, K, DEV)
+        capped = np.minimum(core, K)
+        assert np.array_equal(core_dev.cpu().numpy(), capped)                   # integer k-core assignment: bit-exact at 1 M nodes
+        ref = O.core_adj_list([O.kcore_matrices(g, capped)], 0, 1, 1, max_core=K)[0]      # levels above max_core are never told apart (helper.py:63)
+        assert a.nnz_per_slot == [m.nnz for m in ref] and len(a) == len(ref)
+        adj.append(a)
+        ref_adj.append([TP.coo_like_reference(m) for m in ref])
+    idx = torch.arange(n).repeat(2, 1)
+    xs = [torch.sparse_coo_tensor(idx, torch.ones(n), (n, n)) for _ in graphs]
+    torch.manual_seed(0)
+    model = ctgcn_amd.CTGCN(n, 128, 128, 1, 2, len(graphs)).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    t0 = time.time()
+    with torch.no_grad():
+        want = TP.ctgcn(sd, xs, ref_adj)
+        t1 = time.time()
+        want64 = TP.ctgcn({k: v.double() for k, v in sd.items()}, [x.double() for x in xs], [[a.double() for a in l] for l in ref_adj])
+    return dict(model=model, adj=adj, xs=[x.to(DEV) for x in xs], want=want.numpy(), want64=want64.numpy(),
+                times=dict(oracle_fp32_s=t1 - t0, oracle_fp64_s=time.time() - t1), K=[len(a) for a in adj], nnz=[a.nnz for a in adj])
+
+
+@pytest.mark.parametrize("path", ["inference", "autograd_forward", "hub_rows"])
+def test_config5_full_size_matches_cpu_oracle(config5, path):
+    """the fused inference path had never met the oracle above 87 036 rows (and a layer-kernel bug once was
+    invisible at 70 001 rows, non-finite at 1 M).  Reference chain: models.py:240-253 -> layers.py:38-63."""
+    from ctgcn_amd.core_adj import CoreAdj
+    c = config5
+    model, old = c["model"], CoreAdj.LONG_ROW
+    extra = dict(c["times"], K=c["K"], nnz=c["nnz"], path=path)
+    try:
+        if path == "hub_rows":
+            CoreAdj.LONG_ROW = 96          # ~1 % of the rows of snapshot 15 go through the block-per-row kernels (+ the mapped split)
+            for a in c["adj"]:
+                a._long.clear()
+            extra["hub_rows"] = [0 if a.long_rows() is None else int(a.long_rows().numel()) for a in c["adj"]]
+            assert min(extra["hub_rows"]) > 1000
+        if path == "autograd_forward":
+            model.train()
+            got = model(c["xs"], c["adj"])
+            assert got.requires_grad
+            got = got.detach()
+        else:
+            model.eval()
+            with torch.no_grad():
+                got = model(c["xs"], c["adj"])
+    finally:
+        CoreAdj.LONG_ROW = old
+        for a in c["adj"]:
+            a._long.clear()
+        model.eval()
+    got = got.cpu().numpy()
+    assert got.shape == c["want"].shape == (2, C5["n"], 128) and np.isfinite(got).all()
+    _compare("config5_full_" + path, got, c["want"], c["want64"], extra)

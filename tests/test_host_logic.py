@@ -433,3 +433,40 @@ def test_device_builder_for_nested_npz_lists_equals_the_host_builder():
     a = sp.random(50, 50, 0.1, format="csr", random_state=1)
     b = sp.random(50, 50, 0.1, format="csr", random_state=2)
     assert CoreAdj.from_nested_matrices_device([a + a.T, b + b.T], "cpu") is None
+
+
+def test_row_plan_names_exactly_rows_that_repeat_in_the_oracle():
+    """CoreAdj.row_plan (inference path): a clear bit j of a tile's mask promises that H[v, j] == H[v, j-1] for the 16 rows of
+    the tile — checked against the C oracle's H = relu(cumulative A_k x) (layers.py:41-48) for a k-core list and for a general list;
+    `order` is a permutation that keeps equal patterns together."""
+    import scipy.sparse as sp
+    from ctgcn_amd import CoreAdj
+    from ctgcn_amd.utils import symmetric_csr_from_rows
+    from oracle import oracle as O
+    rng = np.random.default_rng(4)
+    n = 1000
+    src, dst = rng.integers(0, n, 450), rng.integers(0, n, 450)
+    hub = rng.choice(n, 30, replace=False)
+    src, dst = np.concatenate([src, rng.choice(hub, 400)]), np.concatenate([dst, rng.choice(hub, 400)])
+    csr = symmetric_csr_from_rows(src, dst, np.ones(len(src)), n)
+    nested = O.core_adj_list([O.kcore_matrices(csr)], 0, 1, 1, max_core=5)[0]
+    general = [sp.random(n, n, density=0.001 * (1 + j % 2), random_state=j, format="csr", dtype=np.float32) for j in range(4)]
+    x = rng.standard_normal((n, 8)).astype(np.float32)
+    for mats, kw in ((nested, {}), (general, dict(self_loop=False))):
+        adj = CoreAdj.from_matrices(mats, **kw)
+        plan = adj.row_plan()
+        K = adj.K
+        order, tmask = plan["order"].numpy().astype(np.int64), plan["tile_mask"].numpy().astype(np.int64)
+        assert np.array_equal(np.sort(order), np.arange(n)) and np.array_equal(plan["inverse"].numpy()[order], np.arange(n))
+        assert len(tmask) == -(-n // 16) and np.all(tmask & 1)
+        H = O.core_aggregate(mats, x)                       # [n, K, d], ReLU applied
+        repeats = np.zeros((n, K), dtype=bool)
+        repeats[:, 1:] = (H[:, 1:] == H[:, :-1]).all(axis=2)
+        bits = (tmask[np.arange(n) // 16][:, None] >> np.arange(K)[None, :]) & 1          # [position, slot]
+        assert repeats[order][bits == 0].all(), "the plan skips a row that is not a repeat"
+        # patterns are grouped: the masks are not looser than the rows' own patterns except at group boundaries (< 2^K tiles)
+        own = ~repeats[order]
+        loose = ((bits == 1) & ~own).any(axis=1).reshape(-1)
+        assert loose.sum() <= 16 * (1 << K), loose.sum()
+        assert plan["new_rows"] == 16 * sum(bin(int(m) & ((1 << K) - 1)).count("1") for m in tmask)
+    assert CoreAdj.from_matrices([general[0]] * 1, self_loop=True).row_plan()["new_rows"] == -(-n // 16) * 16

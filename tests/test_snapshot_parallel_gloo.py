@@ -1,5 +1,6 @@
-"""N>1 path on CPU: world_size 2, gloo.  Covers plan_assignment, both exchange modes, uneven T/world,
-autograd through the collectives and the replicated-head grad all-reduce."""
+"""N>1 path on CPU: world_size 2 and 4, gloo.  Covers plan_assignment, both exchange modes, uneven T/world (incl. a rank that owns
+nothing), the pipelined inference exchange with its cached buffers, autograd through the collectives and the replicated-head grad
+all-reduce."""
 import socket
 
 import pytest
@@ -28,14 +29,19 @@ def test_plan_assignment_balances_cumulative_snapshots():
     assert (p.per, p.n_slice, p.n_pad) == (2, 5, 10) and p.owner(3) == 0 and p.node_range(1) == (5, 10)
 
 
-@pytest.mark.parametrize("exchange,T,n", [("all_to_all", 5, 301), ("all_gather", 4, 300)])
-def test_sharded_ctgcn_matches_unsharded(exchange, T, n):
+@pytest.mark.parametrize("exchange,T,n,world", [("all_to_all", 5, 301, 2), ("all_gather", 4, 300, 2),
+                                                 ("all_to_all", 5, 203, 4),      # uneven: one rank owns two snapshots, three own one
+                                                 ("all_to_all", 3, 150, 4),      # a rank that owns nothing still takes part in the exchange
+                                                 ("all_gather", 6, 150, 4)])
+def test_sharded_ctgcn_matches_unsharded(exchange, T, n, world):
     from _dist_worker import run
     mgr = mp.Manager()
     results = mgr.dict()
-    mp.spawn(run, args=(2, _free_port(), T, n, exchange, results), nprocs=2, join=True)
-    assert len(results) == 2
-    for rank in range(2):
+    mp.spawn(run, args=(world, _free_port(), T, n, exchange, results), nprocs=world, join=True)
+    assert len(results) == world
+    if T < world:
+        assert [] in results[0][3]
+    for rank in range(world):
         err_fwd, err_bwd, err_full, assignment = results[rank]
         assert err_fwd < 1e-5 and err_full < 1e-5, (rank, err_fwd, err_full)
         assert err_bwd < 1e-4, (rank, err_bwd)

@@ -18,17 +18,8 @@ def alg_bytes(n, nnz, K, d):
 
 
 def split_aggregate(x, adj):
-    from ctgcn_amd import _lib
-    lib = _lib.load()
-    n, d = x.shape
-    lr = adj.long_rows()
-    nl = 0 if lr is None else lr.numel()
-    wsb = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, d, adj.K, 1, nl))
-    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    _lib.check(lib.ctgcn_core_aggregate_split_f32(n, d, adj.K, _lib.ptr(adj.row_ptr), _lib.ptr(adj.col), _lib.ptr(adj.val), _lib.ptr(adj.slot),
-                                                  _lib.ptr(x), x.stride(0), adj.flags | _lib.F_RELU, _lib.ptr(lr), nl, adj.LONG_ROW, 1, _lib.ptr(ws),
-                                                  wsb, torch.cuda.current_stream().cuda_stream), "ctgcn_core_aggregate_split_f32")
-    return ws
+    from ctgcn_amd import ops
+    return ops.aggregate_split_planes(x, adj, 1)[0]
 
 
 def main():

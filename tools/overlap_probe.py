@@ -41,22 +41,10 @@ def main():
     out = torch.empty(n, 128, device=dev)
 
     def agg():
-        lr = adj.long_rows()
-        nl = 0 if lr is None else lr.numel()
-        wsb = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, 128, adj.K, 1, nl))
-        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-        _lib.check(lib.ctgcn_core_aggregate_split_f32(n, 128, adj.K, _lib.ptr(adj.row_ptr), _lib.ptr(adj.col), _lib.ptr(adj.val), _lib.ptr(adj.slot),
-                                                      _lib.ptr(x), 128, adj.flags | _lib.F_RELU, _lib.ptr(lr), nl, adj.LONG_ROW, 1, _lib.ptr(ws), wsb,
-                                                      torch.cuda.current_stream().cuda_stream), "agg")
-        return ws
-
-    bias, b_hn = ops._gru_bias(rnn, 128)
-    w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous()
+        return ops.aggregate_split_planes(x, adj, 1)[0]
 
     def layer(ws):
-        _lib.check(lib.ctgcn_gru_layer_presplit_f32(n, adj.K, 128, _lib.ptr(ws), _lib.ptr(w_ih), _lib.ptr(w_hh), _lib.ptr(bias), _lib.ptr(b_hn),
-                                                    _lib.ptr(norm.weight), _lib.ptr(norm.bias), 1e-5, _lib.ptr(out), 128,
-                                                    torch.cuda.current_stream().cuda_stream), "layer")
+        ops.gru_layer_presplit(ws, n, adj.K, rnn, norm, out)
 
     def timeit(fn, iters):
         fn()

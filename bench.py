@@ -493,6 +493,10 @@ def main():
                           "peel_ms_capped_at_max_core_%d" % max_core: round(res["capped"][0], 3),
                           "snapshot": kc_t, "stored_entries": int(col.numel()),
                           "note": "includes the host read-back of the level counter every 16 levels; latency-bound (peel depth), not bandwidth-bound"}
+    # ------------------------------------------------------------------------- training step (fwd AND fwd+bwd)
+    train = None
+    if not args.no_extras and not args.train and not args.graph and not use_dist and os.environ.get("CTGCN_BENCH_TRAIN_LEG", "1") != "0":
+        train = training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log)
     if use_dist:
         dist.barrier()
     if rank != 0:
@@ -549,6 +553,7 @@ def main():
         "roofline_gru": roof_mfma,
         "roofline_kcore": roof_kcore,
         "exact_fp32": exact,
+        "training_step": train,
         "cpu_baseline": cpu,
         "cpu_baseline_kcore": cpu_k,
     }
@@ -558,6 +563,63 @@ def main():
     os.dup2(2, 1)               # whatever RCCL prints while shutting down must not follow the JSON line on stdout
     if use_dist:
         dist.destroy_process_group()
+
+
+def training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log):
+    """fwd + bwd + Adam on the same window (the reference's training step, embedding.py:346-352, with the surrogate loss
+    out.square().mean(): the negative-sampling loss is outside the hot path): 1 warm-up + 2 timed steps after the forward measurement,
+    plus the aggregation-backward kernels' HIP-event times and their roofline (DESIGN §4.2 bytes)."""
+    import torch
+    recs = []
+    ops.set_launch_timer(lambda name, s, e, meta: recs.append((name, s, e, meta)))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    try:
+        def one():
+            opt.zero_grad(set_to_none=True)
+            out = first(model(x_list, adj_list))
+            out.square().mean().backward()
+            opt.step()
+        one()
+        torch.cuda.synchronize()
+        recs.clear()
+        steps = 2
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        ms = 1000.0 * (time.perf_counter() - t0) / steps
+        by = {}
+        for name, s_, e_, meta in recs:
+            by.setdefault(name, []).append((s_.elapsed_time(e_), meta))
+        res = {"ms_per_step": round(ms, 2), "steps": steps, "what": "forward + backward + Adam, surrogate loss out.square().mean(), same window and weights",
+               "aggregated_edges_per_s_fwd_plus_bwd": 2.0 * agg_edges_step / (ms * 1e-3),
+               "kernel_ms_per_step": {k: round(sum(t for t, _ in v) / steps, 3) for k, v in sorted(by.items())}}
+        if "agg_bwd" in by:
+            g = by["agg_bwd"]
+            t_ms = sum(t for t, _ in g) / len(g)
+            b = sum(m["nnz"] * (4 * m["d"] + 9) + m["n"] * 8 * m["d"] + 4 * (m["n"] + 1) for _, m in g) / len(g)
+            res["roofline_agg_bwd"] = {"kernel": "agg_bwd_kernel (gather of Z[col, slot] rows: dX = S0 + sum_e val_e Z[col_e, slot_e])", "bound": "hbm",
+                                       "achieved": round(b / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(t_ms, 4),
+                                       "algorithmic_bytes_per_launch": int(b), "launches_timed": len(g)}
+        if "agg_bwd_prep" in by:
+            g = by["agg_bwd_prep"]
+            t_ms = sum(t for t, _ in g) / len(g)
+            b = sum(3.0 * m["n"] * m["K"] * 4 * m["d"] + (m["n"] * 4 * m["d"] if m.get("self_loop") else 0) for _, m in g) / len(g)
+            res["roofline_agg_bwd_prep"] = {"kernel": "agg_bwd_prep_kernel (elementwise: dH, H in; Z, S0 out)", "bound": "hbm",
+                                            "achieved": round(b / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(t_ms, 4),
+                                            "launches_timed": len(g)}
+        log("training step: %.1f ms" % ms)
+        return res
+    finally:
+        ops.set_launch_timer(None)
+        model.eval()
+        del opt
+        for p in model.parameters():
+            p.grad = None
+        torch.cuda.empty_cache()
 
 
 def cpu_baseline(adj_list, widths, budget_s, log):

@@ -91,6 +91,22 @@ class CoreAdj(object):
     def cpu(self):
         return self.to("cpu")
 
+    HUB_SPLIT_ENTRIES = 8192   # entries per block when a hub row is cut into pieces (HUB_SPLIT_ENTRIES of ctgcn_hip.hip)
+    HUB_SPLIT_MAX = 32
+
+    def hub_split(self, transposed=False):
+        """Blocks per hub row the aggregation kernels may use (1: no row is long enough to be cut into pieces)."""
+        key = ("split", bool(transposed) and not self.symmetric)
+        if key not in self._long:
+            lr = self.long_rows(transposed)
+            if lr is None:
+                self._long[key] = 1
+            else:
+                rp = self.transposed()[0] if key[1] else self.row_ptr
+                longest = int((rp[1:] - rp[:-1]).max().item())
+                self._long[key] = max(1, min(self.HUB_SPLIT_MAX, -(-longest // self.HUB_SPLIT_ENTRIES)))
+        return self._long[key]
+
     def long_rows(self, transposed=False):
         """int32 device tensor of the rows with more than LONG_ROW entries (None if there are none)."""
         key = bool(transposed) and not self.symmetric

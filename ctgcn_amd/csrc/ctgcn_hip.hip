@@ -88,6 +88,12 @@ struct AggArgs {
     int32_t long_thresh;
     int32_t hub_groups;    // lane groups of the hub block that share one long row
     int32_t hub_compact;   // fwd hub kernel: write hub row i of long_rows to out row i (a compact scratch) instead of its own row
+    // very long hub rows: hub_split > 1 blocks per hub row (grid = n_long * hub_split; a row of L entries uses ceil(L / HUB_SPLIT_ENTRIES) of
+    // them, at most hub_split), each leaving the per-slot partial sums of its piece in hub_part [n_long][hub_split][K (fwd) | 1 (bwd)][hub_ld];
+    // agg_*_hub_final_kernel adds the pieces in piece order (deterministic) and finishes the row.  hub_part null: one block per row.
+    int32_t hub_split;
+    int32_t hub_ld;        // floats per partial vector (the feature width rounded up to whole passes)
+    float *hub_part;
     // agg_fwd_split*_kernel with the GRU layer kernel as consumer (d = 128): rows are processed in `order` (position p takes matrix row
     // order[p], its K output rows are rows p K .. p K + K - 1 of the planes) and slot j of position p is only written when bit j of
     // tmask[p / 16] is set — a row whose first entry is tagged f has H[row, 0] = ... = H[row, f - 1] (nothing but the self loop has arrived),
@@ -243,6 +249,12 @@ __global__ __launch_bounds__(256) void agg_bwd_kernel(const AggArgs a)
 // into LDS, group 0 then adds the partials in group order (deterministic) and runs the same R/P recurrence.
 // ------------------------------------------------------------------------------------------------
 constexpr int HUB_THREADS = 1024;
+constexpr int HUB_SPLIT_ENTRIES = 8192;                  // entries per block when a hub row is cut into pieces
+__host__ __device__ __forceinline__ int hub_pieces(int len, int max_pieces)
+{
+    const int np = (len + HUB_SPLIT_ENTRIES - 1) / HUB_SPLIT_ENTRIES;
+    return np < 1 ? 1 : (np > max_pieces ? max_pieces : np);
+}
 
 template <int VEC, int LPR, int U>
 __global__ __launch_bounds__(HUB_THREADS) void agg_fwd_hub_kernel(const AggArgs a)
@@ -251,15 +263,24 @@ __global__ __launch_bounds__(HUB_THREADS) void agg_fwd_hub_kernel(const AggArgs 
     extern __shared__ __align__(16) unsigned char hub_smem[];
     V *part = reinterpret_cast<V *>(hub_smem);            // [G][K][LPR]
     const int lig = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR, G = a.hub_groups;
-    const int64_t row = a.long_rows[blockIdx.x];
-    const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    const bool pieces = a.hub_part != nullptr;            // several blocks per row: this one leaves the partial sums of its piece
+    const int hub = pieces ? (int)(blockIdx.x / a.hub_split) : (int)blockIdx.x, piece = pieces ? (int)(blockIdx.x % a.hub_split) : 0;
+    const int64_t row = a.long_rows[hub];
+    int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    if (pieces) {
+        const int np = hub_pieces(end - start, a.hub_split);
+        if (piece >= np) return;
+        const int plen = ((end - start + np - 1) / np + LPR - 1) / LPR * LPR;
+        start = min(end, start + piece * plen);
+        end = min(end, start + plen);
+    }
     const int seg = ((end - start + G - 1) / G + LPR - 1) / LPR * LPR;
     const int my_s = min(end, start + grp * seg), my_e = min(end, my_s + seg);
     const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0, relu = (a.flags & CTGCN_F_RELU) != 0;
     const bool nested = (a.flags & CTGCN_F_NESTED) != 0;
     const uint8_t *__restrict__ slot = a.slot;
     const float *__restrict__ X = a.src;
-    float *__restrict__ outrow = a.out + (a.hub_compact ? (int64_t)blockIdx.x : row) * a.out_ld;
+    float *__restrict__ outrow = a.out + (a.hub_compact ? (int64_t)hub : row) * a.out_ld;
 
     for (int pass = 0; pass < a.passes; ++pass) {
         const int ch = pass * LPR + lig;
@@ -313,6 +334,17 @@ __global__ __launch_bounds__(HUB_THREADS) void agg_fwd_hub_kernel(const AggArgs 
             if (cur >= 0) part[((int64_t)grp * a.K + cur) * LPR + lig] = P;
         }
         __syncthreads();
+        if (pieces) {
+            if (grp == 0 && live) {
+                for (int k = 0; k < a.K; ++k) {
+                    V sk = vzero<VEC>();
+                    for (int g = 0; g < G; ++g) sk += part[((int64_t)g * a.K + k) * LPR + lig];
+                    *(V *)(a.hub_part + (((int64_t)hub * a.hub_split + piece) * a.K + k) * a.hub_ld + foff) = sk;
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         if (grp == 0) {
             V R = vzero<VEC>(), Pc = vzero<VEC>();
             if (self) R = *(const V *)(X + row * a.ldsrc + foff);
@@ -340,8 +372,17 @@ __global__ __launch_bounds__(HUB_THREADS) void agg_bwd_hub_kernel(const AggArgs 
     extern __shared__ __align__(16) unsigned char hub_smem[];
     V *part = reinterpret_cast<V *>(hub_smem);            // [G][LPR]
     const int lig = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR, G = a.hub_groups;
-    const int64_t row = a.long_rows[blockIdx.x];
-    const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    const bool pieces = a.hub_part != nullptr;
+    const int hub = pieces ? (int)(blockIdx.x / a.hub_split) : (int)blockIdx.x, piece = pieces ? (int)(blockIdx.x % a.hub_split) : 0;
+    const int64_t row = a.long_rows[hub];
+    int start = a.row_ptr[row], end = a.row_ptr[row + 1];
+    if (pieces) {
+        const int np = hub_pieces(end - start, a.hub_split);
+        if (piece >= np) return;
+        const int plen = ((end - start + np - 1) / np + LPR - 1) / LPR * LPR;
+        start = min(end, start + piece * plen);
+        end = min(end, start + plen);
+    }
     const int seg = ((end - start + G - 1) / G + LPR - 1) / LPR * LPR;
     const int my_s = min(end, start + grp * seg), my_e = min(end, my_s + seg);
     const uint8_t *__restrict__ slot = a.slot;
@@ -385,6 +426,15 @@ __global__ __launch_bounds__(HUB_THREADS) void agg_bwd_hub_kernel(const AggArgs 
             part[(int64_t)grp * LPR + lig] = P;
         }
         __syncthreads();
+        if (pieces) {
+            if (grp == 0 && live) {
+                V P = vzero<VEC>();
+                for (int g = 0; g < G; ++g) P += part[(int64_t)g * LPR + lig];
+                *(V *)(a.hub_part + ((int64_t)hub * a.hub_split + piece) * a.hub_ld + foff) = P;
+            }
+            __syncthreads();
+            continue;
+        }
         if (grp == 0) {
             V P = vzero<VEC>();
             if (a.self) P = *(const V *)(a.self + row * (int64_t)a.d + foff);
@@ -396,6 +446,45 @@ __global__ __launch_bounds__(HUB_THREADS) void agg_bwd_hub_kernel(const AggArgs 
             }
         }
         __syncthreads();
+    }
+}
+
+// Second pass for hub rows cut into pieces: one small block per hub row adds the pieces' partial sums in piece order and runs the
+// row's R/P recurrence (forward) / adds the self term (backward).  Deterministic: fixed piece boundaries, fixed order.
+template <int VEC, bool FWD>
+__global__ __launch_bounds__(256) void agg_hub_final_kernel(const AggArgs a)
+{
+    using V = typename vec_of<VEC>::type;
+    const int hub = blockIdx.x;
+    const int64_t row = a.long_rows[hub];
+    const int np = hub_pieces(a.row_ptr[row + 1] - a.row_ptr[row], a.hub_split);
+    const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0, relu = (a.flags & CTGCN_F_RELU) != 0, nested = (a.flags & CTGCN_F_NESTED) != 0;
+    const int KK = FWD ? a.K : 1;
+    const float *__restrict__ mine = a.hub_part + (int64_t)hub * a.hub_split * KK * a.hub_ld;
+    for (int ch = threadIdx.x; ch < a.chunks; ch += 256) {
+        const int64_t foff = (int64_t)ch * VEC;
+        if (FWD) {
+            float *__restrict__ outrow = a.out + (a.hub_compact ? (int64_t)hub : row) * a.out_ld;
+            V R = vzero<VEC>(), Pc = vzero<VEC>();
+            if (self) R = *(const V *)(a.src + row * a.ldsrc + foff);
+            for (int k = 0; k < a.K; ++k) {
+                V sk = vzero<VEC>();
+                for (int p = 0; p < np; ++p) sk += *(const V *)(mine + ((int64_t)p * a.K + k) * a.hub_ld + foff);
+                Pc = nested ? Pc + sk : sk;
+                R += Pc;
+                V v = relu ? vmax0(R) : R;
+                V *o = (V *)(outrow + (int64_t)k * a.d + foff);
+                if (a.accumulate) v += *o;
+                *o = v;
+            }
+        } else {
+            V P = vzero<VEC>();
+            if (a.self) P = *(const V *)(a.self + row * (int64_t)a.d + foff);
+            for (int p = 0; p < np; ++p) P += *(const V *)(mine + (int64_t)p * a.hub_ld + foff);
+            V *o = (V *)(a.out + row * a.out_ld + foff);
+            if (a.accumulate) P += *o;
+            *o = P;
+        }
     }
 }
 
@@ -472,15 +561,34 @@ void launch_agg_t(AggArgs a, hipStream_t st)
         while (G > 1 && per_group * G > HUB_LDS_BUDGET) --G;
         a.hub_groups = G;
         const size_t lds = per_group * G;
+        const unsigned hub_grid = (unsigned)a.n_long * (unsigned)(a.hub_part ? a.hub_split : 1);
         if (FWD) {
             auto k = agg_fwd_hub_kernel<VEC, LPR, U>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3((unsigned)a.n_long), dim3(HUB_THREADS), lds, st, a);
+            hipLaunchKernelGGL(k, dim3(hub_grid), dim3(HUB_THREADS), lds, st, a);
         } else {
             auto k = agg_bwd_hub_kernel<VEC, LPR, U>;
-            hipLaunchKernelGGL(k, dim3((unsigned)a.n_long), dim3(HUB_THREADS), lds, st, a);
+            hipLaunchKernelGGL(k, dim3(hub_grid), dim3(HUB_THREADS), lds, st, a);
         }
+        if (a.hub_part) hipLaunchKernelGGL((agg_hub_final_kernel<VEC, FWD>), dim3((unsigned)a.n_long), dim3(256), 0, st, a);
     }
+}
+
+// hub rows in pieces (AggArgs::hub_split / hub_part): validated against the caller's workspace; slots = K (forward) or 1 (backward)
+size_t hub_workspace_bytes_(int64_t n_long, int32_t hub_split, int32_t slots, int32_t d)
+{
+    if (n_long <= 0 || hub_split <= 1) return 0;
+    return (size_t)n_long * hub_split * slots * ((d + 3) / 4 * 4) * sizeof(float);
+}
+int set_hub_pieces(AggArgs &a, int32_t slots, int32_t hub_split, void *ws, size_t ws_bytes, const char *who)
+{
+    a.hub_split = 1; a.hub_part = nullptr; a.hub_ld = (a.d + 3) / 4 * 4;
+    if (a.n_long <= 0 || hub_split <= 1 || !ws) return CTGCN_OK;
+    if (hub_split > 64) return fail(CTGCN_E_INVALID, "%s: hub_split=%d outside [1,64]", who, hub_split);
+    if ((reinterpret_cast<uintptr_t>(ws) & 15u) || ws_bytes < hub_workspace_bytes_(a.n_long, hub_split, slots, a.d))
+        return fail(CTGCN_E_WORKSPACE, "%s: hub workspace must be 16-byte aligned and hold ctgcn_hub_workspace_bytes() bytes", who);
+    a.hub_split = hub_split; a.hub_part = (float *)ws;
+    return CTGCN_OK;
 }
 
 template <bool FWD>
@@ -3136,7 +3244,8 @@ int ctgcn_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *row_ptr, const 
 int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
                              const int32_t *col_idx, const float *val, const uint8_t *slot,
                              const float *X, int64_t ldx, float *H, uint32_t flags,
-                             const int32_t *long_rows, int32_t n_long, int32_t long_threshold, void *stream)
+                             const int32_t *long_rows, int32_t n_long, int32_t long_threshold,
+                             int32_t hub_split, void *hub_workspace, size_t hub_workspace_bytes, void *stream)
 {
     if (n_rows < 0 || d <= 0 || ldx < d) return fail(CTGCN_E_INVALID, "core_aggregate: bad sizes n=%lld d=%d ldx=%lld", (long long)n_rows, d, (long long)ldx);
     if (K < 1 || K > CTGCN_MAX_SLOTS) return fail(CTGCN_E_INVALID, "core_aggregate: K=%d outside [1,%d]", K, CTGCN_MAX_SLOTS);
@@ -3150,6 +3259,7 @@ int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t
     a.flags = flags; a.accumulate = 0;
     a.long_rows = long_rows; a.n_long = n_long; a.long_thresh = long_threshold;
     if (n_long > 0 && long_threshold < 1) return fail(CTGCN_E_INVALID, "core_aggregate: long_threshold must be >= 1");
+    if (int rc = set_hub_pieces(a, K, hub_split, hub_workspace, hub_workspace_bytes, "core_aggregate")) return rc;
     const bool v4 = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(X) && aligned16(H);
     return launch_agg<true>(a, v4, (hipStream_t)stream);
 }
@@ -3164,6 +3274,7 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
                                    const float *val, const uint8_t *slot, const float *X, int64_t ldx, uint32_t flags,
                                    const int32_t *long_rows, int32_t n_long, int32_t long_threshold, int32_t n_out,
                                    const int32_t *row_order, const uint32_t *tile_mask, const int32_t *long_rows_pos,
+                                   int32_t hub_split, void *hub_workspace, size_t hub_workspace_bytes,
                                    void *workspace, size_t workspace_bytes, void *stream)
 {
     if (n_rows < 0 || d <= 0 || ldx < d || n_out < 1) return fail(CTGCN_E_INVALID, "core_aggregate_split: bad sizes n=%lld d=%d ldx=%lld", (long long)n_rows, d, (long long)ldx);
@@ -3198,6 +3309,7 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
     a.passes = p.passes;
     if (a.n_long > 0 && (size_t)K * p.lpr * 16 > HUB_LDS_BUDGET) a.n_long = 0;      // K*d too large for the hub kernel's LDS partials
     if (a.n_long <= 0) { a.n_long = 0; a.long_thresh = 0x7fffffff; }
+    if (int rc = set_hub_pieces(a, K, hub_split, hub_workspace, hub_workspace_bytes, "core_aggregate_split")) return rc;
     const int rows_per_block = p.chunks <= 32 ? 8 : 4;
     const int64_t blocks = (n_rows + rows_per_block - 1) / rows_per_block;
     if (blocks > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: grid too large");
@@ -3221,10 +3333,11 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
         if (p.lpr == L) {                                                                                                                 \
             auto k = agg_fwd_hub_kernel<4, L, 4>;                                                                                        \
             if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(k, dim3((unsigned)a.n_long), dim3(HUB_THREADS), lds, st, a);                                              \
+            hipLaunchKernelGGL(k, dim3((unsigned)a.n_long * (unsigned)(a.hub_part ? a.hub_split : 1)), dim3(HUB_THREADS), lds, st, a);    \
         }
         HUBCASE(8) else HUBCASE(16) else HUBCASE(32) else HUBCASE(64)
 #undef HUBCASE
+        if (a.hub_part) hipLaunchKernelGGL((agg_hub_final_kernel<4, true>), dim3((unsigned)a.n_long), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
         // (hub rows leave with all K slots, whatever the tile mask says: the extra rows are never read)
         const int rc = ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, row_order ? long_rows_pos : long_rows, K, rsc, stream);
@@ -3257,7 +3370,7 @@ int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int
                                  const int32_t *col_idx, const float *val, const uint8_t *slot,
                                  const float *Z, const float *S0, float *dX, int64_t lddx,
                                  uint32_t flags, const int32_t *long_rows, int32_t n_long,
-                                 int32_t long_threshold, void *stream)
+                                 int32_t long_threshold, int32_t hub_split, void *hub_workspace, size_t hub_workspace_bytes, void *stream)
 {
     if (n_rows < 0 || d <= 0 || lddx < d || K < 1 || K > CTGCN_MAX_SLOTS) return fail(CTGCN_E_INVALID, "core_aggregate_bwd: bad sizes");
     if (n_rows == 0) return CTGCN_OK;
@@ -3271,8 +3384,14 @@ int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int
     a.out = dX; a.out_ld = lddx; a.flags = flags; a.accumulate = 0;
     a.long_rows = long_rows; a.n_long = n_long; a.long_thresh = long_threshold;
     if (n_long > 0 && long_threshold < 1) return fail(CTGCN_E_INVALID, "core_aggregate_bwd: long_threshold must be >= 1");
+    if (int rc = set_hub_pieces(a, 1, hub_split, hub_workspace, hub_workspace_bytes, "core_aggregate_bwd")) return rc;
     const bool v4 = (d % 4 == 0) && (lddx % 4 == 0) && aligned16(Z) && aligned16(dX) && (!a.self || aligned16(a.self));
     return launch_agg<false>(a, v4, (hipStream_t)stream);
+}
+
+size_t ctgcn_hub_workspace_bytes(int32_t n_long, int32_t hub_split, int32_t slots, int32_t d)
+{
+    return hub_workspace_bytes_(n_long, hub_split, slots, d);
 }
 
 size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t K)

@@ -162,6 +162,15 @@ def linear_of_identity(weight, bias):
 
 
 # -------------------------------------------------------------------- CoreDiffusion aggregation
+def _hub_pieces(lib, adj, long_rows, slots, d, device, transposed=False):
+    """(hub_split, workspace, bytes) for hub rows long enough to be cut into pieces (several blocks per row + a fixed-order second pass)"""
+    split = adj.hub_split(transposed) if long_rows is not None else 1
+    if split <= 1:
+        return 1, None, 0
+    nbytes = int(lib.ctgcn_hub_workspace_bytes(long_rows.numel(), split, slots, d))
+    return split, torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
 def _aggregate_fwd(adj, x, relu):
     lib = _lib.load()
     n, d = x.shape
@@ -169,9 +178,10 @@ def _aggregate_fwd(adj, x, relu):
     flags = adj.flags | (_lib.F_RELU if relu else 0)
     with torch.cuda.device(x.device), _timed("agg_fwd", n=n, d=d, K=adj.K, nnz=adj.nnz):
         long_rows = adj.long_rows()
+        split, hub_ws, hub_bytes = _hub_pieces(lib, adj, long_rows, adj.K, d, x.device)
         check(lib.ctgcn_core_aggregate_f32(n, d, adj.K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x),
                                            x.stride(0), ptr(H), flags, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
-                                           adj.LONG_ROW, _stream()), "ctgcn_core_aggregate_f32")
+                                           adj.LONG_ROW, split, ptr(hub_ws), hub_bytes, _stream()), "ctgcn_core_aggregate_f32")
     return H
 
 
@@ -184,12 +194,15 @@ def _aggregate_bwd(adj, H, dH, relu):
     dX = torch.empty(n, d, dtype=torch.float32, device=dH.device)
     t_ptr, t_col, t_val, t_slot = adj.transposed()
     long_rows = adj.long_rows(transposed=True)
+    split, hub_ws, hub_bytes = _hub_pieces(lib, adj, long_rows, 1, d, dH.device, transposed=True)
     with torch.cuda.device(dH.device):
-        check(lib.ctgcn_core_aggregate_bwd_prep_f32(n, d, K, ptr(dH), ptr(H), ptr(Z), ptr(S0), flags, _stream()),
-              "ctgcn_core_aggregate_bwd_prep_f32")
-        check(lib.ctgcn_core_aggregate_bwd_f32(n, d, K, ptr(t_ptr), ptr(t_col), ptr(t_val), ptr(t_slot), ptr(Z), ptr(S0),
-                                               ptr(dX), d, flags, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
-                                               adj.LONG_ROW, _stream()), "ctgcn_core_aggregate_bwd_f32")
+        with _timed("agg_bwd_prep", n=n, d=d, K=K, self_loop=adj.self_loop):
+            check(lib.ctgcn_core_aggregate_bwd_prep_f32(n, d, K, ptr(dH), ptr(H), ptr(Z), ptr(S0), flags, _stream()),
+                  "ctgcn_core_aggregate_bwd_prep_f32")
+        with _timed("agg_bwd", n=n, d=d, K=K, nnz=adj.nnz):
+            check(lib.ctgcn_core_aggregate_bwd_f32(n, d, K, ptr(t_ptr), ptr(t_col), ptr(t_val), ptr(t_slot), ptr(Z), ptr(S0),
+                                                   ptr(dX), d, flags, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
+                                                   adj.LONG_ROW, split, ptr(hub_ws), hub_bytes, _stream()), "ctgcn_core_aggregate_bwd_f32")
     return dX
 
 
@@ -451,11 +464,12 @@ def aggregate_split_planes(x, adj, n_out, plan=None, ws=None):
     if ws is None:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     long_pos = plan["inverse"][long_rows.long()].contiguous() if (plan is not None and n_long) else None
+    split, hub_ws, hub_bytes = _hub_pieces(lib, adj, long_rows, adj.K, d, x.device)
     with _timed("agg_fwd", n=n, d=d, K=adj.K, nnz=adj.nnz, split=True, rows_written=(plan["new_rows"] if plan is not None else n * adj.K)):
         check(lib.ctgcn_core_aggregate_split_f32(n, d, adj.K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x), x.stride(0),
                                                  flags, ptr(long_rows), n_long, adj.LONG_ROW, n_out,
                                                  ptr(plan["order"]) if plan is not None else None, ptr(plan["tile_mask"]) if plan is not None else None,
-                                                 ptr(long_pos), ptr(ws), ws_bytes, _stream()), "ctgcn_core_aggregate_split_f32")
+                                                 ptr(long_pos), split, ptr(hub_ws), hub_bytes, ptr(ws), ws_bytes, _stream()), "ctgcn_core_aggregate_split_f32")
     return ws, ws_bytes
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 13
+#define CTGCN_ABI_VERSION 14
 
 enum {
     CTGCN_OK = 0,
@@ -89,13 +89,19 @@ int ctgcn_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *row_ptr, const 
  * otherwise it is present in A_s only.  H is [n_rows, K, d] contiguous (the [batch, core, feat]
  * layout nn.GRU(batch_first=True) consumes at layers.py:59).   1 <= K <= CTGCN_MAX_SLOTS.
  * long_rows (optional, device int32[n_long]): the rows with more than long_threshold entries (hubs).  They are
- * skipped by the row-per-lane-group kernel and processed one 256-thread block each, so that a 100k-entry row does
+ * skipped by the row-per-lane-group kernel and processed one 1024-thread block each, so that a 100k-entry row does
  * not serialise on 32 lanes.  n_long == 0 disables the split.
+ * hub_split > 1 with a hub workspace (ctgcn_hub_workspace_bytes(n_long, hub_split, slots = K forward / 1 backward, d) bytes, 16-byte
+ * aligned): a hub row of L entries is cut into min(hub_split, ceil(L / 8192)) pieces, one block each; a second small kernel adds the
+ * pieces' partial sums in piece order and finishes the row (two passes, fixed order: results do not depend on scheduling).
+ * hub_split <= 1 or a NULL workspace: one block per hub row.  hub_split <= 64.
  */
+size_t ctgcn_hub_workspace_bytes(int32_t n_long, int32_t hub_split, int32_t slots, int32_t d);
 int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
                              const int32_t *col_idx, const float *val, const uint8_t *slot,
                              const float *X, int64_t ldx, float *H, uint32_t flags,
-                             const int32_t *long_rows, int32_t n_long, int32_t long_threshold, void *stream);
+                             const int32_t *long_rows, int32_t n_long, int32_t long_threshold,
+                             int32_t hub_split, void *hub_workspace, size_t hub_workspace_bytes, void *stream);
 
 /*
  * Backward of ctgcn_core_aggregate_f32 w.r.t. X (what autograd derives for layers.py:41-48).
@@ -113,7 +119,8 @@ int ctgcn_core_aggregate_bwd_f32(int64_t n_rows, int32_t d, int32_t K, const int
                                  const int32_t *col_idx, const float *val, const uint8_t *slot,
                                  const float *Z, const float *S0, float *dX, int64_t lddx,
                                  uint32_t flags, const int32_t *long_rows, int32_t n_long,
-                                 int32_t long_threshold, void *stream);
+                                 int32_t long_threshold, int32_t hub_split, void *hub_workspace, size_t hub_workspace_bytes,
+                                 void *stream);
 
 /*
  * Edge rows (in file order) -> the snapshot's simple undirected weighted graph as symmetric, zero-diagonal CSR
@@ -263,6 +270,7 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
                                    const float *val, const uint8_t *slot, const float *X, int64_t ldx, uint32_t flags,
                                    const int32_t *long_rows, int32_t n_long, int32_t long_threshold, int32_t n_out,
                                    const int32_t *row_order, const uint32_t *tile_mask, const int32_t *long_rows_pos,
+                                   int32_t hub_split, void *hub_workspace, size_t hub_workspace_bytes,
                                    void *workspace, size_t workspace_bytes, void *stream);
 int ctgcn_linear_presplit_f32(int64_t rows, int32_t n_out, int32_t k, const float *w, int64_t ldw, const float *bias, float *y, int64_t ldy,
                               void *workspace, size_t workspace_bytes, void *stream);

@@ -216,7 +216,7 @@ def test_abi_rejects_bad_arguments():
     import ctypes
     lib = _lib.load()
     x = torch.zeros(4, 4, device=_dev())
-    rc = lib.ctgcn_core_aggregate_f32(4, 4, 0, None, None, None, None, x.data_ptr(), 4, x.data_ptr(), 0, None, 0, 0, None)
+    rc = lib.ctgcn_core_aggregate_f32(4, 4, 0, None, None, None, None, x.data_ptr(), 4, x.data_ptr(), 0, None, 0, 0, 1, None, 0, None)
     assert rc == -1 and b"K=0" in lib.ctgcn_last_error()
     rc = lib.ctgcn_kcore_i32(4, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 8, -1, None, None)
     assert rc == -3
@@ -322,6 +322,42 @@ def test_hub_rows_take_the_block_per_row_path(d, long_row):
             assert adj.long_rows().numel() > 100
     finally:
         CoreAdj.LONG_ROW = old
+
+
+@pytest.mark.parametrize("d", [128, 500, 12])
+def test_very_long_hub_rows_are_cut_into_pieces(d):
+    """rows longer than 8192 entries: several blocks per row + a fixed-order second pass (forward, backward and the inference
+    path's compact scratch), against the CPU oracle; two runs are bit-identical (nothing depends on block scheduling)."""
+    from ctgcn_amd import CoreAdj, CoreDiffusion, ops
+    from ctgcn_amd.utils import symmetric_csr_from_rows
+    from oracle import oracle as O
+    n = 60000
+    rng = np.random.default_rng(d)
+    src = np.concatenate([np.zeros(45000, np.int64), np.ones(20000, np.int64), rng.integers(2, n, 60000)])
+    dst = np.concatenate([rng.choice(np.arange(2, n), 45000, replace=False), rng.choice(np.arange(2, n), 20000, replace=False),
+                          rng.integers(2, n, 60000)])
+    csr = symmetric_csr_from_rows(src, dst, rng.integers(1, 5, len(src)) * 0.5, n)
+    kept = O.core_adj_list([O.kcore_matrices(csr)], 0, 1, 1, max_core=4)[0]
+    adj = _agg_case(kept, d, seed=1, rtol=2e-5)          # forward + backward vs the oracle (45 000-term sums)
+    assert adj.long_rows().numel() == 2 and adj.hub_split() == 6
+    x = torch.randn(n, d, device=_dev(), requires_grad=True)
+    runs = []
+    for _ in range(2):
+        x.grad = None
+        H = ops.core_aggregate(x, adj)
+        H.square().sum().backward()
+        runs.append((H.detach().clone(), x.grad.clone()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    if d % 4 == 0:                                          # inference: hub rows pass through the compact scratch of the split kernels
+        torch.manual_seed(0)
+        layer = CoreDiffusion(d, 128).to(_dev()).eval()
+        with torch.no_grad():
+            fused = layer(x.detach(), adj)
+        seq = ops.core_aggregate(x.detach(), adj)
+        from ctgcn_amd.layers import rnn_reduce_norm
+        with torch.no_grad():
+            plain = rnn_reduce_norm(layer.rnn, layer.norm, seq, reduce_sum=True)
+        assert torch.isfinite(fused).all() and torch.equal(fused, plain)
 
 
 def test_hub_rows_general_lists():

@@ -118,22 +118,29 @@ class CoreAdj(object):
 
     # ------------------------------------------------------------------ repeated rows of H (inference path)
     PLAN_TILE = 16      # sequences per tile of the GRU layer kernel (gru_layer8_h2_kernel)
+    PLAN_TILE_GEMM = 64 # ... and of the recurrence kernel behind the split GEMM (gru_seq_h2_kernel)
 
-    def row_plan(self):
-        """Row plan for ctgcn_core_aggregate_split_f32 + ctgcn_gru_layer_presplit_f32, or None (K > 32).
+    def row_plan(self, tile=None):
+        """Row plan for the inference path (ctgcn_core_aggregate_split_f32 and its consumers), or None (K > 32).
 
         layers.py:41-48: res_j = res_{j-1} + A_j x, so as long as no entry of row v has arrived (slots below the row's first tag f;
         nested lists: f = K - capped core number) H[v, 0..f-1] is the same row relu(x_v) f times, and the GRU multiplies it by W_ih f
         times (layers.py:58-59).  The plan lets the kernels write and multiply it once:
-          order      int32[n]   matrix row handled at position p.  Rows with equal repeat patterns are neighbours, so that the 16
-                                sequences of a GRU tile share one pattern; inside a pattern rows go by falling degree (the two rows of a
+          order      int32[n]   matrix row handled at position p.  Rows with equal repeat patterns are neighbours, so that the
+                                sequences of a GRU tile share one; inside a pattern rows go by falling degree (the two rows of a
                                 wave and the eight of a block are equally long, and the long blocks of a launch start first).
-          tile_mask  int32[ceil(n / 16)]  bit j set = slot j carries a new row for at least one of the tile's positions (bit 0 always)
+          tile_mask  int32[ceil(n / tile)]  bit j set = slot j carries a new row for at least one of the tile's positions (bit 0 always)
+          tile_base  int32[tiles]  first COMPACT operand row of the tile (tile * popcount(mask) rows per tile, incl. the padding
+                                of the last one) and operand_rows, their total: the GEMM consumer's layout (tile = 64)
           inverse    int32[n]   position of matrix row v (hub rows are looked up here)
+        tile: PLAN_TILE (16: the GRU layer kernel reads the planes with holes) or PLAN_TILE_GEMM (64).
         Static per graph: built once on the device, cached."""
+        tile = self.PLAN_TILE if tile is None else int(tile)
         if self.K > 32 or self.n == 0:
             return None
         if self._plan is None:
+            self._plan = {}
+        if "order" not in self._plan:
             dev, n, K = self.device, self.n, self.K
             rp = self.row_ptr.long()
             deg = rp[1:] - rp[:-1]
@@ -151,20 +158,47 @@ class CoreAdj(object):
                 mask = (present.view(n, K) * bit[None, :]).sum(1) | 1
             o1 = torch.argsort(deg, descending=True, stable=True)
             order = o1[torch.argsort(mask[o1], descending=True, stable=True)]
-            T = self.PLAN_TILE
-            ntiles = -(-n // T)
-            padded = torch.ones(ntiles * T, dtype=torch.int64, device=dev)
-            padded[:n] = mask[order]
-            tiles = padded.view(ntiles, T)
-            tmask = torch.zeros(ntiles, dtype=torch.int64, device=dev)
-            for j in range(K):
-                tmask |= ((tiles >> j) & 1).any(1).long() << j
             inverse = torch.empty(n, dtype=torch.int64, device=dev)
             inverse[order] = torch.arange(n, device=dev)
-            self._plan = dict(order=order.to(torch.int32).contiguous(), tile_mask=tmask.to(torch.int32).contiguous(),
-                              inverse=inverse.to(torch.int32).contiguous(),
-                              new_rows=int(sum(int(((tmask >> j) & 1).sum()) for j in range(K))) * T)   # (position, slot) rows written per layer (incl. tile padding)
-        return self._plan
+            self._plan.update(order=order.to(torch.int32).contiguous(), inverse=inverse.to(torch.int32).contiguous(),
+                              _sorted_mask=mask[order])
+        if tile not in self._plan:
+            dev, n, K = self.device, self.n, self.K
+            ntiles = -(-n // tile)
+            padded = torch.ones(ntiles * tile, dtype=torch.int64, device=dev)
+            padded[:n] = self._plan["_sorted_mask"]
+            tiles = padded.view(ntiles, tile)
+            tmask = torch.zeros(ntiles, dtype=torch.int64, device=dev)
+            fresh = torch.zeros(ntiles, dtype=torch.int64, device=dev)
+            for j in range(K):
+                anyj = ((tiles >> j) & 1).any(1).long()
+                tmask |= anyj << j
+                fresh += anyj
+            per_tile = fresh * tile                                   # compact operand rows of each tile
+            base = torch.cumsum(per_tile, 0) - per_tile
+            total = int(per_tile.sum().item())
+            if total >= 2 ** 31:
+                return None
+            self._plan[tile] = dict(order=self._plan["order"], inverse=self._plan["inverse"], tile=tile,
+                                    tile_mask=tmask.to(torch.int32).contiguous(), tile_base=base.to(torch.int32).contiguous(),
+                                    new_rows=total, operand_rows=total)      # (position, slot) rows written per layer (incl. tile padding)
+        return self._plan[tile]
+
+    def plan_row_dest(self, plan, rows, compact):
+        """int32[len(rows) * K]: operand row of slot j of matrix row rows[i] under `plan` (hub rows take this map), -1 = not wanted.
+        compact: the GEMM consumer's layout (tile_base), else rows position * K + slot."""
+        K, tile = self.K, plan["tile"]
+        pos = plan["inverse"][rows.long()].long()
+        t = torch.div(pos, tile, rounding_mode="floor")
+        need = plan["tile_mask"][t].long() & 0xffffffff
+        j = torch.arange(K, device=pos.device)[None, :]
+        bits = (need[:, None] >> j) & 1
+        if compact:
+            rank = torch.cumsum(bits, 1) - bits
+            dest = plan["tile_base"][t].long()[:, None] + (pos % tile)[:, None] * bits.sum(1, keepdim=True) + rank
+        else:
+            dest = pos[:, None] * K + j
+        return torch.where(bits.bool(), dest, torch.full_like(dest, -1)).to(torch.int32).contiguous().view(-1)
 
     # ------------------------------------------------------------------ transposed view (backward pass)
     def transposed(self):

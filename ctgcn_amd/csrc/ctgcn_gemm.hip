@@ -62,8 +62,10 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *src = x + row * ldx;
-    // destination row: the same, or (hub rows of the fused aggregation) group g of `group` consecutive source rows -> group group_map[g]
-    const int64_t drow = group_map ? (int64_t)group_map[row / group] * group + row % group : row;
+    // destination row: the same, or (hub rows of the fused aggregation) group g of `group` consecutive source rows -> group group_map[g],
+    // or (group < 0) group_map[row] itself, a negative entry meaning "this row is not wanted" (a repeated row under a row plan)
+    const int64_t drow = !group_map ? row : (group < 0 ? (int64_t)group_map[row] : (int64_t)group_map[row / group] * group + row % group);
+    if (drow < 0) return;
     float m = 0.f;
     constexpr int HOLD = 8;                               // float4 per lane kept in registers: rows up to 2048 columns are read ONCE
     f4v keep[HOLD];
@@ -372,7 +374,8 @@ static void launch_split(int64_t rows, int32_t k, int32_t kp, const float *x, in
     else hipLaunchKernelGGL(split_rows_h2_kernel<false>, grid, dim3(256), 0, st, rows, k, kp, x, ldx, p1, p2, scale, group_map, group, residual_scale);
 }
 
-// internal (ctgcn_hip.hip: hub rows of ctgcn_core_aggregate_split_f32): source row r -> plane row group_map[r / group] * group + r % group
+// internal (ctgcn_hip.hip: hub rows of ctgcn_core_aggregate_split_f32): source row r -> plane row group_map[r / group] * group + r % group,
+// or with group < 0: -> plane row group_map[r] (negative: skipped)
 int ctgcn_split_rows_mapped_(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, void *p1, void *p2, float *scale,
                              const int32_t *group_map, int32_t group, float residual_scale, void *stream)
 {

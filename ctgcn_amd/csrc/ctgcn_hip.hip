@@ -100,6 +100,11 @@ struct AggArgs {
     // the consumer multiplies the repeated row by W_ih once.  Both null: natural order, every slot written.
     const int32_t *order;
     const uint32_t *tmask;
+    // GEMM consumer (d != 128): tiles of 64 positions (tile_shift 6: the row tile of gru_seq_h2_kernel) and COMPACT operand rows — the
+    // written slots of tile T start at row tbase[T], position p of the tile owns popcount(mask) consecutive rows from
+    // tbase[T] + (p % 64) popcount(mask); the GEMM then runs over the compact rows only.  tbase null: rows p K + slot (holes).
+    int32_t tile_shift;
+    const int32_t *tbase;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -858,6 +863,13 @@ struct GruArgs {
     float *gates;           // optional [rows, steps, 4, 128]: r, z, n, q = W_hn h + b_hn, saved for the backward kernel
     int32_t gi_blocked;     // gi is in the blocked tile layout (gi_blocked_offset); fp16x2 kernel only
     int64_t ldo;            // reduce_sum: floats between output rows (128 = dense; larger: rows of a [rows, T, 128] tensor)
+    // row plan of the aggregation that produced gi through the GEMM (gru_seq_h2_kernel<reduce>, plain gi layout only; all null: gi is
+    // [rows, steps, 384]).  Sequence p is written to out row order[p]; gi holds only the steps that bring a new x, compactly: tile T (64
+    // sequences) starts at gi row tbase[T], sequence p owns popcount(tmask[T]) consecutive rows, and step t of it reads the row of the
+    // last set bit <= t of tmask[T] (a repeated x row has the same projection: the reference multiplies it again, layers.py:59).
+    const int32_t *order;
+    const uint32_t *tmask;
+    const int32_t *tbase;
 };
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each): far inside the fp32 tolerance of the layer, a fraction of an IEEE divide's cost
@@ -1358,7 +1370,9 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
     if (pos >= a.n) return;
     const int64_t row = a.order ? (int64_t)a.order[pos] : pos;
     // the block's 256 / LPR positions lie in one 16-position tile: a scalar load
-    const uint32_t need = a.tmask ? a.tmask[((int64_t)blockIdx.x * (256 / LPR)) >> 4] : 0xffffffffu;
+    const int64_t tile = ((int64_t)blockIdx.x * (256 / LPR)) >> a.tile_shift;
+    const uint32_t need = a.tmask ? a.tmask[tile] : 0xffffffffu;
+    const int64_t obase = a.tbase ? (int64_t)a.tbase[tile] + (pos & ((1 << a.tile_shift) - 1)) * __popc(need) : pos * a.K;
     const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
     if (end - start > a.long_thresh) return;          // hub row: agg_fwd_hub_kernel into the compact scratch, split afterwards
     const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0;
@@ -1397,7 +1411,7 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
         m = group_max<LPR>(m);
         float s, inv;
         h2_scale(m, s, inv);
-        const int64_t orow = pos * a.K + cur;
+        const int64_t orow = obase + (a.tbase ? __popc(need & ((1u << cur) - 1u)) : cur);
         if (lig == 0) scale[orow] = s;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -1675,7 +1689,13 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
         const float *gi_tile = a.gi_blocked ? a.gi + tile * (int64_t)gstride * GRU_BM + wave * 1024 + col * 16 + 4 * grp
                                             : a.gi + row0 * gstride + oc;
         const int gi_gs = a.gi_blocked ? 8 * 1024 : GRU_H;
+        // compact gi under a row plan (REDUCE form only): see GruArgs
+        const bool planned = REDUCE && !SAVE && a.tmask != nullptr;
+        const uint32_t tm = planned ? a.tmask[tile] : 0u;
+        const int nfresh = __popc(tm);
+        const float *gi_plan = planned ? a.gi + (int64_t)a.tbase[tile] * (3 * GRU_H) + oc : nullptr;
         auto gaddr = [&](int t, int rt) {
+            if (planned) return gi_plan + ((int64_t)min(rt * 16 + col, last) * nfresh + (__popc(tm & ((2u << t) - 1u)) - 1)) * (3 * GRU_H);
             return a.gi_blocked ? gi_tile + t * (3 * 8 * 1024) + rt * 256 : gi_tile + t * 3 * GRU_H + min(rt * 16 + col, last) * gstride;
         };
         f4v hreg[GRU_RT];
@@ -1818,8 +1838,10 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
             emit_step(steps - 1);
         }
         if (REDUCE)
-            for (int r = wave; r <= last; r += 8)
-                gru_layernorm_row(sbuf[r], a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
+            for (int r = wave; r <= last; r += 8) {
+                const int64_t orow = (planned && a.order) ? (int64_t)a.order[row0 + r] : row0 + r;
+                gru_layernorm_row(sbuf[r], a.out + orow * a.ldo, lane, a.gamma, a.beta, a.eps);
+            }
         __syncthreads();       // LDS is reused by the next tile
     }
 }
@@ -3267,13 +3289,15 @@ int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t
 size_t ctgcn_core_aggregate_split_workspace_bytes(int64_t n_rows, int32_t d, int32_t K, int32_t n_out, int32_t n_long)
 {
     if (n_rows < 0 || d < 1 || K < 1 || n_out < 1 || n_long < 0) return 0;
-    return ctgcn_linear_workspace_bytes(n_rows * K, n_out, d) + ((size_t)n_long * K * d * 4 + 255) / 256 * 256;
+    // (n_rows rounded up to whole tiles of 64: the compact operand rows of a row plan include the padding of the last tile)
+    return ctgcn_linear_workspace_bytes((n_rows + 63) / 64 * 64 * K, n_out, d) + ((size_t)n_long * K * d * 4 + 255) / 256 * 256;
 }
 
 int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr, const int32_t *col_idx,
                                    const float *val, const uint8_t *slot, const float *X, int64_t ldx, uint32_t flags,
                                    const int32_t *long_rows, int32_t n_long, int32_t long_threshold, int32_t n_out,
-                                   const int32_t *row_order, const uint32_t *tile_mask, const int32_t *long_rows_pos,
+                                   const int32_t *row_order, const uint32_t *tile_mask, const int32_t *tile_base, int64_t operand_rows,
+                                   const int32_t *hub_row_dest,
                                    int32_t hub_split, void *hub_workspace, size_t hub_workspace_bytes,
                                    void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -3286,24 +3310,28 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
         return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: needs d %% 4 == 0, d <= 512, 16-byte aligned rows, 256-byte aligned workspace");
     if (n_long < 0 || (n_long > 0 && (!long_rows || long_threshold < 1))) return fail(CTGCN_E_INVALID, "core_aggregate_split: bad hub row list");
     if ((row_order == nullptr) != (tile_mask == nullptr)) return fail(CTGCN_E_INVALID, "core_aggregate_split: row_order and tile_mask come together");
-    if (row_order && (K > 32 || d != 128 || n_out != 1))
-        return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: a row plan needs K <= 32 and the GRU layer kernel as consumer (d = 128, n_out = 1)");
-    if (row_order && n_long > 0 && !long_rows_pos) return fail(CTGCN_E_INVALID, "core_aggregate_split: hub rows under a row plan need their positions");
+    if (row_order && K > 32) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: a row plan needs K <= 32");
+    if (row_order && ((d == 128 && n_out == 1) != (tile_base == nullptr)))
+        return fail(CTGCN_E_INVALID, "core_aggregate_split: tile_base (compact operand rows, tiles of 64) goes with the GEMM consumer, tiles of 16 without it with the GRU layer kernel");
+    if (!row_order && tile_base) return fail(CTGCN_E_INVALID, "core_aggregate_split: tile_base without a row plan");
+    if (tile_base && (operand_rows < 1 || operand_rows > (n_rows + 63) / 64 * 64 * K))
+        return fail(CTGCN_E_INVALID, "core_aggregate_split: operand_rows=%lld outside [1, ceil64(n_rows) K]", (long long)operand_rows);
+    if (row_order && n_long > 0 && !hub_row_dest) return fail(CTGCN_E_INVALID, "core_aggregate_split: hub rows under a row plan need their destination rows");
     if (workspace_bytes < ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, K, n_out, n_long))
         return fail(CTGCN_E_WORKSPACE, "core_aggregate_split: workspace too small (ctgcn_core_aggregate_split_workspace_bytes)");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t rows = n_rows * K;
+    const int64_t rows = tile_base ? operand_rows : n_rows * K;     // operand rows of the consumer: the planes' layout follows ITS row count
     const int32_t kp = (d + 63) / 64 * 64;                // the k padding of ctgcn_linear_f32
     _Float16 *p1 = (_Float16 *)workspace, *p2 = p1 + (size_t)rows * kp;
     float *scale = (float *)(p2 + (size_t)rows * kp);
-    float *hub = (float *)((char *)workspace + ctgcn_linear_workspace_bytes(rows, n_out, d));
+    float *hub = (float *)((char *)workspace + ctgcn_linear_workspace_bytes((n_rows + 63) / 64 * 64 * K, n_out, d));
     AggArgs a{};
     a.n = n_rows; a.d = d; a.K = K;
     a.row_ptr = row_ptr; a.col = col_idx; a.val = val; a.slot = slot;
     a.src = X; a.ldsrc = ldx; a.self = nullptr; a.out = hub; a.out_ld = (int64_t)K * d;
     a.flags = flags; a.accumulate = 0;
     a.long_rows = long_rows; a.n_long = n_long; a.long_thresh = long_threshold;
-    a.order = row_order; a.tmask = tile_mask;
+    a.order = row_order; a.tmask = tile_mask; a.tbase = tile_base; a.tile_shift = tile_base ? 6 : 4;
     const AggPlan p = plan_for(d, true);
     a.chunks = p.chunks;
     a.passes = p.passes;
@@ -3339,8 +3367,8 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
 #undef HUBCASE
         if (a.hub_part) hipLaunchKernelGGL((agg_hub_final_kernel<4, true>), dim3((unsigned)a.n_long), dim3(256), 0, st, a);
         HIP_TRY(hipGetLastError());
-        // (hub rows leave with all K slots, whatever the tile mask says: the extra rows are never read)
-        const int rc = ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, row_order ? long_rows_pos : long_rows, K, rsc, stream);
+        const int rc = row_order ? ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, hub_row_dest, -1, rsc, stream)
+                                 : ctgcn_split_rows_mapped_((int64_t)a.n_long * K, d, kp, hub, d, p1, p2, scale, long_rows, K, rsc, stream);
         if (rc != CTGCN_OK) return rc;
     }
     return CTGCN_OK;
@@ -3495,9 +3523,14 @@ int64_t ctgcn_gru_row_granule(void)
 
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, int64_t ld_out, float *gates_out, int split_bf16, int gi_blocked, void *stream)
+                      int reduce_sum, float *out, int64_t ld_out, float *gates_out, int split_bf16, int gi_blocked,
+                      const int32_t *row_order, const uint32_t *tile_mask, const int32_t *tile_base, void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq: hidden=%d, only %d is built", hidden, GRU_H);
+    if ((row_order == nullptr) != (tile_mask == nullptr) || (row_order == nullptr) != (tile_base == nullptr))
+        return fail(CTGCN_E_INVALID, "gru_seq: row_order, tile_mask and tile_base come together");
+    if (row_order && (!reduce_sum || gates_out || gi_blocked || split_bf16 != CTGCN_SPLIT_F16X2 || steps > 32))
+        return fail(CTGCN_E_UNSUPPORTED, "gru_seq: a row plan needs the sum-over-steps form, CTGCN_SPLIT_F16X2, the plain gi layout and steps <= 32");
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq: bad sizes rows=%lld steps=%d", (long long)rows, steps);
     if (rows == 0) return CTGCN_OK;
     if (!gi || !w_hh || !out) return fail(CTGCN_E_INVALID, "gru_seq: null pointer");
@@ -3507,6 +3540,7 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     a.rows = rows; a.steps = steps; a.gi = gi; a.whh = w_hh; a.bhn = b_hn; a.gamma = ln_weight; a.beta = ln_bias;
     a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = gates_out; a.gi_blocked = gi_blocked ? 1 : 0;
     a.ldo = ld_out > 0 ? ld_out : GRU_H;
+    a.order = row_order; a.tmask = tile_mask; a.tbase = tile_base;
     if (ld_out > 0 && (!reduce_sum || ld_out < GRU_H || (ld_out & 1))) return fail(CTGCN_E_INVALID, "gru_seq: ld_out=%lld needs reduce_sum and an even value >= %d", (long long)ld_out, GRU_H);
     if (gi_blocked && split_bf16 != CTGCN_SPLIT_F16X2) return fail(CTGCN_E_INVALID, "gru_seq: the blocked gi layout belongs to CTGCN_SPLIT_F16X2");
     if (gates_out && (reduce_sum || ln_weight)) return fail(CTGCN_E_INVALID, "gru_seq: gates_out needs reduce_sum == 0 and no LayerNorm (raw h sequence)");

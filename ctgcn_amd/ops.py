@@ -415,7 +415,7 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
             with _timed("gru_seq", rows=n, steps=steps):
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_buf), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
                                             1 if reduce_sum else 0, ptr(out[lo:lo + n]), ldo, None, split, 1 if blocked else 0,
-                                            _stream()), "ctgcn_gru_seq_f32")
+                                            None, None, None, _stream()), "ctgcn_gru_seq_f32")
     return out
 
 
@@ -454,7 +454,8 @@ def row_plan_enabled():
 
 def aggregate_split_planes(x, adj, n_out, plan=None, ws=None):
     """ctgcn_core_aggregate_split_f32: relu(cumulative A_k x) as fp16 planes + row scales in a workspace (returned).  n_out = width of
-    the GEMM that follows (1: the GRU layer kernel).  plan = adj.row_plan() (layer-kernel consumer only): repeated rows are not written."""
+    the GEMM that follows (1: the GRU layer kernel).  plan = adj.row_plan(tile): repeated rows are not written — tile 16 with the layer
+    kernel as consumer (holes in the [n K] row layout), tile 64 with the GEMM (compact operand rows, plan["operand_rows"] of them)."""
     lib = _lib.load()
     n, d = x.shape
     flags = adj.flags | _lib.F_RELU
@@ -463,13 +464,17 @@ def aggregate_split_planes(x, adj, n_out, plan=None, ws=None):
     ws_bytes = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, d, adj.K, n_out, n_long))
     if ws is None:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    long_pos = plan["inverse"][long_rows.long()].contiguous() if (plan is not None and n_long) else None
+    compact = plan is not None and not (d == 128 and n_out == 1)
+    if plan is not None and plan["tile"] != (adj.PLAN_TILE_GEMM if compact else adj.PLAN_TILE):
+        raise ValueError("aggregate_split_planes: plan tile %d does not belong to this consumer" % plan["tile"])
+    hub_dest = adj.plan_row_dest(plan, long_rows, compact) if (plan is not None and n_long) else None
     split, hub_ws, hub_bytes = _hub_pieces(lib, adj, long_rows, adj.K, d, x.device)
     with _timed("agg_fwd", n=n, d=d, K=adj.K, nnz=adj.nnz, split=True, rows_written=(plan["new_rows"] if plan is not None else n * adj.K)):
         check(lib.ctgcn_core_aggregate_split_f32(n, d, adj.K, ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot), ptr(x), x.stride(0),
                                                  flags, ptr(long_rows), n_long, adj.LONG_ROW, n_out,
                                                  ptr(plan["order"]) if plan is not None else None, ptr(plan["tile_mask"]) if plan is not None else None,
-                                                 ptr(long_pos), split, ptr(hub_ws), hub_bytes, ptr(ws), ws_bytes, _stream()), "ctgcn_core_aggregate_split_f32")
+                                                 ptr(plan["tile_base"]) if compact else None, plan["operand_rows"] if compact else 0,
+                                                 ptr(hub_dest), split, ptr(hub_ws), hub_bytes, ptr(ws), ws_bytes, _stream()), "ctgcn_core_aggregate_split_f32")
     return ws, ws_bytes
 
 
@@ -513,14 +518,18 @@ def core_diffusion_split(x, adj, rnn, norm, out=None):
         ln_w = None if norm is None else norm.weight
         ln_b = None if norm is None else norm.bias
         eps = 0.0 if norm is None else float(norm.eps)
-        ws, ws_bytes = aggregate_split_planes(x, adj, n_out)
-        gi_buf = _gi_buffer(n, K, hid, x.device)
-        with _timed("linear_split", rows=n * K, k=d, n_out=n_out, presplit=True):
-            check(lib.ctgcn_linear_presplit_f32(n * K, n_out, d, ptr(w_ih), w_ih.stride(0), ptr(bias), ptr(gi_buf), n_out, ptr(ws), ws_bytes,
+        plan = adj.row_plan(adj.PLAN_TILE_GEMM) if (row_plan_enabled() and forward_split_mode() == 2) else None
+        ws, ws_bytes = aggregate_split_planes(x, adj, n_out, plan)
+        rows = plan["operand_rows"] if plan is not None else n * K          # under a plan the GEMM only sees rows that bring a new x
+        gi_buf = torch.empty(rows * n_out, dtype=torch.float32, device=x.device) if plan is not None else _gi_buffer(n, K, hid, x.device)
+        with _timed("linear_split", rows=rows, k=d, n_out=n_out, presplit=True):
+            check(lib.ctgcn_linear_presplit_f32(rows, n_out, d, ptr(w_ih), w_ih.stride(0), ptr(bias), ptr(gi_buf), n_out, ptr(ws), ws_bytes,
                                                 _stream()), "ctgcn_linear_presplit_f32")
         with _timed("gru_seq", rows=n, steps=K):
             check(lib.ctgcn_gru_seq_f32(n, K, hid, ptr(gi_buf), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps, 1, ptr(out), out.stride(0),
-                                        None, forward_split_mode(), 0, _stream()), "ctgcn_gru_seq_f32")
+                                        None, forward_split_mode(), 0, ptr(plan["order"]) if plan is not None else None,
+                                        ptr(plan["tile_mask"]) if plan is not None else None, ptr(plan["tile_base"]) if plan is not None else None,
+                                        _stream()), "ctgcn_gru_seq_f32")
     return out
 
 
@@ -601,7 +610,7 @@ class _GruSeq(torch.autograd.Function):
                 gi = gi_flat[: n * steps * 3 * hid].view(n * steps, 3 * hid)                 # the [rows, 3h] view (d_gi later)
                 blocked = _project(x2d, w_ih_d, bias, gi_flat, steps_blocked=steps)
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_flat), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq), 0,
-                                            ptr(gates), forward_split_mode(), 1 if blocked else 0, _stream()), "ctgcn_gru_seq_f32")
+                                            ptr(gates), forward_split_mode(), 1 if blocked else 0, None, None, None, _stream()), "ctgcn_gru_seq_f32")
                 # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)
                 g_out = dout[lo:lo + n]
                 pre = hseq.sum(1) if reduce_sum else hseq

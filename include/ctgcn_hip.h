@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 14
+#define CTGCN_ABI_VERSION 15
 
 enum {
     CTGCN_OK = 0,
@@ -190,10 +190,15 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  *   ([node tile of 64][step][gate][16-column group][node in tile][16]; the buffer must cover ceil(rows/64)*64 rows).
  * gates_out (optional; requires reduce_sum == 0 and ln_weight == NULL): [rows, steps, 4, 128] receives r, z, n and
  * q = W_hn·h_{t-1} + b_hn for ctgcn_gru_seq_bwd_f32.
+ * row_order / tile_mask / tile_base (all or none; reduce_sum, CTGCN_SPLIT_F16X2, plain gi layout, steps <= 32): gi was projected from
+ * the COMPACT operand rows ctgcn_core_aggregate_split_f32 wrote under a row plan with tiles of 64 — only the steps that bring a new x
+ * row exist: tile T starts at gi row tile_base[T], sequence p of it owns popcount(tile_mask[T]) consecutive rows, step t reads the row of
+ * the last set bit <= t.  Sequence p is written to out row row_order[p].  Same arithmetic on the same numbers: bit-identical.
  */
 int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                       const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
-                      int reduce_sum, float *out, int64_t ld_out, float *gates_out, int split_bf16, int gi_blocked, void *stream);
+                      int reduce_sum, float *out, int64_t ld_out, float *gates_out, int split_bf16, int gi_blocked,
+                      const int32_t *row_order, const uint32_t *tile_mask, const int32_t *tile_base, void *stream);
 
 /*
  * The same for nn.LSTM (rnn_type = 'LSTM'; layers.py:27-28, models.py:234-235): gi [rows, steps, 512] = x·W_ih^T + b_ih
@@ -262,14 +267,22 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
  *   reference computes, stacks and multiplies by W_ih f times (layers.py:41-48,58-59).  With a plan, operand rows p K .. p K + K - 1
  *   belong to matrix row row_order[p] (a permutation that puts rows with equal repeat patterns next to each other, so that the 16
  *   sequences of a GRU tile share one), and slot j of position p is only WRITTEN when bit j of tile_mask[p / 16] is set (bit 0 always
- *   is; a clear bit j promises that slot j repeats slot j - 1 for all 16 positions of the tile).  long_rows_pos[i] = position of hub
- *   row long_rows[i] (required when n_long > 0).  The planes' layout does not change - skipped rows are holes nobody reads.
+ *   is; a clear bit j promises that slot j repeats slot j - 1 for all 16 positions of the tile).  The planes' layout does not change -
+ *   skipped rows are holes nobody reads.
+ *   GEMM consumer (d != 128) under a row plan: tiles of 64 positions (the row tile of ctgcn_gru_seq_f32) and tile_base int32[tiles]:
+ *   the operand rows are COMPACT - tile T's written rows start at row tile_base[T], position p owns popcount(tile_mask[T])
+ *   consecutive rows (one per set bit, in slot order) from tile_base[T] + (p % 64) popcount(tile_mask[T]); operand_rows = their total
+ *   (incl. the padding of the last tile), which is the row count ctgcn_linear_presplit_f32 is then called with, and
+ *   ctgcn_gru_seq_f32 takes the same plan.  tile_base NULL with d = 128, n_out = 1.
+ *   hub_row_dest int32[n_long K] (required under a row plan when n_long > 0): operand row of slot j of hub row long_rows[i], or -1
+ *   when the plan does not want that slot.
  */
 size_t ctgcn_core_aggregate_split_workspace_bytes(int64_t n_rows, int32_t d, int32_t K, int32_t n_out, int32_t n_long);
 int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr, const int32_t *col_idx,
                                    const float *val, const uint8_t *slot, const float *X, int64_t ldx, uint32_t flags,
                                    const int32_t *long_rows, int32_t n_long, int32_t long_threshold, int32_t n_out,
-                                   const int32_t *row_order, const uint32_t *tile_mask, const int32_t *long_rows_pos,
+                                   const int32_t *row_order, const uint32_t *tile_mask, const int32_t *tile_base, int64_t operand_rows,
+                                   const int32_t *hub_row_dest,
                                    int32_t hub_split, void *hub_workspace, size_t hub_workspace_bytes,
                                    void *workspace, size_t workspace_bytes, void *stream);
 int ctgcn_linear_presplit_f32(int64_t rows, int32_t n_out, int32_t k, const float *w, int64_t ldw, const float *bias, float *y, int64_t ldy,

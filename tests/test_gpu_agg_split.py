@@ -222,13 +222,41 @@ def test_row_plan_with_hub_rows_general_lists_and_k1(monkeypatch):
         cases.append(CoreAdj.from_matrices(mats, device=_dev(), self_loop=False))
         cases.append(CoreAdj.from_matrices([mats[0]], device=_dev(), self_loop=True))
         for a in cases:
-            layer = _layer(128, 2)
-            x = torch.randn(a.n, 128, device=_dev())
-            with torch.no_grad():
-                monkeypatch.setenv("CTGCN_DEDUP", "1")
-                got = layer(x, a)
-                monkeypatch.setenv("CTGCN_DEDUP", "0")
-                want = layer(x, a)
-            assert torch.isfinite(got).all() and torch.equal(got, want)
+            for d in (128, 500, 64):          # 128: GRU layer kernel on planes with holes; others: split GEMM on compact operand rows
+                layer = _layer(d, 2)
+                x = torch.randn(a.n, d, device=_dev())
+                with torch.no_grad():
+                    monkeypatch.setenv("CTGCN_DEDUP", "1")
+                    got = layer(x, a)
+                    monkeypatch.setenv("CTGCN_DEDUP", "0")
+                    want = layer(x, a)
+                assert torch.isfinite(got).all() and torch.equal(got, want), (a.n, a.K, d)
     finally:
         CoreAdj.LONG_ROW = old
+
+
+@pytest.mark.parametrize("d,n", [(500, 70001), (256, 5000), (96, 129), (500, 64), (500, 3)])
+def test_compact_operand_rows_for_the_gemm_consumer(d, n, monkeypatch):
+    """d != 128: under the row plan the aggregation writes only the rows that bring a new x, compactly; the split GEMM runs over those
+    rows and the recurrence kernel reads a step's projection from the row of the last new x — the same numbers as without a plan."""
+    from ctgcn_amd import ops
+    adj, _ = _sparse_core_adj(n, seed=n + d)
+    plan = adj.row_plan(adj.PLAN_TILE_GEMM)
+    assert plan["operand_rows"] <= -(-n // 64) * 64 * adj.K
+    if n >= 5000:
+        assert plan["operand_rows"] < 0.8 * n * adj.K
+    layer = _layer(d, 4)
+    x = torch.randn(n, d, device=_dev())
+    names = []
+    ops.set_launch_timer(lambda name, s, e, meta: names.append((name, dict(meta))))
+    try:
+        with torch.no_grad():
+            monkeypatch.setenv("CTGCN_DEDUP", "1")
+            got = layer(x, adj)
+            rows_gemm = [m["rows"] for nm, m in names if nm == "linear_split"]
+            monkeypatch.setenv("CTGCN_DEDUP", "0")
+            want = layer(x, adj)
+    finally:
+        ops.set_launch_timer(None)
+    assert rows_gemm == [plan["operand_rows"]]
+    assert torch.isfinite(got).all() and torch.equal(got, want)

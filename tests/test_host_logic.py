@@ -469,4 +469,19 @@ def test_row_plan_names_exactly_rows_that_repeat_in_the_oracle():
         loose = ((bits == 1) & ~own).any(axis=1).reshape(-1)
         assert loose.sum() <= 16 * (1 << K), loose.sum()
         assert plan["new_rows"] == 16 * sum(bin(int(m) & ((1 << K) - 1)).count("1") for m in tmask)
+        # the GEMM consumer's compact layout (tiles of 64): every wanted (row, slot) has its own operand row inside its tile's range
+        p64 = adj.row_plan(adj.PLAN_TILE_GEMM)
+        tb, tm64 = p64["tile_base"].numpy().astype(np.int64), p64["tile_mask"].numpy().astype(np.int64) & 0xffffffff
+        cnt = np.array([bin(int(m)).count("1") for m in tm64])
+        assert np.array_equal(tb, np.cumsum(cnt * 64) - cnt * 64) and p64["operand_rows"] == int((cnt * 64).sum())
+        dest = adj.plan_row_dest(p64, torch.arange(n), True).numpy().reshape(n, K)
+        pos = p64["inverse"].numpy().astype(np.int64)
+        want_bits = (tm64[pos // 64][:, None] >> np.arange(K)[None, :]) & 1
+        assert np.array_equal(dest >= 0, want_bits == 1)
+        used = dest[dest >= 0]
+        assert len(np.unique(used)) == len(used) and used.max() < p64["operand_rows"]
+        lo, hi = tb[pos // 64], tb[pos // 64] + cnt[pos // 64] * 64
+        assert ((dest >= lo[:, None]) | (dest < 0)).all() and (dest < hi[:, None]).all()
+        assert np.array_equal(adj.plan_row_dest(plan, torch.arange(n), False).numpy().reshape(n, K),
+                              np.where(bits[np.argsort(order)] == 1, (np.argsort(order) * K)[:, None] + np.arange(K)[None, :], -1))
     assert CoreAdj.from_matrices([general[0]] * 1, self_loop=True).row_plan()["new_rows"] == -(-n // 16) * 16

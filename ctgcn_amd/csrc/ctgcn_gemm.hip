@@ -38,6 +38,7 @@ namespace {
     } while (0)
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef f4v f4u __attribute__((aligned(4)));            // a float4 at a 4-byte aligned address
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
@@ -69,31 +70,38 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
     float m = 0.f;
     constexpr int HOLD = 8;                               // float4 per lane kept in registers: rows up to 2048 columns are read ONCE
     f4v keep[HOLD];
-    const bool held = VEC && K <= HOLD * 256;
-    if (VEC) {
-        if (held) {
+    const bool held = K <= HOLD * 256;
+    // VEC: 16-byte aligned rows, K % 4 == 0.  Otherwise (K = 1737: rows are only 4-byte aligned) the same 16-byte loads from 4-byte
+    // aligned addresses — gfx950 serves them (unaligned access mode), the memory pipeline splits the ones that straddle a line — and
+    // the last K % 4 columns of a row with scalar loads.  (The first version read and wrote element by element: 2-byte stores, 0.38 ms
+    // for the 60 730 x 1737 degree features of the Facebook-like CTGCN-S window, as long as the GEMM behind it.)
+    auto load4 = [&](int k) -> f4v {
+        if (VEC) return *(const f4v *)(src + k);
+        if (k + 4 <= K) return *(const f4u *)(src + k);
+        f4v v = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = src[k + j];
+        return v;
+    };
+    if (held) {
 #pragma unroll
-            for (int i = 0; i < HOLD; ++i) {
-                const int k = lane * 4 + i * 256;
-                keep[i] = k < K ? *(const f4v *)(src + k) : f4v{0.f, 0.f, 0.f, 0.f};
-                m = fmaxf(m, fmaxf(fmaxf(fabsf(keep[i][0]), fabsf(keep[i][1])), fmaxf(fabsf(keep[i][2]), fabsf(keep[i][3]))));
-            }
-        } else {
-            for (int k = lane * 4; k < K; k += 256) {
-                const f4v v = *(const f4v *)(src + k);
-                m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-            }
+        for (int i = 0; i < HOLD; ++i) {
+            const int k = lane * 4 + i * 256;
+            keep[i] = k < K ? load4(k) : f4v{0.f, 0.f, 0.f, 0.f};
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(keep[i][0]), fabsf(keep[i][1])), fmaxf(fabsf(keep[i][2]), fabsf(keep[i][3]))));
         }
     } else {
-        for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(src[k]));
+        for (int k = lane * 4; k < K; k += 256) {
+            const f4v v = load4(k);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
     }
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     float s, inv;
     h2_scale(m, s, inv);
     if (lane == 0) scale[drow] = s;
-    _Float16 *d1 = p1 + drow * Kp, *d2 = p2 + drow * Kp;
-    if (VEC && held) {
+    _Float16 *d1 = p1 + drow * Kp, *d2 = p2 + drow * Kp;      // Kp is a multiple of 64: plane rows are 16-byte aligned whatever K is
+    if (held) {
 #pragma unroll
         for (int i = 0; i < HOLD; ++i) {
             const int k = lane * 4 + i * 256;
@@ -109,11 +117,11 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
                 *(h4v *)(d2 + k) = b;
             }
         }
-    } else if (VEC) {
+    } else {
         for (int k = lane * 4; k < Kp; k += 256) {
             h4v a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-            if (k < K) {                                  // K % 4 == 0: a float4 is entirely inside or outside
-                const f4v v = *(const f4v *)(src + k);    // second read: L2 / MALL hit
+            if (k < K) {
+                const f4v v = load4(k);                   // second read: L2 / MALL hit
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float xs = v[j] * inv;
@@ -123,17 +131,6 @@ __global__ __launch_bounds__(256) void split_rows_h2_kernel(int64_t rows, int32_
             }
             *(h4v *)(d1 + k) = a;
             *(h4v *)(d2 + k) = b;
-        }
-    } else {
-        for (int k = lane; k < Kp; k += 64) {
-            _Float16 a = 0, b = 0;
-            if (k < K) {
-                const float xs = src[k] * inv;
-                a = (_Float16)xs;
-                b = (_Float16)((xs - (float)a) * residual_scale);
-            }
-            d1[k] = a;
-            d2[k] = b;
         }
     }
 }
@@ -148,6 +145,7 @@ struct GemmArgs {
     int32_t N, Kp;
     const _Float16 *a1, *a2, *b1, *b2;       // planes [M, Kp] / [N, Kp]
     const float *sa, *sb, *bias;             // row scales, bias[N] or null
+    int32_t act;                             // 0: none, 1: SELU (layers.py:103-104 F.selu after each Linear of an 'N' MLP) applied to y
     float *y;
     int64_t ldy;
     int64_t mtiles;
@@ -163,6 +161,13 @@ struct GemmArgs {
 // each one and — not knowing which loads are still outstanding on which path — waits for vmcnt(0) before every store; stores
 // count in vmcnt on gfx9, so each waited for the previous one to complete: 64 serialised write round trips, 25 us of a
 // 46 us block life (per-block timeline with wall_clock64, 435 180 x 500 x 384).  Only edge tiles take the tested path.
+// torch's SELU: scale (max(0, x) + min(0, alpha (exp(x) - 1))) with expm1 (no cancellation near 0)
+__device__ __forceinline__ float gemm_act(float v, int act)
+{
+    if (act == 1) return v > 0.f ? 1.0507009873554804934193349852946f * v : (1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f) * expm1f(v);
+    return v;
+}
+
 template <int NI, int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const f16v (&acc)[NI][NJ], int64_t mrow0, int ncol0, int lane, bool full)
 {
@@ -186,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const f16v (&ac
             for (int v = 0; v < 16; ++v) {
                 float *row = yp + (int64_t)(i * 32 + 8 * (v / 4) + (v % 4)) * a.ldy;
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) row[j * 32] = fmaf(acc[i][j][v], sc[i][v] * sb[j], bs[j]);
+                for (int j = 0; j < NJ; ++j) row[j * 32] = gemm_act(fmaf(acc[i][j][v], sc[i][v] * sb[j], bs[j]), a.act);
             }
         return;
     }
@@ -200,7 +205,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const f16v (&ac
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int64_t m = mbase + i * 32 + 8 * (v / 4) + (v % 4);
-                if (m < a.M) a.y[m * a.ldy + n] = fmaf(acc[i][j][v], a.sa[m] * sb, bs);
+                if (m < a.M) a.y[m * a.ldy + n] = gemm_act(fmaf(acc[i][j][v], a.sa[m] * sb, bs), a.act);
             }
     }
 }
@@ -386,7 +391,7 @@ int ctgcn_split_rows_mapped_(int64_t rows, int32_t k, int32_t kp, const float *x
 }
 
 // x == nullptr: the A planes and scales are already in the workspace (ctgcn_core_aggregate_split_f32 wrote them)
-static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
+static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias, int32_t act,
                        float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (rows < 0 || n_out < 1 || k < 1 || (x && ldx < k) || ldw < k || ldy < n_out)
@@ -408,7 +413,7 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
     if (x) launch_split(rows, k, kp, x, ldx, a1, a2, sa, nullptr, 1, 1.f, st);
     launch_split(n_out, k, kp, w, ldw, b1, b2, sb, nullptr, 1, 1.f, st);
     GemmArgs g{};
-    g.M = rows; g.N = n_out; g.Kp = kp; g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.sa = sa; g.sb = sb; g.bias = bias; g.y = y; g.ldy = ldy;
+    g.M = rows; g.N = n_out; g.Kp = kp; g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.sa = sa; g.sb = sb; g.bias = bias; g.act = act; g.y = y; g.ldy = ldy;
     g.ntiles = (n_out + BN - 1) / BN;
     g.mtiles = (rows + 127) / 128;
     const int64_t blocks = (g.mtiles + 7) / 8 * 8 * g.ntiles;
@@ -440,16 +445,17 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
 }
 
 int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
-                     float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream)
+                     int32_t activation, float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (rows > 0 && !x) return ctgcn_set_error_(CTGCN_E_INVALID, "linear: null pointer");
-    return linear_impl(rows, n_out, k, x, ldx, w, ldw, bias, y, ldy, workspace, workspace_bytes, stream);
+    if (activation != CTGCN_ACT_NONE && activation != CTGCN_ACT_SELU) return ctgcn_set_error_(CTGCN_E_INVALID, "linear: unknown activation");
+    return linear_impl(rows, n_out, k, x, ldx, w, ldw, bias, activation, y, ldy, workspace, workspace_bytes, stream);
 }
 
 int ctgcn_linear_presplit_f32(int64_t rows, int32_t n_out, int32_t k, const float *w, int64_t ldw, const float *bias, float *y, int64_t ldy,
                               void *workspace, size_t workspace_bytes, void *stream)
 {
-    return linear_impl(rows, n_out, k, nullptr, 0, w, ldw, bias, y, ldy, workspace, workspace_bytes, stream);
+    return linear_impl(rows, n_out, k, nullptr, 0, w, ldw, bias, CTGCN_ACT_NONE, y, ldy, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -2185,6 +2185,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
 // for the whole tile, so h_{t-1} and the running sum stay in registers; the sum goes through the idle x slot for the final
 // LayerNorm.  Sum-over-steps form only.  Same arithmetic as the other two paths (bit-identical).
 // ------------------------------------------------------------------------------------------------
+#ifndef CTGCN_LAYER_LOOKAHEAD
+#define CTGCN_LAYER_LOOKAHEAD 1      // 0: A/B build without the early x products of gru_layer8_h2_kernel<presplit, sum>
+#endif
 constexpr int L8_WL = 12;
 constexpr int L8_PITCH = 128;                            // halfs per plane row, no padding
 // half index of element k of row r (r < 16): 16-byte segment k / 8 goes to segment (k / 8) ^ r
@@ -2363,6 +2366,127 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             }
         ln_last = -1;
     };
+#if CTGCN_LAYER_LOOKAHEAD && !defined(CTGCN_LAYER_TIMELINE)
+    if constexpr (DEDUP) {
+        // Inference form (planes + row plan).  The x·W_ih products of a unit do not depend on the recurrence, so they are issued one unit
+        // EARLY: at the end of the unit before, after h_t is published and in front of the barrier — where a wave that finishes its gate
+        // math first used to wait for the others (414 of 2 260 ns per unit for the older wave of a SIMD, profiles/r02_layer_timeline_summary.txt)
+        // it now multiplies.  After the barrier a unit starts with the h·W_hh products alone.  Same MFMAs in the same order per
+        // accumulator: bit-identical.  The x ring keeps its two slots: slot i % 2 is read here for fresh unit i and the other one, last
+        // read one barrier ago, takes the planes of fresh unit i + 1 right behind the MFMAs.
+        f4v acc0[3] = {zero4, zero4, zero4};
+        float rs_n = 0.f;
+        int xslot = 0;                                    // slot of the next unit that brings a new x
+        auto x_products = [&]() {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc0[g] = zero4;
+            rs_n = xscale[xslot][col];
+            h8v x1 = *(const h8v *)(&Xs[xslot][0][col][l8_off(col, 8 * grp)]);
+            h8v x2 = *(const h8v *)(&Xs[xslot][1][col][l8_off(col, 8 * grp)]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                h8v wr[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wr[g] = l8_lds_slot(1, c, g) >= 0 ? Wl[wave][l8_lds_slot(1, c, g) < 0 ? 0 : l8_lds_slot(1, c, g)][lane] : Wi[1][c][g];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                    acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x2, acc0[g], 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], x1, acc0[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                    acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x1, acc0[g], 0, 0, 0);
+                }
+                if (c < 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    x1 = *(const h8v *)(&Xs[xslot][0][col][l8_off(col, (c + 1) * 32 + 8 * grp)]);
+                    x2 = *(const h8v *)(&Xs[xslot][1][col][l8_off(col, (c + 1) * 32 + 8 * grp)]);
+                }
+            }
+            // the planes of the fresh unit after this one (in registers since the last call) go to the other slot; request the one after
+            if (ptile < ntiles) stage_x(xslot ^ 1, xr);
+            next_unit(ptile, pt);
+            load_x(ptile, pt, xr);
+            xslot ^= 1;
+        };
+        x_products();                                     // the block's first unit
+        int pb = 0, ln_buf = 0, ln_last = -1;
+        int64_t ln_row0 = 0;
+        auto pending_layernorm = [&]() {
+            if (ln_last < 0) return;
+            for (int r = wave * 2; r < wave * 2 + 2; ++r)
+                if (r <= ln_last) {
+                    const int64_t orow = a.order ? (int64_t)a.order[ln_row0 + r] : ln_row0 + r;
+                    gru_layernorm_row((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H, a.out + orow * a.ldo, lane, a.gamma, a.beta, a.eps);
+                }
+            ln_last = -1;
+        };
+        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int64_t row0 = tile * 16;
+            const int last = (int)min((int64_t)16, a.rows - row0) - 1;
+            f4v hprev = zero4, hsum = zero4;
+            const uint32_t tmask = tile_mask(tile);
+            f4v gi[3] = {zero4, zero4, zero4};
+            for (int t = 0; t < S; ++t) {
+                if (t == 0) pending_layernorm();          // the previous tile's rows (its last unit ended with a barrier)
+                if ((tmask >> t) & 1) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs_n) + *(const f4v *)(&bias_s[g][oc]);
+                }
+                f4v ach[3] = {zero4, zero4, zero4};
+                if (t > 0) {
+                    const int hp = pb ^ 1;                // the buffer step t-1 published into
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const h8v h1 = *(const h8v *)(&Hs[hp][0][col][l8_off(col, c * 32 + 8 * grp)]);
+                        const h8v h2 = *(const h8v *)(&Hs[hp][1][col][l8_off(col, c * 32 + 8 * grp)]);
+                        CTGCN_H2_MFMA1(Wh, c, h1, h2, ach)
+                    }
+                }
+                const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
+                const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
+                f4v h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], gi[0][j]));
+                    const float zv = gru_sigmoid(fmaf(ach[1][j], csc[1][j], gi[1][j]));
+                    const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
+                    const float nv = gru_tanh(fmaf(rv, an, gi[2][j]));
+                    h[j] = nv + zv * (hprev[j] - nv);
+                }
+                hprev = h;
+                hsum = t > 0 ? hsum + h : h;
+                if (t + 1 < S) {                          // fp16x2 planes of h·2^14 for the next step (the buffer nobody reads in this unit)
+                    h4v p, q;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        _Float16 x, y;
+                        h2_split<1>(h[j] * 16384.f, x, y);
+                        p[j] = x; q[j] = y;
+                    }
+                    *(h4v *)(&Hs[pb][0][col][l8_off(col, oc)]) = p;
+                    *(h4v *)(&Hs[pb][1][col][l8_off(col, oc)]) = q;
+                } else {                                  // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
+                    *(f4v *)((float *)&Hs[pb][0][0][0] + col * GRU_H + oc) = hsum;
+                    ln_buf = pb; ln_last = last; ln_row0 = row0;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // the next unit's x·W_ih, if it brings a new x (a repeat keeps gi): this tile's next step, or step 0 of the block's next tile
+                const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + gridDim.x < ntiles;
+                if (next_fresh) x_products();
+                __syncthreads();
+                pb ^= 1;
+            }
+        }
+        pending_layernorm();
+        return;
+    }
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * 16;
         const int last = (int)min((int64_t)16, a.rows - row0) - 1;

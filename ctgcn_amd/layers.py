@@ -137,23 +137,29 @@ class MLP(nn.Module):
             self.linears = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(widths[:-1], widths[1:]))
 
     @staticmethod
-    def _apply_linear(layer, h):
+    def _apply_linear(layer, h, selu=False):
+        """layer(h), followed by F.selu when asked (fused into the split GEMM's epilogue on that path)"""
+        out, fused = MLP._linear(layer, h, selu)
+        return F.selu(out) if (selu and not fused) else out
+
+    @staticmethod
+    def _linear(layer, h, selu):
+        """(layer(h), whether the activation was already applied)"""
         if h.is_sparse:          # one-hot / sparse features (helper.py:161-172)
             if _is_identity(h):  # Linear(I) = W^T + b: one pass over W instead of an N x N SpMM
                 if h.is_cuda and layer.weight.dtype == torch.float32 and not (torch.is_grad_enabled() and layer.weight.requires_grad):
-                    return ops.linear_of_identity(layer.weight, layer.bias)
-                return layer.weight.t() + layer.bias if layer.bias is not None else layer.weight.t().contiguous()
+                    return ops.linear_of_identity(layer.weight, layer.bias), False
+                return (layer.weight.t() + layer.bias if layer.bias is not None else layer.weight.t().contiguous()), False
             out = torch.sparse.mm(h, layer.weight.t())
-            return out if layer.bias is None else out + layer.bias
+            return (out if layer.bias is None else out + layer.bias), False
         needs_grad = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in layer.parameters()))
         if not needs_grad and h.dim() == 2 and ops.linear_split_ok(h, layer.weight):
-            return ops.linear_split(h, layer.weight, layer.bias)     # fp32-accurate split GEMM on the 16-bit matrix cores (inference)
-        return layer(h)
+            # fp32-accurate split GEMM on the 16-bit matrix cores (inference), SELU in its epilogue
+            return ops.linear_split(h, layer.weight, layer.bias, selu=selu), bool(selu)
+        return layer(h), False
 
     def forward(self, x):
         stack = [self.linear] if self.layer_num == 1 else list(self.linears)
         for layer in stack:
-            x = self._apply_linear(layer, x)
-            if self.activate_type == 'N':
-                x = F.selu(x)
+            x = self._apply_linear(layer, x, selu=self.activate_type == 'N')
         return x

@@ -313,8 +313,9 @@ def linear_split_ok(x2d, weight):
             and x2d.shape[0] > 0 and x2d.shape[1] >= 32 and x2d.stride(0) >= x2d.shape[1] and weight.stride(0) >= weight.shape[1])
 
 
-def linear_split(x2d, weight, bias, out=None):
-    """out[rows, n_out] = x2d @ weight^T + bias in fp32-accurate fp16x2 split arithmetic on the matrix cores (ctgcn_linear_f32)."""
+def linear_split(x2d, weight, bias, out=None, selu=False):
+    """out[rows, n_out] = x2d @ weight^T + bias in fp32-accurate fp16x2 split arithmetic on the matrix cores (ctgcn_linear_f32);
+    selu: F.selu applied in the GEMM's epilogue (one pass over the output less)."""
     lib = _lib.load()
     rows, k = x2d.shape
     n_out = weight.shape[0]
@@ -331,8 +332,8 @@ def linear_split(x2d, weight, bias, out=None):
             n = min(chunk, rows - lo)
             xs, ys = x2d[lo:lo + n], out[lo:lo + n]
             with _timed("linear_split", rows=n, k=k, n_out=n_out):
-                check(lib.ctgcn_linear_f32(n, n_out, k, ptr(xs), xs.stride(0), ptr(w), w.stride(0), ptr(b), ptr(ys), ys.stride(0), ptr(ws), ws_bytes,
-                                           _stream()), "ctgcn_linear_f32")
+                check(lib.ctgcn_linear_f32(n, n_out, k, ptr(xs), xs.stride(0), ptr(w), w.stride(0), ptr(b), _lib.ACT_SELU if selu else _lib.ACT_NONE,
+                                           ptr(ys), ys.stride(0), ptr(ws), ws_bytes, _stream()), "ctgcn_linear_f32")
     return out
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 15
+#define CTGCN_ABI_VERSION 16
 
 enum {
     CTGCN_OK = 0,
@@ -57,6 +57,8 @@ enum { /* `op` of ctgcn_workspace_bytes */
 #define CTGCN_SPLIT_NONE 0
 #define CTGCN_SPLIT_BF16X3 1
 #define CTGCN_SPLIT_F16X2 2
+#define CTGCN_ACT_NONE 0
+#define CTGCN_ACT_SELU 1     /* torch.nn.functional.selu, layers.py:103-104 */
 
 int ctgcn_abi_version(void);
 const char *ctgcn_last_error(void);
@@ -243,12 +245,13 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
  * matrix cores (CTGCN_SPLIT_F16X2: operand rows scaled by a power of two and written as two fp16 terms, three
  * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation) - the GRU input projection for d_in != 128 (layers.py:59 with
  * input_size = hid_dim = 500) and nn.Linear on dense inputs (layers.py:95-106), which otherwise run as fp32 library GEMMs.
- * ldx / ldw / ldy: row strides in floats.  Any k >= 1 (rows that are not 16-byte aligned or k % 4 != 0 are read with scalar loads).
+ * ldx / ldw / ldy: row strides in floats.  Any k >= 1 (rows that are only 4-byte aligned, e.g. k = 1737, are read with the same 16-byte
+ * loads).  activation: CTGCN_ACT_NONE, or CTGCN_ACT_SELU applied to y in the epilogue (the F.selu after each Linear of an 'N' MLP).
  * workspace: ctgcn_linear_workspace_bytes(rows, n_out, k) bytes, 256-byte aligned (the fp16 planes + row scales of x and w).
  */
 size_t ctgcn_linear_workspace_bytes(int64_t rows, int32_t n_out, int32_t k);
 int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
-                     float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
+                     int32_t activation, float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * CoreDiffusion aggregation (ctgcn_core_aggregate_f32: layers.py:41-48,58) whose only consumer is the GRU input projection of a

@@ -62,3 +62,27 @@ def test_gru_with_wide_input_uses_the_split_gemm_and_matches_torch():
         ops.set_launch_timer(None)
     assert "linear_split" in seen and "gru_seq" in seen
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,k,n_out", [(5000, 1737, 500), (777, 503, 130), (64, 33, 9)])
+def test_rows_that_are_only_4_byte_aligned_and_selu_epilogue(rows, k, n_out):
+    """k % 4 != 0: rows start at 4-byte aligned addresses and are read with 16-byte loads + a scalar tail — the result equals the GEMM
+    on a zero-padded, 16-byte aligned copy bit for bit (same planes).  activation = SELU in the epilogue equals F.selu of the plain
+    output (torch's selu uses expm1 as the kernel does) to a few ulp, and is the reference's Linear + SELU (layers.py:95-106)."""
+    from ctgcn_amd import ops
+    torch.manual_seed(k)
+    x = torch.randn(rows, k, device=DEV) * 3
+    w = torch.randn(n_out, k, device=DEV) / k ** 0.5
+    b = torch.randn(n_out, device=DEV)
+    kpad = -(-k // 4) * 4
+    xp = torch.zeros(rows, kpad + 4, device=DEV)[:, :kpad]          # 16-byte aligned rows, zero columns beyond k
+    wp = torch.zeros(n_out, kpad + 4, device=DEV)[:, :kpad]
+    xp[:, :k] = x
+    wp[:, :k] = w
+    assert x.stride(0) % 4 != 0 or k % 4 == 0
+    got = ops.linear_split(x, w, b)
+    assert torch.equal(got, ops.linear_split(xp, wp, b))
+    act = ops.linear_split(x, w, b, selu=True)
+    want = torch.nn.functional.selu(got)
+    assert torch.allclose(act, want, rtol=2e-6, atol=1e-7), float((act - want).abs().max())
+    assert bool((act[got > 0] > 0).all()) and bool((act[got < 0] < 0).all())

@@ -2372,46 +2372,57 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
         // EARLY: at the end of the unit before, after h_t is published and in front of the barrier — where a wave that finishes its gate
         // math first used to wait for the others (414 of 2 260 ns per unit for the older wave of a SIMD, profiles/r02_layer_timeline_summary.txt)
         // it now multiplies.  After the barrier a unit starts with the h·W_hh products alone.  Same MFMAs in the same order per
-        // accumulator: bit-identical.  The x ring keeps its two slots: slot i % 2 is read here for fresh unit i and the other one, last
+        // accumulator: bit-identical.  (Also slicing the gate math between the four k chunks of these products — transcendental chains in the
+        // MFMAs' shadow — keeps gi, the pre-activations and the new accumulators alive together: 23 scratch reloads inside the loop, 99 instead
+        // of 65 ms per window.  Removed.)  The x ring keeps its two slots: slot i % 2 is read here for fresh unit i and the other one, last
         // read one barrier ago, takes the planes of fresh unit i + 1 right behind the MFMAs.
         f4v acc0[3] = {zero4, zero4, zero4};
         float rs_n = 0.f;
         int xslot = 0;                                    // slot of the next unit that brings a new x
-        auto x_products = [&]() {
+        h8v xo1, xo2;                                     // x operand fragments of the running chunk
+        auto x_begin = [&]() {
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc0[g] = zero4;
             rs_n = xscale[xslot][col];
-            h8v x1 = *(const h8v *)(&Xs[xslot][0][col][l8_off(col, 8 * grp)]);
-            h8v x2 = *(const h8v *)(&Xs[xslot][1][col][l8_off(col, 8 * grp)]);
+            xo1 = *(const h8v *)(&Xs[xslot][0][col][l8_off(col, 8 * grp)]);
+            xo2 = *(const h8v *)(&Xs[xslot][1][col][l8_off(col, 8 * grp)]);
+        };
+        auto x_chunk = [&](auto ctag) {
+            constexpr int c = decltype(ctag)::value;
+            h8v wr[3];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                h8v wr[3];
+            for (int g = 0; g < 3; ++g) wr[g] = l8_lds_slot(1, c, g) >= 0 ? Wl[wave][l8_lds_slot(1, c, g) < 0 ? 0 : l8_lds_slot(1, c, g)][lane] : Wi[1][c][g];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < 3; ++g) wr[g] = l8_lds_slot(1, c, g) >= 0 ? Wl[wave][l8_lds_slot(1, c, g) < 0 ? 0 : l8_lds_slot(1, c, g)][lane] : Wi[1][c][g];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
-                    acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x2, acc0[g], 0, 0, 0);
-                }
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], x1, acc0[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
-                    acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x1, acc0[g], 0, 0, 0);
-                }
-                if (c < 3) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    x1 = *(const h8v *)(&Xs[xslot][0][col][l8_off(col, (c + 1) * 32 + 8 * grp)]);
-                    x2 = *(const h8v *)(&Xs[xslot][1][col][l8_off(col, (c + 1) * 32 + 8 * grp)]);
-                }
+            for (int g = 0; g < 3; ++g) {
+                const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xo2, acc0[g], 0, 0, 0);
             }
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], xo1, acc0[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xo1, acc0[g], 0, 0, 0);
+            }
+            if (c < 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                xo1 = *(const h8v *)(&Xs[xslot][0][col][l8_off(col, (c + 1) * 32 + 8 * grp)]);
+                xo2 = *(const h8v *)(&Xs[xslot][1][col][l8_off(col, (c + 1) * 32 + 8 * grp)]);
+            }
+        };
+        auto x_end = [&]() {
             // the planes of the fresh unit after this one (in registers since the last call) go to the other slot; request the one after
             if (ptile < ntiles) stage_x(xslot ^ 1, xr);
             next_unit(ptile, pt);
             load_x(ptile, pt, xr);
             xslot ^= 1;
+        };
+        auto x_products = [&]() {
+            x_begin();
+            x_chunk(std::integral_constant<int, 0>{}); x_chunk(std::integral_constant<int, 1>{});
+            x_chunk(std::integral_constant<int, 2>{}); x_chunk(std::integral_constant<int, 3>{});
+            x_end();
         };
         x_products();                                     // the block's first unit
         int pb = 0, ln_buf = 0, ln_last = -1;
@@ -2450,6 +2461,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 }
                 const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
                 const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
+                // the next unit's x·W_ih, if it brings a new x (a repeat keeps gi): this tile's next step, or step 0 of the block's next tile
+                const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + gridDim.x < ntiles;
                 f4v h;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -2476,8 +2489,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     ln_buf = pb; ln_last = last; ln_row0 = row0;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // the next unit's x·W_ih, if it brings a new x (a repeat keeps gi): this tile's next step, or step 0 of the block's next tile
-                const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + gridDim.x < ntiles;
                 if (next_fresh) x_products();
                 __syncthreads();
                 pb ^= 1;

@@ -17,9 +17,9 @@ def alg_bytes(n, nnz, K, d):
     return nnz * (4 * d + 9) + n * K * 4 * d + 4 * (n + 1)
 
 
-def split_aggregate(x, adj):
+def split_aggregate(x, adj, plan=None):
     from ctgcn_amd import ops
-    return ops.aggregate_split_planes(x, adj, 1)[0]
+    return ops.aggregate_split_planes(x, adj, 1, plan)[0]
 
 
 def main():
@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=1_000_000)
     ap.add_argument("--max-core", type=int, default=8)
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--plan", type=int, default=1, help="with --split: 1 (default) the graph's row plan, 0 every (node, core) row written")
     ap.add_argument("--split", action="store_true", help="ctgcn_core_aggregate_split_f32 (fp16 planes + row scales out) instead of the fp32 H")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -39,7 +40,8 @@ def main():
         rp, col, val = graphs[t]
         adj, core, files = CoreAdj.from_graph(rp, col, val, max_core=a.max_core)
         x = torch.randn(a.nodes, a.d, device=dev)
-        run = (lambda: split_aggregate(x, adj)) if a.split else (lambda: ops.core_aggregate(x, adj))
+        plan = adj.row_plan() if (a.split and a.plan) else None        # the inference path's row plan: repeated rows of H are not written
+        run = (lambda: split_aggregate(x, adj, plan)) if a.split else (lambda: ops.core_aggregate(x, adj))
         for _ in range(2):
             h = run()
         torch.cuda.synchronize()

@@ -901,6 +901,53 @@ __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src,
     *(float2 *)(dst + lane * 2) = gru_layernorm_vals(*(const float2 *)(src + lane * 2), lane, gamma, beta, eps);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the LayerNorm behind a GRU (layers.py:61-62 norm(output.sum(dim=1)), models.py:250 norm(output)): one wave per row of 128.
+//   x = sum over `steps` rows of h (steps = 1: the row itself), xhat = (x - mean) rstd, dxhat = dy gamma,
+//   dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat));  dgamma = sum_rows dy xhat;  dbeta = sum_rows dy.
+// The framework's LayerNorm backward on 128-wide rows (three kernels incl. a partial gamma/beta reduction) plus the sum over steps and the
+// forward recompute cost the config-5 training step 265 of 1 780 ms; this is one pass: steps x 512 B + 512 B read, 512 B written per row.
+// dgamma / dbeta leave as per-block partial sums [gridDim.x][256] (gamma | beta), added by the caller: deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int32_t steps, const float *__restrict__ h, const float *__restrict__ dy,
+                                                            const float *__restrict__ gamma, float eps, float *__restrict__ dx,
+                                                            float *__restrict__ partial)
+{
+    __shared__ float red[4][2 * GRU_H];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float2 g = *(const float2 *)(gamma + lane * 2);
+    float2 dg = {0.f, 0.f}, db = {0.f, 0.f};
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float *src = h + row * steps * GRU_H + lane * 2;
+        float2 x = *(const float2 *)src;
+        for (int t = 1; t < steps; ++t) {
+            const float2 v = *(const float2 *)(src + (int64_t)t * GRU_H);
+            x.x += v.x; x.y += v.y;
+        }
+        const float2 d = *(const float2 *)(dy + row * GRU_H + lane * 2);
+        float s = x.x + x.y;
+        for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / GRU_H);
+        const float cx = x.x - mean, cy = x.y - mean;
+        float q = cx * cx + cy * cy;
+        for (int o = 32; o; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * (1.0f / GRU_H) + eps);
+        const float hx = cx * rstd, hy = cy * rstd;
+        const float ex = d.x * g.x, ey = d.y * g.y;                 // dxhat
+        float m1 = ex + ey, m2 = ex * hx + ey * hy;
+        for (int o = 32; o; o >>= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+        m1 *= (1.0f / GRU_H); m2 *= (1.0f / GRU_H);
+        *(float2 *)(dx + row * GRU_H + lane * 2) = float2{rstd * (ex - m1 - hx * m2), rstd * (ey - m1 - hy * m2)};
+        dg.x += d.x * hx; dg.y += d.y * hy;
+        db.x += d.x; db.y += d.y;
+    }
+    *(float2 *)(&red[wave][lane * 2]) = dg;
+    *(float2 *)(&red[wave][GRU_H + lane * 2]) = db;
+    __syncthreads();
+    const int c = threadIdx.x;                                      // 256 threads = 256 partial columns
+    partial[(int64_t)blockIdx.x * (2 * GRU_H) + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
 template <bool REDUCE, bool SAVE>
 __global__ __launch_bounds__(512, 2) void gru_seq_kernel(const GruArgs a)
 {
@@ -1906,6 +1953,7 @@ struct LayerArgs {
     // the x·W_ih products of step t-1 are kept, the step costs the h·W_hh half only.  Bit 0 is always set; steps <= 32.
     const int32_t *order;
     const uint32_t *tmask;
+    float *gates;                // SAVE (per-step form without LayerNorm): [rows, steps, 4, 128] r, z, n, q = W_hn h + b_hn for ctgcn_gru_seq_bwd_f32
 #ifdef CTGCN_LAYER_TIMELINE
     unsigned long long *timeline;   // diagnostic build: per (block, wave) sums of the unit phases, see tools/layer_timeline.py
 #endif
@@ -2194,7 +2242,7 @@ constexpr int L8_PITCH = 128;                            // halfs per plane row,
 __device__ __forceinline__ int l8_off(int r, int k) { return ((((k >> 3) ^ r) & 15) << 3) | (k & 7); }
 __device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : -1; }
 
-template <bool PRESPLIT, bool REDUCE>
+template <bool PRESPLIT, bool REDUCE, bool SAVE = false>
 __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
 {
     // x and h planes: 16 rows of 128 halfs, unpadded; the 16-byte segment q of row r is stored at segment q ^ r (l8_off).  Every access
@@ -2580,7 +2628,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             TL_MARK(0)
             const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
             const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
-            f4v h;
+            f4v h, rv4, zv4, nv4, an4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], gi[0][j]));
@@ -2588,6 +2636,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
                 const float nv = gru_tanh(fmaf(rv, an, gi[2][j]));
                 h[j] = nv + zv * (hprev[j] - nv);
+                if (SAVE) { rv4[j] = rv; zv4[j] = zv; nv4[j] = nv; an4[j] = an; }
+            }
+            if (SAVE && col <= last) {                    // the gates of this step for the backward recurrence (training: recompute pass)
+                float *gp = a.gates + ((row0 + col) * S + t) * (4 * GRU_H) + oc;
+                *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
             }
             hprev = h;
             if (REDUCE) hsum = t > 0 ? hsum + h : h;
@@ -3707,11 +3760,28 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     return CTGCN_OK;
 }
 
+int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *h, const float *dy, const float *gamma, float eps,
+                            float *dx, float *partial, int32_t n_partial, void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "layernorm_bwd: hidden=%d, only %d is built", hidden, GRU_H);
+    if (rows < 0 || steps < 1 || n_partial < 1 || n_partial > 65535) return fail(CTGCN_E_INVALID, "layernorm_bwd: bad sizes rows=%lld steps=%d n_partial=%d", (long long)rows, steps, n_partial);
+    if (!partial) return fail(CTGCN_E_INVALID, "layernorm_bwd: null pointer");
+    if (rows == 0) { HIP_TRY(hipMemsetAsync(partial, 0, (size_t)n_partial * 2 * GRU_H * sizeof(float), (hipStream_t)stream)); return CTGCN_OK; }
+    if (!h || !dy || !gamma || !dx) return fail(CTGCN_E_INVALID, "layernorm_bwd: null pointer");
+    if ((reinterpret_cast<uintptr_t>(h) & 7u) || (reinterpret_cast<uintptr_t>(dy) & 7u) || (reinterpret_cast<uintptr_t>(dx) & 7u) || (reinterpret_cast<uintptr_t>(gamma) & 7u))
+        return fail(CTGCN_E_INVALID, "layernorm_bwd: h / dy / dx / gamma must be 8-byte aligned");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, rows, steps, h, dy, gamma, eps, dx, partial);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
 int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
                         const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
-                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, void *stream)
+                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, float *gates_out, void *stream)
 {
     if (hidden != GRU_H || d_in != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer: only d_in = hidden = %d is built (got %d, %d)", GRU_H, d_in, hidden);
+    if (gates_out && (reduce_sum || ln_weight)) return fail(CTGCN_E_INVALID, "gru_layer: gates_out needs reduce_sum == 0 and no LayerNorm (raw h sequence)");
+    if (gates_out && !aligned16(gates_out)) return fail(CTGCN_E_INVALID, "gru_layer: gates_out must be 16-byte aligned");
     if (rows < 0 || steps < 1 || ldx < d_in) return fail(CTGCN_E_INVALID, "gru_layer: bad sizes rows=%lld steps=%d ldx=%lld", (long long)rows, steps, (long long)ldx);
     if (rows == 0) return CTGCN_OK;
     if (!x || !w_ih || !w_hh || !out) return fail(CTGCN_E_INVALID, "gru_layer: null pointer");
@@ -3729,7 +3799,17 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 4-wave block per CU (one wave per SIMD, 512 registers)
     LayerArgs a{};
     a.rows = rows; a.steps = steps; a.x = x; a.ldx = ldx; a.wih = w_ih; a.whh = w_hh; a.bias_gi = bias_gi; a.bhn = b_hn;
-    a.gamma = ln_weight; a.beta = ln_bias; a.eps = ln_eps; a.out = out; a.ldo = ldo;
+    a.gamma = ln_weight; a.beta = ln_bias; a.eps = ln_eps; a.out = out; a.ldo = ldo; a.gates = gates_out;
+    if (gates_out) {
+        // training's recompute pass: raw h sequence + gates straight from the layer kernel (the kernel pair wrote and re-read gi for this)
+        const int64_t nt8 = (rows + 15) / 16;
+#ifdef CTGCN_LAYER_TIMELINE
+        a.timeline = nullptr;
+#endif
+        hipLaunchKernelGGL((gru_layer8_h2_kernel<false, false, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+        HIP_TRY(hipGetLastError());
+        return CTGCN_OK;
+    }
     // sum-over-steps form: the 8-wave kernel (4.6 ms per 1M x 8 call; 5.2 for the 4-wave one, 6.4 for the kernel pair); CTGCN_GRU_LAYER_WAVES=4 forces the latter
     static const int nw = [] { const char *e = getenv("CTGCN_GRU_LAYER_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
     if (nw == 8 && reduce_sum) {

@@ -406,7 +406,7 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
         # projection + recurrence in one kernel, both weight matrices in the register file, gi never materialised
         with torch.cuda.device(seq.device), _timed("gru_layer", rows=rows, steps=steps, reduce_sum=bool(reduce_sum)):
             check(lib.ctgcn_gru_layer_f32(rows, steps, d_in, hid, ptr(seq), seq.stride(1), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn),
-                                          ptr(ln_w), ptr(ln_b), eps, 1 if reduce_sum else 0, ptr(out), ldo, _stream()), "ctgcn_gru_layer_f32")
+                                          ptr(ln_w), ptr(ln_b), eps, 1 if reduce_sum else 0, ptr(out), ldo, None, _stream()), "ctgcn_gru_layer_f32")
         return out
     chunks = _row_chunks(lib, rows, steps, hid)
     gi_buf = _gi_buffer(chunks[0][1], steps, hid, seq.device)
@@ -592,6 +592,7 @@ class _GruSeq(torch.autograd.Function):
         bias_part = torch.empty(512, 4 * hid, dtype=torch.float32, device=dev)
         dln_w = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
         dln_b = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
+        ln_part = torch.empty(2048, 2 * hid, dtype=torch.float32, device=dev) if ln_w is not None else None
         chunks = _row_chunks(lib, rows, steps, hid)
         cmax = chunks[0][1]
         gi_flat = _gi_buffer(cmax, steps, hid, dev)                                          # reused as d_gi
@@ -609,20 +610,29 @@ class _GruSeq(torch.autograd.Function):
                 x2d = seq[lo:lo + n].reshape(n * steps, d_in)
                 gates, hseq = gates_buf[: n * steps], hseq_buf[:n]
                 gi = gi_flat[: n * steps * 3 * hid].view(n * steps, 3 * hid)                 # the [rows, 3h] view (d_gi later)
-                blocked = _project(x2d, w_ih_d, bias, gi_flat, steps_blocked=steps)
-                check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_flat), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq), 0,
-                                            ptr(gates), forward_split_mode(), 1 if blocked else 0, None, None, None, _stream()), "ctgcn_gru_seq_f32")
+                xs = seq[lo:lo + n]
+                if forward_split_mode() == 2 and d_in == hid and layer_kernel_enabled(False) and xs.stride(2) == 1 and xs.stride(1) % 4 == 0 \
+                        and xs.stride(0) == steps * xs.stride(1) and xs.data_ptr() % 16 == 0 and w_ih_d.is_contiguous():
+                    # recompute in the layer kernel: raw h sequence + gates, the projection consumed from the accumulators (bit-identical
+                    # to the pair below, without writing and re-reading gi)
+                    with _timed("gru_layer", rows=n, steps=steps, reduce_sum=False, save=True):
+                        check(lib.ctgcn_gru_layer_f32(n, steps, d_in, hid, ptr(xs), xs.stride(1), ptr(w_ih_d), ptr(w_hh_d), ptr(bias), ptr(b_hn), None, None,
+                                                      0.0, 0, ptr(hseq), 0, ptr(gates), _stream()), "ctgcn_gru_layer_f32")
+                else:
+                    blocked = _project(x2d, w_ih_d, bias, gi_flat, steps_blocked=steps)
+                    check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_flat), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq), 0,
+                                                ptr(gates), forward_split_mode(), 1 if blocked else 0, None, None, None, _stream()), "ctgcn_gru_seq_f32")
                 # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)
                 g_out = dout[lo:lo + n]
-                pre = hseq.sum(1) if reduce_sum else hseq
                 if ln_w is not None:
-                    with torch.enable_grad():
-                        p = pre.detach().requires_grad_(True)
-                        lw, lb = ln_w.detach().requires_grad_(True), ln_b.detach().requires_grad_(True)
-                        torch.nn.functional.layer_norm(p, (hid,), lw, lb, eps).backward(g_out)
-                    dpre = p.grad
-                    dln_w += lw.grad
-                    dln_b += lb.grad
+                    # one HIP pass: sum over steps (reduce_sum), mean / rstd recomputed, dpre, per-block partials of d gamma / d beta
+                    ln_rows = n if reduce_sum else n * steps
+                    dpre = torch.empty((n, hid) if reduce_sum else (n, steps, hid), dtype=torch.float32, device=dev)
+                    check(lib.ctgcn_layernorm_bwd_f32(ln_rows, steps if reduce_sum else 1, hid, ptr(hseq), ptr(g_out), ptr(ln_w.detach()), eps,
+                                                      ptr(dpre), ptr(ln_part), ln_part.shape[0], _stream()), "ctgcn_layernorm_bwd_f32")
+                    ln_sum = ln_part.sum(0)
+                    dln_w += ln_sum[:hid]
+                    dln_b += ln_sum[hid:]
                 else:
                     dpre = g_out
                 dpre = dpre.contiguous()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 16
+#define CTGCN_ABI_VERSION 18
 
 enum {
     CTGCN_OK = 0,
@@ -203,6 +203,15 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
                       const int32_t *row_order, const uint32_t *tile_mask, const int32_t *tile_base, void *stream);
 
 /*
+ * Backward of the LayerNorm(128) behind the GRU (layers.py:61-62 norm(output.sum(dim=1)); models.py:250 norm(output)):
+ *   x[r] = sum_{t < steps} h[r, t, :]  (steps = 1: h is [rows, 128]);  dx = dL/dx given dy = dL/dLayerNorm(x) (the mean / rstd are recomputed),
+ *   partial [n_partial, 256]: per-block partial sums of (dgamma | dbeta), every row written; the caller adds them up (deterministic).
+ * One pass instead of the framework's three kernels + sum + forward recompute.  n_partial = number of blocks (<= 65535, e.g. 2048).
+ */
+int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *h, const float *dy, const float *gamma, float eps,
+                            float *dx, float *partial, int32_t n_partial, void *stream);
+
+/*
  * The same for nn.LSTM (rnn_type = 'LSTM'; layers.py:27-28, models.py:234-235): gi [rows, steps, 512] = x·W_ih^T + b_ih
  * + b_hh in PyTorch's gate order i,f,g,o; w_hh [512, 128]; h_0 = c_0 = 0.  Exact fp32 (f32-input MFMA).
  * Inference only (no backward entry point: training goes through the framework's LSTM).
@@ -220,10 +229,12 @@ int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float 
  * ln_weight / ln_bias NULL: no LayerNorm.  bias_gi [384] = b_ih (+ b_hh for the r and z gates), b_hn [128] = bias_hh_l0[256:384];
  * either may be NULL.  CTGCN_SPLIT_F16X2 arithmetic, operation for operation that of ctgcn_gru_input_proj_f32 followed by
  * ctgcn_gru_seq_f32: results are bit-identical to the kernel pair.  HBM traffic: x in + out (the pair: 7x that).
+ * gates_out (optional; reduce_sum == 0, no LayerNorm): [rows, steps, 4, 128] as ctgcn_gru_seq_f32 writes them - the recompute pass of
+ * training without the gi round trip.
  */
 int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
                         const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
-                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, void *stream);
+                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, float *gates_out, void *stream);
 
 /*
  * ctgcn_gru_layer_f32 (sum-over-steps form) on an input that ctgcn_core_aggregate_split_f32 already wrote as fp16 planes + row scales

@@ -128,3 +128,21 @@ def run_cgcn(rank, world, port, T, n, results):
         results[rank] = (err_fwd, err_bwd, assignment)
     finally:
         dist.destroy_process_group()
+
+
+def run_shared_seed(rank, world, port, results):
+    """snapshot_parallel.share_loss_seed: every rank ends up with rank 0's entropy-drawn stream base (and a reset call counter)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ctgcn_amd import snapshot_parallel as spp
+
+        class Loss(object):
+            seed = None
+            shared_base = None
+            _shared_calls = 7
+        loss = Loss()
+        base = spp.share_loss_seed(loss)
+        results[rank] = (base, loss.shared_base, loss._shared_calls)
+    finally:
+        dist.destroy_process_group()

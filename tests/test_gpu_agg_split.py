@@ -221,6 +221,10 @@ def test_row_plan_with_hub_rows_general_lists_and_k1(monkeypatch):
         mats = [sp.random(900, 900, density=0.002 * (1 + j % 2), random_state=j, format="csr", dtype=np.float32) for j in range(5)]
         cases.append(CoreAdj.from_matrices(mats, device=_dev(), self_loop=False))
         cases.append(CoreAdj.from_matrices([mats[0]], device=_dev(), self_loop=True))
+        many = CoreAdj.from_matrices([sp.random(300, 300, density=0.01, random_state=100 + j, format="csr", dtype=np.float32) for j in range(40)],
+                                     device=_dev(), self_loop=False)
+        assert many.K == 40 and many.row_plan() is None          # masks are 32 bits wide: longer lists run without a plan
+        cases.append(many)
         for a in cases:
             for d in (128, 500, 64):          # 128: GRU layer kernel on planes with holes; others: split GEMM on compact operand rows
                 layer = _layer(d, 2)

@@ -287,3 +287,27 @@ def test_register_resident_layer_kernel_equals_the_kernel_pair(rows, steps, redu
                 buf = torch.zeros(rows, 3, 128, device=DEV)
                 ops.gru_sequence(rnn, x, norm, True, out=buf[:, 1])
                 assert torch.equal(buf[:, 1], want) and not buf[:, 0].any() and not buf[:, 2].any()
+
+
+@pytest.mark.parametrize("rows,steps", [(1, 1), (1003, 1), (777, 5), (70001, 8)])
+def test_layernorm_backward_kernel_matches_autograd(rows, steps):
+    """ctgcn_layernorm_bwd_f32: d/dx and d/d(gamma, beta) of LayerNorm(sum_t h[:, t]) — against float64 autograd of the same expression."""
+    from ctgcn_amd import _lib
+    from ctgcn_amd._lib import check, ptr
+    lib = _lib.load()
+    torch.manual_seed(rows + steps)
+    dev = torch.device("cuda:0")
+    h = torch.randn(rows, steps, 128, device=dev) * 0.7
+    dy = torch.randn(rows, 128, device=dev)
+    gamma = torch.randn(128, device=dev)
+    dx = torch.empty(rows, 128, device=dev)
+    part = torch.empty(300, 256, device=dev)
+    check(lib.ctgcn_layernorm_bwd_f32(rows, steps, 128, ptr(h), ptr(dy), ptr(gamma), 1e-5, ptr(dx), ptr(part), part.shape[0],
+                                      torch.cuda.current_stream().cuda_stream), "ctgcn_layernorm_bwd_f32")
+    x64 = h.double().sum(1).requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), torch.zeros(128, dtype=torch.float64, device=dev, requires_grad=True)
+    torch.nn.functional.layer_norm(x64, (128,), g64, b64, 1e-5).backward(dy.double())
+    sums = part.double().sum(0)
+    assert (dx.double() - x64.grad).abs().max().item() <= 2e-5 * x64.grad.abs().max().item() + 1e-6
+    assert (sums[:128] - g64.grad).abs().max().item() <= 1e-5 * g64.grad.abs().max().item() + 1e-5
+    assert (sums[128:] - b64.grad).abs().max().item() <= 1e-5 * b64.grad.abs().max().item() + 1e-5

@@ -56,3 +56,13 @@ def test_sharded_cgcn_is_data_parallel():
         err_fwd, err_bwd, assignment = results[rank]
         assert err_fwd < 1e-5 and err_bwd < 1e-4, (rank, err_fwd, err_bwd)
         assert sorted(sum(assignment, [])) == list(range(5))
+
+
+def test_share_loss_seed_gives_every_rank_the_same_stream():
+    from _dist_worker import run_shared_seed
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(run_shared_seed, args=(3, _free_port(), results), nprocs=3, join=True)
+    bases = {results[r][0] for r in range(3)}
+    assert len(bases) == 1 and all(results[r][1] == results[r][0] and results[r][2] == 0 for r in range(3))
+    assert next(iter(bases)) > 0

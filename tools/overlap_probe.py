@@ -27,24 +27,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--agg-cus", type=int, default=32)
     ap.add_argument("--iters", type=int, default=6)
+    ap.add_argument("--snapshot", type=int, default=15)
+    ap.add_argument("--dedup", type=int, default=1, help="1: both kernels under the graph's row plan (the inference path), 0: every row of H")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     lib = _lib.load()
     hip = ctypes.CDLL("libamdhip64.so")
     n = 1_000_000
-    rp, col, val = dynamic_graph_device(n, 16, 16, dev, which=[15])[15]
+    rp, col, val = dynamic_graph_device(n, 16, 16, dev, which=[a.snapshot])[a.snapshot]
     adj, _, _ = CoreAdj.from_graph(rp, col, val, max_core=8)
     x = torch.randn(n, 128, device=dev)
     rnn = torch.nn.GRU(128, 128, 1, batch_first=True).to(dev)
     norm = torch.nn.LayerNorm(128).to(dev)
     out = torch.empty(n, 128, device=dev)
 
+    plan = adj.row_plan() if a.dedup else None
+
     def agg():
-        return ops.aggregate_split_planes(x, adj, 1)[0]
+        return ops.aggregate_split_planes(x, adj, 1, plan)[0]
 
     def layer(ws):
-        ops.gru_layer_presplit(ws, n, adj.K, rnn, norm, out)
+        ops.gru_layer_presplit(ws, n, adj.K, rnn, norm, out, plan)
 
     def timeit(fn, iters):
         fn()

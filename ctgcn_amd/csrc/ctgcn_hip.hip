@@ -2696,7 +2696,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
 constexpr int LSTM_BM = 32;
 constexpr int LSTM_RT = LSTM_BM / 16;
 
-template <bool REDUCE>
+template <bool REDUCE, bool SAVE = false>
 __global__ __launch_bounds__(512, 2) void lstm_seq_kernel(const GruArgs a)
 {
     __shared__ float hbuf[2][LSTM_BM][GRU_PITCH];
@@ -2768,6 +2768,10 @@ __global__ __launch_bounds__(512, 2) void lstm_seq_kernel(const GruArgs a)
                     creg[rt][i] = c;
                     hsum[rt][i] += h;
                     hcur[rt * 16 + grp * 4 + i][hid] = h;
+                    if (SAVE && rt * 16 + grp * 4 + i <= last) {       // training (recompute pass): i, f, g, o, c of this step for lstm_seq_bwd_kernel
+                        float *gp = a.gates + ((row0 + rt * 16 + grp * 4 + i) * steps + t) * (5 * GRU_H) + hid;
+                        gp[0] = ig; gp[GRU_H] = fg; gp[2 * GRU_H] = gg; gp[3 * GRU_H] = og; gp[4 * GRU_H] = c;
+                    }
                 }
             }
             __syncthreads();
@@ -2786,6 +2790,127 @@ __global__ __launch_bounds__(512, 2) void lstm_seq_kernel(const GruArgs a)
                 gru_layernorm_row(sbuf[r], a.out + (row0 + r) * a.ldo, lane, a.gamma, a.beta, a.eps);
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the LSTM recurrence (what autograd derives for nn.LSTM, rnn_type = 'LSTM': layers.py:27-28 / models.py:234-235).
+// Walks t = steps-1 .. 0 with dh = dh_seq[t] (or the broadcast dh_sum) + the recurrent term, dc carried in registers:
+//   tc = tanh(c_t); do = dh tc; dc += dh o (1 - tc²); di = dc g; df = dc c_{t-1}; dg = dc i; dc_{t-1} = dc f
+//   dGI[t] = (di i(1-i), df f(1-f), dg (1-g²), do o(1-o))      dh_{t-1} = dGI[t]·W_hh
+// Same shape as gru_seq_bwd_kernel, exact fp32 (v_mfma_f32_16x16x4_f32): wave w owns hidden units [16w,16w+16) of dh and keeps
+// W_hh[:, 16w..] (512 x 16) in 128 VGPRs as MFMA B operands; the block's dGI rows go through LDS (double buffered) as A operands.
+// d x and the weight gradients are plain GEMMs over the materialised dGI and stay with the caller's BLAS.
+// ------------------------------------------------------------------------------------------------
+constexpr int LSTMB_BM = 32;
+constexpr int LSTMB_RT = LSTMB_BM / 16;
+constexpr int LSTMB_PITCH = 4 * GRU_H + 4;
+
+struct LstmBwdArgs {
+    int64_t rows;
+    int32_t steps;
+    const float *gates;    // [rows, steps, 5, 128]: i, f, g, o, c
+    const float *dh_seq;   // [rows, steps, 128] or null
+    const float *dh_sum;   // [rows, 128] added at every step, or null
+    const float *whh;      // [512, 128]
+    float *dgi;            // [rows, steps, 512]
+    float *bias_partial;   // [gridDim.x, 512] per-block column sums of d_gi, or null
+};
+
+__global__ __launch_bounds__(512, 2) void lstm_seq_bwd_kernel(const LstmBwdArgs a)
+{
+    __shared__ float gbuf[2][LSTMB_BM][LSTMB_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 15, grp = lane >> 4;
+    const int hid = wave * 16 + col;
+    const int steps = a.steps;
+
+    // B operands: dh_prev[:, hid] = sum_k dGI[:, k] W_hh[k][hid];  k = g*128 + 32*grp + kk
+    float W[4][32];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) W[g][kk] = a.whh[(int64_t)(g * GRU_H + 32 * grp + kk) * GRU_H + hid];
+
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t ntiles = (a.rows + LSTMB_BM - 1) / LSTMB_BM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * LSTMB_BM;
+        const int last = (int)min((int64_t)LSTMB_BM, a.rows - row0) - 1;
+        float drec[LSTMB_RT][4], dcar[LSTMB_RT][4];
+#pragma unroll
+        for (int rt = 0; rt < LSTMB_RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { drec[rt][i] = 0.f; dcar[rt][i] = 0.f; }
+
+        for (int t = steps - 1; t >= 0; --t) {
+            float(*gcur)[LSTMB_PITCH] = gbuf[t & 1];
+#pragma unroll
+            for (int rt = 0; rt < LSTMB_RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r_ = rt * 16 + grp * 4 + i;
+                    const int64_t row = row0 + min(r_, last);
+                    const float *gp = a.gates + (row * steps + t) * (5 * GRU_H) + hid;
+                    const float ig = gp[0], fg = gp[GRU_H], gg = gp[2 * GRU_H], og = gp[3 * GRU_H], c = gp[4 * GRU_H];
+                    const float cprev = t > 0 ? gp[4 * GRU_H - 5 * GRU_H] : 0.f;       // c of step t-1: one step back in the same row
+                    float dh = drec[rt][i];
+                    if (a.dh_seq) dh += a.dh_seq[(row * steps + t) * GRU_H + hid];
+                    if (a.dh_sum) dh += a.dh_sum[row * GRU_H + hid];
+                    const float tc = gru_tanh(c);
+                    const float dc = dcar[rt][i] + dh * og * (1.f - tc * tc);
+                    const float dai = dc * gg * ig * (1.f - ig);
+                    const float daf = dc * cprev * fg * (1.f - fg);
+                    const float dag = dc * ig * (1.f - gg * gg);
+                    const float dao = dh * tc * og * (1.f - og);
+                    dcar[rt][i] = dc * fg;
+                    drec[rt][i] = 0.f;                           // no direct h path in an LSTM: the W_hh term is added after the MFMAs
+                    gcur[r_][hid] = dai;
+                    gcur[r_][GRU_H + hid] = daf;
+                    gcur[r_][2 * GRU_H + hid] = dag;
+                    gcur[r_][3 * GRU_H + hid] = dao;
+                    if (r_ <= last) {
+                        float *o = a.dgi + (row * steps + t) * (4 * GRU_H) + hid;
+                        o[0] = dai; o[GRU_H] = daf; o[2 * GRU_H] = dag; o[3 * GRU_H] = dao;
+                        bsum[0] += dai; bsum[1] += daf; bsum[2] += dag; bsum[3] += dao;
+                    }
+                }
+            if (t == 0) break;                                   // h_{-1} is the constant 0: nothing to propagate
+            __syncthreads();
+#pragma unroll
+            for (int rt = 0; rt < LSTMB_RT; ++rt) {
+                f4v acc0 = f4v{0.f, 0.f, 0.f, 0.f}, acc1 = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float av[32];
+                    const f4v *src = (const f4v *)(&gcur[rt * 16 + col][g * GRU_H + 32 * grp]);
+#pragma unroll
+                    for (int qd = 0; qd < 8; ++qd) {
+                        const f4v v = src[qd];
+                        av[4 * qd + 0] = v.x; av[4 * qd + 1] = v.y; av[4 * qd + 2] = v.z; av[4 * qd + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 32; kk += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], W[g][kk], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk + 1], W[g][kk + 1], acc1, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) drec[rt][i] = acc0[i] + acc1[i];
+            }
+        }
+        __syncthreads();       // LDS is reused by the next tile
+    }
+    if (a.bias_partial) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bsum[i] += __shfl_xor(bsum[i], 16);
+            bsum[i] += __shfl_xor(bsum[i], 32);
+        }
+        if (grp == 0) {
+            float *o = a.bias_partial + (int64_t)blockIdx.x * (4 * GRU_H) + hid;
+            o[0] = bsum[0]; o[GRU_H] = bsum[1]; o[2 * GRU_H] = bsum[2]; o[3 * GRU_H] = bsum[3];
+        }
     }
 }
 
@@ -3984,8 +4109,9 @@ int ctgcn_gru_weight_grad_f32(int64_t rows, int32_t steps, int32_t hidden, const
 
 int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                        const float *ln_weight, const float *ln_bias, float ln_eps, int reduce_sum, float *out,
-                       void *stream)
+                       float *gates_out, void *stream)
 {
+    if (gates_out && (reduce_sum || ln_weight)) return fail(CTGCN_E_INVALID, "lstm_seq: gates_out needs reduce_sum == 0 and no LayerNorm (raw h sequence)");
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "lstm_seq: hidden=%d, only %d is built", hidden, GRU_H);
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "lstm_seq: bad sizes");
     if (rows == 0) return CTGCN_OK;
@@ -3993,17 +4119,47 @@ int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float 
     if (!aligned16(w_hh) || (reinterpret_cast<uintptr_t>(out) & 7u)) return fail(CTGCN_E_INVALID, "lstm_seq: w_hh must be 16-byte aligned, out 8-byte aligned");
     GruArgs a{};
     a.rows = rows; a.steps = steps; a.gi = gi; a.whh = w_hh; a.bhn = nullptr; a.gamma = ln_weight; a.beta = ln_bias;
-    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = nullptr; a.ldo = GRU_H;
+    a.eps = ln_eps; a.reduce_sum = reduce_sum ? 1 : 0; a.out = out; a.gates = gates_out; a.ldo = GRU_H;
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     cus = persistent_cus(cus);
     const int64_t ntiles = (rows + LSTM_BM - 1) / LSTM_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;
-    if (a.reduce_sum)
+    if (gates_out)
+        hipLaunchKernelGGL((lstm_seq_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (a.reduce_sum)
         hipLaunchKernelGGL(lstm_seq_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(lstm_seq_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_lstm_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *dh_seq, const float *dh_sum,
+                           const float *w_hh, float *d_gi, float *bias_partial, int32_t n_partial, void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "lstm_seq_bwd: hidden=%d, only %d is built", hidden, GRU_H);
+    if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "lstm_seq_bwd: bad sizes");
+    if (rows == 0) return CTGCN_OK;
+    if (!gates || !w_hh || !d_gi || (!dh_seq && !dh_sum)) return fail(CTGCN_E_INVALID, "lstm_seq_bwd: null pointer");
+    if (bias_partial && n_partial < 1) return fail(CTGCN_E_INVALID, "lstm_seq_bwd: n_partial must be >= 1");
+    LstmBwdArgs a{};
+    a.rows = rows; a.steps = steps; a.gates = gates; a.dh_seq = dh_seq; a.dh_sum = dh_sum; a.whh = w_hh; a.dgi = d_gi; a.bias_partial = nullptr;
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
+    const int64_t ntiles = (rows + LSTMB_BM - 1) / LSTMB_BM;
+    int64_t blocks = ntiles < cus ? ntiles : cus;
+    if (bias_partial) {
+        if (blocks > n_partial) blocks = n_partial;
+        a.bias_partial = bias_partial;                            // rows >= blocks of the table stay zero
+        HIP_TRY(hipMemsetAsync(bias_partial, 0, (size_t)n_partial * 4 * GRU_H * sizeof(float), (hipStream_t)stream));
+    }
+    const size_t lds = sizeof(float) * 2 * LSTMB_BM * LSTMB_PITCH;
+    (void)lds;
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -667,29 +667,21 @@ class _GruSeq(torch.autograd.Function):
 
 
 def lstm_fused_ok(rnn, seq):
-    """Fused LSTM recurrence: inference only, hidden 128, single layer, batch_first, fp32 CUDA."""
-    needs_grad = torch.is_grad_enabled() and (seq.requires_grad or any(p.requires_grad for p in rnn.parameters()))
+    """Fused LSTM recurrence (forward and backward): hidden 128, single layer, batch_first, fp32 CUDA."""
     return (isinstance(rnn, torch.nn.LSTM) and rnn.hidden_size == 128 and rnn.num_layers == 1 and not rnn.bidirectional
-            and rnn.batch_first and getattr(rnn, "proj_size", 0) == 0 and seq.is_cuda and seq.dtype == torch.float32
-            and not needs_grad)
+            and rnn.batch_first and getattr(rnn, "proj_size", 0) == 0 and seq.is_cuda and seq.dtype == torch.float32)
 
 
-def lstm_sequence(rnn, seq, norm, reduce_sum):
-    """LayerNorm(sum_t LSTM(seq)_t) / LayerNorm(LSTM(seq)) with the recurrence in ctgcn_lstm_seq_f32 (inference)."""
+def _lstm_forward(seq, w_ih, w_hh, bias, ln_w, ln_b, eps, reduce_sum):
+    """LayerNorm(sum_t LSTM(seq)_t) / LayerNorm(LSTM(seq)): library GEMM for the input projection, recurrence in ctgcn_lstm_seq_f32."""
     lib = _lib.load()
     rows, steps, d_in = seq.shape
-    hid = rnn.hidden_size
-    seq = seq.contiguous()
-    w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous()
-    bias = (rnn.bias_ih_l0.detach() + rnn.bias_hh_l0.detach()) if rnn.bias else None
+    hid = w_hh.shape[1]
     out = torch.empty((rows, hid) if reduce_sum else (rows, steps, hid), dtype=torch.float32, device=seq.device)
     if rows == 0:
         return out
     chunks = _row_chunks(lib, rows, steps, hid)
     gi_buf = torch.empty(chunks[0][1] * steps, 4 * hid, dtype=torch.float32, device=seq.device)
-    ln_w = None if norm is None else norm.weight
-    ln_b = None if norm is None else norm.bias
-    eps = 0.0 if norm is None else float(norm.eps)
     with torch.cuda.device(seq.device):
         for lo, n in chunks:
             gi = gi_buf[: n * steps]
@@ -700,8 +692,94 @@ def lstm_sequence(rnn, seq, norm, reduce_sum):
                 torch.addmm(bias, x2d, w_ih.t(), out=gi)
             with _timed("lstm_seq", rows=n, steps=steps):
                 check(lib.ctgcn_lstm_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh), ptr(ln_w), ptr(ln_b), eps, 1 if reduce_sum else 0,
-                                             ptr(out[lo:lo + n]), _stream()), "ctgcn_lstm_seq_f32")
+                                             ptr(out[lo:lo + n]), None, _stream()), "ctgcn_lstm_seq_f32")
     return out
+
+
+class _LstmSeq(torch.autograd.Function):
+    """LayerNorm(sum_t LSTM(seq)_t) or LayerNorm(LSTM(seq)) with autograd (rnn_type = 'LSTM', layers.py:27-28 / models.py:234-235).
+    Forward = the inference kernels; backward recomputes gates, cell states and the raw h sequence chunk by chunk
+    (ctgcn_lstm_seq_f32 with gates_out), runs ctgcn_layernorm_bwd_f32 and ctgcn_lstm_seq_bwd_f32 and leaves d x / d W — plain GEMMs
+    over the materialised d gi — to the library.  (MIOpen's LSTM needs ~27 000 tensor-op launches per config-5 window.)"""
+
+    @staticmethod
+    def forward(ctx, seq, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b, eps, reduce_sum):
+        bias = (b_ih.detach() + b_hh.detach()) if b_ih is not None else None
+        seq_c = seq.contiguous()
+        out = _lstm_forward(seq_c, w_ih.detach(), w_hh.detach().contiguous(), bias, ln_w, ln_b, eps, reduce_sum)
+        ctx.save_for_backward(seq_c, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b)
+        ctx.eps, ctx.reduce_sum = eps, reduce_sum
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        seq, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b = ctx.saved_tensors
+        reduce_sum, eps = ctx.reduce_sum, ctx.eps
+        rows, steps, d_in = seq.shape
+        hid = w_hh.shape[1]
+        dev = seq.device
+        w_ih_d, w_hh_d = w_ih.detach(), w_hh.detach().contiguous()
+        bias = (b_ih.detach() + b_hh.detach()) if b_ih is not None else None
+        dout = dout.contiguous()
+        dseq = torch.empty_like(seq)
+        dw_ih, dw_hh = torch.zeros_like(w_ih_d), torch.zeros_like(w_hh_d)
+        db = torch.zeros(4 * hid, dtype=torch.float32, device=dev)
+        bias_part = torch.empty(512, 4 * hid, dtype=torch.float32, device=dev)
+        dln_w = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
+        dln_b = torch.zeros(hid, dtype=torch.float32, device=dev) if ln_w is not None else None
+        ln_part = torch.empty(2048, 2 * hid, dtype=torch.float32, device=dev) if ln_w is not None else None
+        chunks = _row_chunks(lib, rows, steps, hid)
+        cmax = chunks[0][1]
+        gi_buf = torch.empty(cmax * steps, 4 * hid, dtype=torch.float32, device=dev)          # reused as d_gi
+        gates_buf = torch.empty(cmax * steps, 5 * hid, dtype=torch.float32, device=dev)
+        hseq_buf = torch.empty(cmax, steps, hid, dtype=torch.float32, device=dev)
+        hprev_buf = torch.zeros(cmax, steps, hid, dtype=torch.float32, device=dev)            # [:, 0] stays 0
+        with torch.cuda.device(dev):
+            for lo, n in chunks:
+                x2d = seq[lo:lo + n].reshape(n * steps, d_in)
+                gi, gates, hseq = gi_buf[: n * steps], gates_buf[: n * steps], hseq_buf[:n]
+                if bias is None:
+                    torch.mm(x2d, w_ih_d.t(), out=gi)
+                else:
+                    torch.addmm(bias, x2d, w_ih_d.t(), out=gi)
+                check(lib.ctgcn_lstm_seq_f32(n, steps, hid, ptr(gi), ptr(w_hh_d), None, None, 0.0, 0, ptr(hseq), ptr(gates), _stream()),
+                      "ctgcn_lstm_seq_f32")
+                g_out = dout[lo:lo + n]
+                if ln_w is not None:
+                    ln_rows = n if reduce_sum else n * steps
+                    dpre = torch.empty((n, hid) if reduce_sum else (n, steps, hid), dtype=torch.float32, device=dev)
+                    check(lib.ctgcn_layernorm_bwd_f32(ln_rows, steps if reduce_sum else 1, hid, ptr(hseq), ptr(g_out), ptr(ln_w.detach()), eps,
+                                                      ptr(dpre), ptr(ln_part), ln_part.shape[0], _stream()), "ctgcn_layernorm_bwd_f32")
+                    ln_sum = ln_part.sum(0)
+                    dln_w += ln_sum[:hid]
+                    dln_b += ln_sum[hid:]
+                else:
+                    dpre = g_out
+                dgi = gi                                                                        # gi is dead: reuse as d_gi
+                check(lib.ctgcn_lstm_seq_bwd_f32(n, steps, hid, ptr(gates), None if reduce_sum else ptr(dpre), ptr(dpre) if reduce_sum else None,
+                                                 ptr(w_hh_d), ptr(dgi), ptr(bias_part), bias_part.shape[0], _stream()), "ctgcn_lstm_seq_bwd_f32")
+                torch.mm(dgi, w_ih_d, out=dseq[lo:lo + n].view(n * steps, d_in))
+                db += bias_part.sum(0)
+                _accumulate_tn(dw_ih, dgi, x2d)
+                hprev = hprev_buf[:n]
+                hprev[:, 1:] = hseq[:, :-1]
+                _accumulate_tn(dw_hh, dgi, hprev.view(n * steps, hid))
+        db_ih = db_hh = None
+        if b_ih is not None:
+            db_ih, db_hh = db, db.clone()
+        return dseq, dw_ih, dw_hh, db_ih, db_hh, dln_w, dln_b, None, None
+
+
+def lstm_sequence(rnn, seq, norm, reduce_sum):
+    """LayerNorm(sum_t LSTM(seq)_t) / LayerNorm(LSTM(seq)) with the recurrence in ctgcn_lstm_seq_f32; with autograd enabled the
+    backward runs ctgcn_lstm_seq_bwd_f32 (see _LstmSeq)."""
+    b_ih = rnn.bias_ih_l0 if rnn.bias else None
+    b_hh = rnn.bias_hh_l0 if rnn.bias else None
+    ln_w = None if norm is None else norm.weight
+    ln_b = None if norm is None else norm.bias
+    eps = 0.0 if norm is None else float(norm.eps)
+    return _LstmSeq.apply(seq, rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, ln_w, ln_b, eps, bool(reduce_sum))
 
 
 def gru_sequence(rnn, seq, norm, reduce_sum, out=None):

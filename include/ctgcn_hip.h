@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 18
+#define CTGCN_ABI_VERSION 19
 
 enum {
     CTGCN_OK = 0,
@@ -214,11 +214,20 @@ int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const f
 /*
  * The same for nn.LSTM (rnn_type = 'LSTM'; layers.py:27-28, models.py:234-235): gi [rows, steps, 512] = x·W_ih^T + b_ih
  * + b_hh in PyTorch's gate order i,f,g,o; w_hh [512, 128]; h_0 = c_0 = 0.  Exact fp32 (f32-input MFMA).
- * Inference only (no backward entry point: training goes through the framework's LSTM).
+ * gates_out (optional; reduce_sum == 0, no LayerNorm): [rows, steps, 5, 128] for ctgcn_lstm_seq_bwd_f32 (training's recompute pass).
  */
 int ctgcn_lstm_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gi, const float *w_hh,
                        const float *ln_weight, const float *ln_bias, float ln_eps, int reduce_sum, float *out,
-                       void *stream);
+                       float *gates_out, void *stream);
+/*
+ * Backward of that recurrence (autograd of nn.LSTM).  gates [rows, steps, 5, 128] = i, f, g, o (after their activations) and c, as
+ * ctgcn_lstm_seq_f32 writes them into gates_out (reduce_sum == 0, no LayerNorm: `out` is then the raw h sequence).  dh_seq
+ * [rows, steps, 128] and / or dh_sum [rows, 128] (added at every step: the gradient of sum_t h_t).  d_gi [rows, steps, 512] = gradient
+ * w.r.t. the gate pre-activations (= d of x·W_ih^T + b; d x, d W_ih, d W_hh are GEMMs over it), bias_partial [n_partial, 512]: per-block
+ * column sums of d_gi (d b_ih = d b_hh = their sum).  Exact fp32 (f32-input MFMA).
+ */
+int ctgcn_lstm_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *dh_seq, const float *dh_sum,
+                           const float *w_hh, float *d_gi, float *bias_partial, int32_t n_partial, void *stream);
 
 /*
  * layers.py:59-62 / models.py:249-250 in ONE kernel for d_in = hidden = 128 with both weight matrices resident in the register

@@ -173,8 +173,9 @@ def test_fused_lstm_matches_torch(rows, steps, d_in, reduce_sum, bias):
         assert ops.lstm_fused_ok(rnn_d, x.to(DEV))
         got = layers.rnn_reduce_norm(rnn_d, norm_d, x.to(DEV), reduce_sum)
     check_close(got.cpu().numpy(), want.numpy(), 1e-4, 1e-5, what="fused GRU vs torch")
-    # with gradients enabled the framework LSTM runs (and agrees)
+    # with gradients enabled the same kernels run behind an autograd function (and agree)
     got_train = layers.rnn_reduce_norm(rnn_d, norm_d, x.to(DEV).requires_grad_(True), reduce_sum)
+    assert got_train.requires_grad
     check_close(got_train.detach().cpu().numpy(), want.numpy(), 1e-4, 1e-5, what="fused LSTM (training path) vs torch")
 
 
@@ -311,3 +312,49 @@ def test_layernorm_backward_kernel_matches_autograd(rows, steps):
     assert (dx.double() - x64.grad).abs().max().item() <= 2e-5 * x64.grad.abs().max().item() + 1e-6
     assert (sums[:128] - g64.grad).abs().max().item() <= 1e-5 * g64.grad.abs().max().item() + 1e-5
     assert (sums[128:] - b64.grad).abs().max().item() <= 1e-5 * b64.grad.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("rows,steps,d_in,reduce_sum,bias,use_norm", [
+    (70, 8, 128, True, True, True), (1000, 5, 40, True, True, True), (513, 6, 128, False, True, True),
+    (90, 3, 128, True, False, True), (33, 1, 16, True, True, True), (200, 4, 128, False, True, False), (70001, 3, 128, True, True, True),
+])
+def test_fused_lstm_gradients_match_torch_autograd(rows, steps, d_in, reduce_sum, bias, use_norm):
+    """rnn_type = 'LSTM' in training (reference layers.py:27-28, models.py:234-235): d/d{x, W_ih, W_hh, b_ih, b_hh, ln.weight, ln.bias}
+    of sum(out * G) through ctgcn_lstm_seq_f32 / ctgcn_lstm_seq_bwd_f32 / ctgcn_layernorm_bwd_f32 vs CPU nn.LSTM autograd."""
+    import copy
+    from ctgcn_amd import ops
+    torch.manual_seed(11 * rows + steps)
+    rnn = torch.nn.LSTM(d_in, 128, 1, bias=bias, batch_first=True)
+    norm = torch.nn.LayerNorm(128) if use_norm else None
+    if norm is not None:
+        with torch.no_grad():
+            norm.weight.uniform_(0.5, 1.5)
+            norm.bias.uniform_(-0.5, 0.5)
+    x = (torch.relu(torch.randn(rows, steps, d_in)) * 1.5).requires_grad_(True)
+    out = rnn(x)[0]
+    out = out.sum(1) if reduce_sum else out
+    out = norm(out) if norm is not None else out
+    G = torch.randn_like(out)
+    (out * G).sum().backward()
+
+    rnn_d, norm_d = copy.deepcopy(rnn).to(DEV), (copy.deepcopy(norm).to(DEV) if norm is not None else None)
+    for p in list(rnn_d.parameters()) + (list(norm_d.parameters()) if norm_d is not None else []):
+        p.grad = None
+    xd = x.detach().to(DEV).requires_grad_(True)
+    assert ops.lstm_fused_ok(rnn_d, xd)
+    got = ops.lstm_sequence(rnn_d, xd, norm_d, reduce_sum)
+    check_close(got.detach().cpu().numpy(), out.detach().numpy(), 1e-4, 1e-5, what="fused LSTM (training forward) vs torch")
+    (got * G.to(DEV)).sum().backward()
+
+    def close(a, b, name):
+        a, b = a.cpu().numpy(), b.numpy()
+        scale = max(1e-6, float(np.abs(b).max()))
+        print("  [tol] grad %-24s |err| / max|grad| %.3e (limit 2e-5)" % (name, np.abs(a - b).max() / scale))
+        assert np.abs(a - b).max() <= 2e-5 * scale, (name, np.abs(a - b).max(), scale)
+
+    close(xd.grad, x.grad, "dx")
+    for (name, pd), (_, pc) in zip(rnn_d.named_parameters(), rnn.named_parameters()):
+        close(pd.grad, pc.grad, name)
+    if norm is not None:
+        close(norm_d.weight.grad, norm.weight.grad, "ln.weight")
+        close(norm_d.bias.grad, norm.bias.grad, "ln.bias")

@@ -14,7 +14,8 @@ workload = default `synthetic-1m` = BASELINE config 5 (1M nodes x 16 cumulative 
 (one process per GPU, RCCL, 127.0.0.1 rendezvous); under a launcher (RANK/WORLD_SIZE set) it runs as that rank.
 
 Extra objects on the JSON line:
-  roofline            dominant kernel (agg_fwd_kernel): algorithmic bytes per launch / HIP-event duration on the launch stream
+  roofline            dominant kernel (the aggregation): algorithmic bytes per launch / HIP-event duration on the launch stream; under the
+                      row plan the algorithmic bytes are those of the rows actually written, survey_8d_* keeps SURVEY §8d's formula
   roofline_by_width   the same per feature width when the model aggregates at more than one (hid=500: d=500 and d=128)
   roofline_gru        matrix-core kernels (recurrence / input projection)
   roofline_kcore      k-core peel of the window's largest snapshot: 2(4(N+1)+4nnz)+8N bytes / measured peel time
@@ -352,26 +353,30 @@ def main():
 
     def roofline_of(group, d):
         avg_ms = sum(ms for ms, _ in group) / len(group)
-        avg_bytes = sum(algorithmic_bytes(m["n"], m["nnz"], m["K"], m["d"]) for _, m in group) / len(group)
-        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9
-        rec = pmc.get(args.workload, {}).get(str(world)) if d == 128 else None
-        # under the row plan the launch writes fewer rows than §8d prices: `achieved` keeps the §8d bytes (the work the reference
-        # defines), `moved_*` prices the bytes this launch actually has to move
-        moved = sum(moved_bytes(m["n"], m["nnz"], m["K"], m["d"], m["rows_written"]) if "rows_written" in m
+        # SURVEY §8d prices the fused kernel at nnz (4d + 9) + N K 4d + 4 (N + 1) bytes: every (node, core) output row.  Under the row
+        # plan (CoreAdj.row_plan) the rows that repeat the row before them are not written, so the bytes a launch HAS to move are fewer;
+        # `achieved` / `frac` use those (a fraction of the HBM peak must be physical), `survey_8d_*` keep the §8d formula (the work the
+        # reference defines — it can exceed the peak precisely because part of it is no longer done).  Without a plan both coincide.
+        survey = sum(algorithmic_bytes(m["n"], m["nnz"], m["K"], m["d"]) for _, m in group) / len(group)
+        moved = sum(moved_bytes(m["n"], m["nnz"], m["K"], m["d"], m["rows_written"]) if m.get("rows_written", m["n"] * m["K"]) != m["n"] * m["K"]
                     else algorithmic_bytes(m["n"], m["nnz"], m["K"], m["d"]) for _, m in group) / len(group)
         rows_frac = sum(m.get("rows_written", m["n"] * m["K"]) for _, m in group) / float(sum(m["n"] * m["K"] for _, m in group))
+        achieved = moved / (avg_ms * 1e-3) / 1e9
+        survey_gbps = survey / (avg_ms * 1e-3) / 1e9
+        rec = pmc.get(args.workload, {}).get(str(world)) if d == 128 else None
         copy_peak = copy_bw["value"] if copy_bw else 6300.0
         return {"kernel": agg_kernel_name(d, bool(group[0][1].get("split"))), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": rec["hbm_bytes_per_launch"] if rec else None,
                 "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/agg_bench.py on the same "
                                    "workload (separate run, not this one)") if rec else None,
-                "launches_timed": len(group), "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(avg_bytes),
+                "launches_timed": len(group), "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(moved),
                 "ms_per_step_rank0": round(sum(ms for ms, _ in group) / roof_steps, 3),
-                "moved_bytes_per_launch": int(moved), "moved_GBps": round(moved / (avg_ms * 1e-3) / 1e9, 1),
-                "moved_frac": round(moved / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "output_rows_written_frac": round(rows_frac, 4),
-                "moved_note": "row plan: (node, core) rows of H that repeat the row before them are not written (bit-identical results); "
-                              "`achieved` prices the §8d bytes of the reference's computation, `moved_*` the bytes this launch moves",
-                "frac_of_measured_copy_bw": round(achieved / copy_peak, 4), "moved_frac_of_measured_copy_bw": round(moved / (avg_ms * 1e-3) / 1e9 / copy_peak, 4)}
+                "output_rows_written_frac": round(rows_frac, 4),
+                "survey_8d_bytes_per_launch": int(survey), "survey_8d_GBps": round(survey_gbps, 1), "survey_8d_frac": round(survey_gbps / HBM_PEAK_GBS, 4),
+                "bytes_note": "algorithmic bytes = entries x (4d + 9) + output rows WRITTEN x (4d + 4) + row_ptr + the plan's order / tile masks; "
+                              "survey_8d_* = SURVEY §8d's formula, which prices every (node, core) output row — the row plan does not write the "
+                              "rows that repeat the row before them (bit-identical results), so that figure is work per time, not traffic per time",
+                "frac_of_measured_copy_bw": round(achieved / copy_peak, 4)}
 
     by_width = {}
     for ms, m in fwd:

@@ -663,7 +663,7 @@ class _GruSeq(torch.autograd.Function):
         if b_ih is not None:
             db_ih = db_all[: 3 * hid].clone()
             db_hh = torch.cat([db_all[: 2 * hid], db_all[3 * hid:]])
-        return dseq, dw_ih, dw_hh, db_ih, db_hh, dln_w, dln_b, None, None
+        return dseq, dw_ih, dw_hh, db_ih, db_hh, dln_w, (dln_b if ln_b is not None else None), None, None
 
 
 def lstm_fused_ok(rnn, seq):
@@ -768,7 +768,7 @@ class _LstmSeq(torch.autograd.Function):
         db_ih = db_hh = None
         if b_ih is not None:
             db_ih, db_hh = db, db.clone()
-        return dseq, dw_ih, dw_hh, db_ih, db_hh, dln_w, dln_b, None, None
+        return dseq, dw_ih, dw_hh, db_ih, db_hh, dln_w, (dln_b if ln_b is not None else None), None, None
 
 
 def lstm_sequence(rnn, seq, norm, reduce_sum):

@@ -225,6 +225,10 @@ def test_row_plan_with_hub_rows_general_lists_and_k1(monkeypatch):
                                      device=_dev(), self_loop=False)
         assert many.K == 40 and many.row_plan() is None          # masks are 32 bits wide: longer lists run without a plan
         cases.append(many)
+        full = CoreAdj.from_matrices([sp.random(300, 300, density=0.004, random_state=200 + j, format="csr", dtype=np.float32) for j in range(32)],
+                                     device=_dev(), self_loop=False)
+        assert full.K == 32 and full.row_plan() is not None and full.row_plan()["new_rows"] < 300 * 32      # bit 31 of the masks in use
+        cases.append(full)
         for a in cases:
             for d in (128, 500, 64):          # 128: GRU layer kernel on planes with holes; others: split GEMM on compact operand rows
                 layer = _layer(d, 2)

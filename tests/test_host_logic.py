@@ -452,7 +452,8 @@ def test_row_plan_names_exactly_rows_that_repeat_in_the_oracle():
     nested = O.core_adj_list([O.kcore_matrices(csr)], 0, 1, 1, max_core=5)[0]
     general = [sp.random(n, n, density=0.001 * (1 + j % 2), random_state=j, format="csr", dtype=np.float32) for j in range(4)]
     x = rng.standard_normal((n, 8)).astype(np.float32)
-    for mats, kw in ((nested, {}), (general, dict(self_loop=False))):
+    wide = [sp.random(n, n, density=0.0004, random_state=50 + j, format="csr", dtype=np.float32) for j in range(32)]      # K = 32: bit 31 of the masks
+    for mats, kw in ((nested, {}), (general, dict(self_loop=False)), (wide, dict(self_loop=False))):
         adj = CoreAdj.from_matrices(mats, **kw)
         plan = adj.row_plan()
         K = adj.K
@@ -467,7 +468,8 @@ def test_row_plan_names_exactly_rows_that_repeat_in_the_oracle():
         # patterns are grouped: the masks are not looser than the rows' own patterns except at group boundaries (< 2^K tiles)
         own = ~repeats[order]
         loose = ((bits == 1) & ~own).any(axis=1).reshape(-1)
-        assert loose.sum() <= 16 * (1 << K), loose.sum()
+        if K <= 8:                                            # (a list with 2^32 possible patterns groups nothing: only correctness matters there)
+            assert loose.sum() <= 16 * (1 << K), loose.sum()
         assert plan["new_rows"] == 16 * sum(bin(int(m) & ((1 << K) - 1)).count("1") for m in tmask)
         # the GEMM consumer's compact layout (tiles of 64): every wanted (row, slot) has its own operand row inside its tile's range
         p64 = adj.row_plan(adj.PLAN_TILE_GEMM)

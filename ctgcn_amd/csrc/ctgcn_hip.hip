@@ -3656,7 +3656,9 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
     if (blocks > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: grid too large");
     // the residual plane is unscaled for every consumer (GRU layer kernel and GEMM both add the three products in one accumulator)
     const float rsc = 1.f;
-    if (p.chunks <= 32 && n_rows <= 200000) hipLaunchKernelGGL(agg_fwd_split32_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
+    static const int force_u8 = [] { const char *e = getenv("CTGCN_AGG_U8"); return e ? atoi(e) : -1; }();      // A/B: 1 = always eight gathers in flight, 0 = never
+    const bool u8 = force_u8 >= 0 ? force_u8 != 0 : n_rows <= 200000;
+    if (p.chunks <= 32 && u8) hipLaunchKernelGGL(agg_fwd_split32_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
     else if (p.chunks <= 32) hipLaunchKernelGGL(agg_fwd_split32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
     else if (p.chunks <= 64) hipLaunchKernelGGL((agg_fwd_split_kernel<64, 1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
     else if (n_rows <= 200000) hipLaunchKernelGGL((agg_fwd_split_kernel<64, 2, 8>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);

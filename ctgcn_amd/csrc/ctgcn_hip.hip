@@ -1953,6 +1953,10 @@ struct LayerArgs {
     // the x·W_ih products of step t-1 are kept, the step costs the h·W_hh half only.  Bit 0 is always set; steps <= 32.
     const int32_t *order;
     const uint32_t *tmask;
+    // x of step t of sequence r at x + r ld_row + step_off[t] instead of x + (r steps + t) ldx (both null / 0: the dense layout): the temporal
+    // GRU of a snapshot-parallel forward reads the all-to-all's receive buffer [slot][rank][node][128] in time order without a copy
+    const int64_t *step_off;
+    int64_t ld_row;
     float *gates;                // SAVE (per-step form without LayerNorm): [rows, steps, 4, 128] r, z, n, q = W_hn h + b_hn for ctgcn_gru_seq_bwd_f32
 #ifdef CTGCN_LAYER_TIMELINE
     unsigned long long *timeline;   // diagnostic build: per (block, wave) sums of the unit phases, see tools/layer_timeline.py
@@ -2303,7 +2307,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 xq2 = *(const h4v *)(a.xp2 + rs_ * GRU_H + sc);
                 xqs = a.xps[rs_];
             } else {
-                v = *(const f4v *)(a.x + (row * S + t) * a.ldx + sc);
+                v = *(const f4v *)(a.x + (a.step_off ? row * a.ld_row + a.step_off[t] : (row * S + t) * a.ldx) + sc);
             }
         }
     };
@@ -3904,8 +3908,10 @@ int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const f
 
 int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
                         const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
-                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, float *gates_out, void *stream)
+                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, float *gates_out,
+                        const int64_t *step_offsets, int64_t ld_row, void *stream)
 {
+    if (step_offsets && (ld_row < d_in || (ld_row & 3))) return fail(CTGCN_E_INVALID, "gru_layer: ld_row=%lld must be a multiple of 4 and >= d_in", (long long)ld_row);
     if (hidden != GRU_H || d_in != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer: only d_in = hidden = %d is built (got %d, %d)", GRU_H, d_in, hidden);
     if (gates_out && (reduce_sum || ln_weight)) return fail(CTGCN_E_INVALID, "gru_layer: gates_out needs reduce_sum == 0 and no LayerNorm (raw h sequence)");
     if (gates_out && !aligned16(gates_out)) return fail(CTGCN_E_INVALID, "gru_layer: gates_out must be 16-byte aligned");
@@ -3927,6 +3933,9 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
     LayerArgs a{};
     a.rows = rows; a.steps = steps; a.x = x; a.ldx = ldx; a.wih = w_ih; a.whh = w_hh; a.bias_gi = bias_gi; a.bhn = b_hn;
     a.gamma = ln_weight; a.beta = ln_bias; a.eps = ln_eps; a.out = out; a.ldo = ldo; a.gates = gates_out;
+    a.step_off = step_offsets; a.ld_row = ld_row;
+    static const int nw_ = [] { const char *e = getenv("CTGCN_GRU_LAYER_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    if (step_offsets && nw_ != 8) return fail(CTGCN_E_UNSUPPORTED, "gru_layer: step_offsets belong to the 8-wave kernels");
     if (gates_out) {
         // training's recompute pass: raw h sequence + gates straight from the layer kernel (the kernel pair wrote and re-read gi for this)
         const int64_t nt8 = (rows + 15) / 16;

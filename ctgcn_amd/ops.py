@@ -406,7 +406,7 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
         # projection + recurrence in one kernel, both weight matrices in the register file, gi never materialised
         with torch.cuda.device(seq.device), _timed("gru_layer", rows=rows, steps=steps, reduce_sum=bool(reduce_sum)):
             check(lib.ctgcn_gru_layer_f32(rows, steps, d_in, hid, ptr(seq), seq.stride(1), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn),
-                                          ptr(ln_w), ptr(ln_b), eps, 1 if reduce_sum else 0, ptr(out), ldo, None, _stream()), "ctgcn_gru_layer_f32")
+                                          ptr(ln_w), ptr(ln_b), eps, 1 if reduce_sum else 0, ptr(out), ldo, None, None, 0, _stream()), "ctgcn_gru_layer_f32")
         return out
     chunks = _row_chunks(lib, rows, steps, hid)
     gi_buf = _gi_buffer(chunks[0][1], steps, hid, seq.device)
@@ -417,6 +417,34 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_buf), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
                                             1 if reduce_sum else 0, ptr(out[lo:lo + n]), ldo, None, split, 1 if blocked else 0,
                                             None, None, None, _stream()), "ctgcn_gru_seq_f32")
+    return out
+
+
+def gru_steps_scattered_ok(rnn, base):
+    """gru_sequence_scattered covers what the register-resident layer kernel covers: GRU 128 -> 128, fp16x2 arithmetic, 8-wave build"""
+    import os
+    return (gru_fused_ok(rnn, base) and rnn.input_size == rnn.hidden_size and forward_split_mode() == 2 and layer_kernel_enabled(False)
+            and os.environ.get("CTGCN_GRU_LAYER_WAVES", "8") != "4" and rnn.weight_ih_l0.is_contiguous()
+            and not (torch.is_grad_enabled() and any(p.requires_grad for p in rnn.parameters())))
+
+
+def gru_sequence_scattered(rnn, norm, base, step_offsets, ld_row, rows):
+    """LayerNorm(GRU(x)) -> [rows, steps, 128] (models.py:249-250) for an input whose steps live at base + step_offsets[t] + r * ld_row
+    (floats) — e.g. the receive buffer of the snapshot-parallel exchange — without gathering them into a [rows, steps, 128] tensor first.
+    Inference only; same kernel and arithmetic as gru_sequence(..., reduce_sum=False)."""
+    lib = _lib.load()
+    steps, hid = int(step_offsets.numel()), rnn.hidden_size
+    bias, b_hn = _gru_bias(rnn, hid)
+    ln_w = None if norm is None else norm.weight
+    ln_b = None if norm is None else norm.bias
+    eps = 0.0 if norm is None else float(norm.eps)
+    out = torch.empty(rows, steps, hid, dtype=torch.float32, device=base.device)
+    if rows == 0:
+        return out
+    with torch.cuda.device(base.device), _timed("gru_layer", rows=rows, steps=steps, reduce_sum=False):
+        check(lib.ctgcn_gru_layer_f32(rows, steps, hid, hid, ptr(base), hid, ptr(rnn.weight_ih_l0.detach()), ptr(rnn.weight_hh_l0.detach().contiguous()),
+                                      ptr(bias), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps, 0, ptr(out), 0, None, ptr(step_offsets), int(ld_row), _stream()),
+              "ctgcn_gru_layer_f32")
     return out
 
 
@@ -617,7 +645,7 @@ class _GruSeq(torch.autograd.Function):
                     # to the pair below, without writing and re-reading gi)
                     with _timed("gru_layer", rows=n, steps=steps, reduce_sum=False, save=True):
                         check(lib.ctgcn_gru_layer_f32(n, steps, d_in, hid, ptr(xs), xs.stride(1), ptr(w_ih_d), ptr(w_hh_d), ptr(bias), ptr(b_hn), None, None,
-                                                      0.0, 0, ptr(hseq), 0, ptr(gates), _stream()), "ctgcn_gru_layer_f32")
+                                                      0.0, 0, ptr(hseq), 0, ptr(gates), None, 0, _stream()), "ctgcn_gru_layer_f32")
                 else:
                     blocked = _project(x2d, w_ih_d, bias, gi_flat, steps_blocked=steps)
                     check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_flat), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq), 0,

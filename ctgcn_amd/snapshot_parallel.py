@@ -274,9 +274,12 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
         buf = model._exchange_buffers = (key,
                                          torch.zeros(plan.per, plan.n_pad, d, dtype=p0.dtype, device=p0.device),
                                          torch.empty(plan.per, plan.world, plan.n_slice, d, dtype=p0.dtype, device=p0.device),
-                                         torch.empty(hi - lo, plan.T, d, dtype=p0.dtype, device=p0.device),
-                                         _slot_moves(plan, p0.device))
-    _, send, recv, seq, moves = buf
+                                         [None],                          # [nodes, T, d] gather buffer: only when the temporal step cannot read recv itself
+                                         _slot_moves(plan, p0.device),
+                                         # element offset of snapshot t's block inside recv [per, world, n_slice, d]
+                                         torch.tensor([((plan.slot_of[t] % plan.per) * plan.world + plan.slot_of[t] // plan.per) * plan.n_slice * d
+                                                       for t in range(plan.T)], dtype=torch.int64, device=p0.device))
+    _, send, recv, seq_box, moves, step_off = buf
     works, trans_local = [], {}
     for s_ in range(plan.per):
         if s_ < len(mine):
@@ -288,13 +291,23 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
         works.append(dist.all_to_all_single(recv[s_].view(plan.world * plan.n_slice, d), send[s_], group=group, async_op=True))
     # recv[s][w] = snapshot assignment[w][s] on my node slice -> [nodes, T, d] in time order (the temporal GRU's input layout); slot s is
     # moved as soon as ITS all-to-all has landed (one strided copy per slot: the ranks' s-th snapshots), under the later slots' exchange
-    for s_ in range(plan.per):
-        works[s_].wait()
-        if moves[s_] is not None:
-            times, owners, count = moves[s_]
-            src = recv[s_, :count, : hi - lo] if owners is None else recv[s_, owners, : hi - lo]
-            seq.index_copy_(1, times, src.transpose(0, 1))
-    out = model.temporal_head(seq)                                                          # [T, my nodes, d]
+    from . import ops
+    if recv.is_cuda and d == 128 and ops.gru_steps_scattered_ok(model.rnn, recv):
+        # the temporal GRU reads the receive buffer in time order through a per-step offset table: no [nodes, T, d] copy at all
+        for w in works:
+            w.wait()
+        out = ops.gru_sequence_scattered(model.rnn, model.norm, recv, step_off, d, hi - lo).transpose(0, 1)        # [T, my nodes, d]
+    else:
+        if seq_box[0] is None:
+            seq_box[0] = torch.empty(hi - lo, plan.T, d, dtype=p0.dtype, device=p0.device)
+        seq = seq_box[0]
+        for s_ in range(plan.per):
+            works[s_].wait()
+            if moves[s_] is not None:
+                times, owners, count = moves[s_]
+                src = recv[s_, :count, : hi - lo] if owners is None else recv[s_, owners, : hi - lo]
+                seq.index_copy_(1, times, src.transpose(0, 1))
+        out = model.temporal_head(seq)                                                      # [T, my nodes, d]
     if model.shard_gather_output:
         padded = torch.nn.functional.pad(out, (0, 0, 0, plan.n_slice - (hi - lo))) if hi - lo < plan.n_slice else out
         full = _GatherReplicatedOutput.apply(padded.transpose(0, 1).contiguous(), group)    # [world, n_slice, T, d]

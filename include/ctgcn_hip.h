@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 19
+#define CTGCN_ABI_VERSION 20
 
 enum {
     CTGCN_OK = 0,
@@ -240,10 +240,14 @@ int ctgcn_lstm_seq_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const fl
  * ctgcn_gru_seq_f32: results are bit-identical to the kernel pair.  HBM traffic: x in + out (the pair: 7x that).
  * gates_out (optional; reduce_sum == 0, no LayerNorm): [rows, steps, 4, 128] as ctgcn_gru_seq_f32 writes them - the recompute pass of
  * training without the gi round trip.
+ * step_offsets (optional, device int64[steps]) + ld_row: x of step t of sequence r is read at x + r ld_row + step_offsets[t] (floats;
+ * offsets multiples of 4) instead of x + (r steps + t) ldx - the steps of a sequence may live in different buffers' regions (the temporal
+ * GRU of models.py:249 on the receive buffer of a snapshot-parallel exchange, no stack / transpose copy).
  */
 int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidden, const float *x, int64_t ldx, const float *w_ih,
                         const float *w_hh, const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias,
-                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, float *gates_out, void *stream);
+                        float ln_eps, int reduce_sum, float *out, int64_t ld_out, float *gates_out,
+                        const int64_t *step_offsets, int64_t ld_row, void *stream);
 
 /*
  * ctgcn_gru_layer_f32 (sum-over-steps form) on an input that ctgcn_core_aggregate_split_f32 already wrote as fp16 planes + row scales

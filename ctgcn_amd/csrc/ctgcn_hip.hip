@@ -910,7 +910,7 @@ __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src,
 // dgamma / dbeta leave as per-block partial sums [gridDim.x][256] (gamma | beta), added by the caller: deterministic.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int32_t steps, const float *__restrict__ h, const float *__restrict__ dy,
-                                                            const float *__restrict__ gamma, float eps, float *__restrict__ dx,
+                                                            int64_t ld_dy, const float *__restrict__ gamma, float eps, float *__restrict__ dx,
                                                             float *__restrict__ partial)
 {
     __shared__ float red[4][2 * GRU_H];
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int32_
             const float2 v = *(const float2 *)(src + (int64_t)t * GRU_H);
             x.x += v.x; x.y += v.y;
         }
-        const float2 d = *(const float2 *)(dy + row * GRU_H + lane * 2);
+        const float2 d = *(const float2 *)(dy + row * ld_dy + lane * 2);
         float s = x.x + x.y;
         for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
         const float mean = s * (1.0f / GRU_H);
@@ -3891,9 +3891,11 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     return CTGCN_OK;
 }
 
-int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *h, const float *dy, const float *gamma, float eps,
+int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *h, const float *dy, int64_t ld_dy, const float *gamma, float eps,
                             float *dx, float *partial, int32_t n_partial, void *stream)
 {
+    if (ld_dy == 0) ld_dy = GRU_H;
+    if (ld_dy < GRU_H || (ld_dy & 1)) return fail(CTGCN_E_INVALID, "layernorm_bwd: ld_dy=%lld must be even and >= %d", (long long)ld_dy, GRU_H);
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "layernorm_bwd: hidden=%d, only %d is built", hidden, GRU_H);
     if (rows < 0 || steps < 1 || n_partial < 1 || n_partial > 65535) return fail(CTGCN_E_INVALID, "layernorm_bwd: bad sizes rows=%lld steps=%d n_partial=%d", (long long)rows, steps, n_partial);
     if (!partial) return fail(CTGCN_E_INVALID, "layernorm_bwd: null pointer");
@@ -3901,7 +3903,7 @@ int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const f
     if (!h || !dy || !gamma || !dx) return fail(CTGCN_E_INVALID, "layernorm_bwd: null pointer");
     if ((reinterpret_cast<uintptr_t>(h) & 7u) || (reinterpret_cast<uintptr_t>(dy) & 7u) || (reinterpret_cast<uintptr_t>(dx) & 7u) || (reinterpret_cast<uintptr_t>(gamma) & 7u))
         return fail(CTGCN_E_INVALID, "layernorm_bwd: h / dy / dx / gamma must be 8-byte aligned");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, rows, steps, h, dy, gamma, eps, dx, partial);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, rows, steps, h, dy, ld_dy, gamma, eps, dx, partial);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -147,8 +147,8 @@ class MLP(nn.Module):
         """(layer(h), whether the activation was already applied)"""
         if h.is_sparse:          # one-hot / sparse features (helper.py:161-172)
             if _is_identity(h):  # Linear(I) = W^T + b: one pass over W instead of an N x N SpMM
-                if h.is_cuda and layer.weight.dtype == torch.float32 and not (torch.is_grad_enabled() and layer.weight.requires_grad):
-                    return ops.linear_of_identity(layer.weight, layer.bias), False
+                if h.is_cuda and layer.weight.dtype == torch.float32:
+                    return ops.linear_of_identity(layer.weight, layer.bias), False      # HIP transpose, forward and backward
                 return (layer.weight.t() + layer.bias if layer.bias is not None else layer.weight.t().contiguous()), False
             out = torch.sparse.mm(h, layer.weight.t())
             return (out if layer.bias is None else out + layer.bias), False

@@ -77,6 +77,30 @@ class CGCN(nn.Module):
         return [r[0] for r in results], [r[1] for r in results]
 
 
+class _StackSteps(torch.autograd.Function):
+    """torch.stack(hx).transpose(0, 1) made dense in ONE pass: [N, T, d] with out[:, t] = hx[t] (reference models.py:248).  The framework
+    route is a cat into [T, N, d], a transposed view and a .contiguous() copy in front of the GRU, and the mirror image in backward; here
+    the forward is T strided column writes and the backward hands every snapshot its column of the gradient as a view (the LayerNorm backward
+    kernel reads it in place)."""
+
+    @staticmethod
+    def forward(ctx, *hx):
+        n, d = hx[0].shape
+        out = torch.empty(n, len(hx), d, dtype=hx[0].dtype, device=hx[0].device)
+        for t, h in enumerate(hx):
+            out[:, t].copy_(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        return tuple(grad[:, t] for t in range(grad.shape[1]))
+
+
+def _stack_steps(hx):
+    same = all(h.shape == hx[0].shape and h.dtype == hx[0].dtype and h.device == hx[0].device for h in hx)
+    return _StackSteps.apply(*hx) if same and hx[0].dim() == 2 else torch.stack(hx).transpose(0, 1)
+
+
 class CTGCN(nn.Module):
     """Temporal k-core GCN: per-snapshot MLP + CDN (own weights per snapshot), then a GRU/LSTM over time and
     a LayerNorm.  Returns [T, N, output_dim] ('C') or that plus the per-snapshot MLP outputs ('S')."""
@@ -223,5 +247,5 @@ class CTGCN(nn.Module):
                     seq[:, t].copy_(h)           # a layer that could not write in place (other rnn type/width) returned its own tensor
                 hx.append(h)
                 trans.append(tr)
-        out = self.temporal_head(seq if seq is not None else torch.stack(hx).transpose(0, 1))
+        out = self.temporal_head(seq if seq is not None else _stack_steps(hx))
         return out if self.model_type == 'C' else (out, trans)

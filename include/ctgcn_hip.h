@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 20
+#define CTGCN_ABI_VERSION 21
 
 enum {
     CTGCN_OK = 0,
@@ -206,9 +206,10 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
  * Backward of the LayerNorm(128) behind the GRU (layers.py:61-62 norm(output.sum(dim=1)); models.py:250 norm(output)):
  *   x[r] = sum_{t < steps} h[r, t, :]  (steps = 1: h is [rows, 128]);  dx = dL/dx given dy = dL/dLayerNorm(x) (the mean / rstd are recomputed),
  *   partial [n_partial, 256]: per-block partial sums of (dgamma | dbeta), every row written; the caller adds them up (deterministic).
+ *   ld_dy: floats between the rows of dy (0 = 128; larger: dy is a column of a [rows, T, 128] gradient, no copy needed).
  * One pass instead of the framework's three kernels + sum + forward recompute.  n_partial = number of blocks (<= 65535, e.g. 2048).
  */
-int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *h, const float *dy, const float *gamma, float eps,
+int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *h, const float *dy, int64_t ld_dy, const float *gamma, float eps,
                             float *dx, float *partial, int32_t n_partial, void *stream);
 
 /*

@@ -389,3 +389,18 @@ def test_linear_of_identity_is_transposed_weight_plus_bias(n, d, bias):
     want = lin.weight.detach().t() + (lin.bias.detach() if bias else 0.0)
     assert got.is_contiguous() and got.shape == (n, d)
     assert torch.equal(got, want.contiguous())
+
+
+@pytest.mark.parametrize("n,d,bias", [(31, 128, True), (70001, 128, True), (4097, 50, False)])
+def test_linear_of_identity_gradients(n, d, bias):
+    """training: d weight = (d out)^T and d bias = column sums, through the same transpose kernel — exactly the framework's values"""
+    from ctgcn_amd import ops
+    torch.manual_seed(n)
+    lin = torch.nn.Linear(n, d, bias=bias).to(_dev())
+    g = torch.randn(n, d, device=_dev())
+    out = ops.linear_of_identity(lin.weight, lin.bias)
+    assert out.requires_grad and out.is_contiguous()
+    (out * g).sum().backward()
+    assert torch.equal(lin.weight.grad, g.t().contiguous())
+    if bias:
+        assert torch.allclose(lin.bias.grad, g.sum(0), rtol=1e-6, atol=1e-5)

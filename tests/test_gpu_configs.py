@@ -42,6 +42,19 @@ def _record(case, **numbers):
         pass
 
 
+def _oracle_fp32_and_fp64(sd, xs, ref_adj, *model_args):
+    """the CPU oracle in fp32 (the reference's path: uncoalesced COO operands) and in fp64 (the truth both sides are measured against;
+    operands coalesced once — their order is immaterial there).  One after the other: run concurrently the two oversubscribe the host's
+    cores and take 1.4x longer in total (measured)."""
+    from oracle import torch_path as TP
+    t0 = time.time()
+    with torch.no_grad():
+        want = TP.ctgcn(sd, xs, ref_adj, *model_args)
+        t32 = time.time() - t0
+        want64 = TP.ctgcn({k: v.double() for k, v in sd.items()}, [x.double() for x in xs], [[a.double().coalesce() for a in l] for l in ref_adj], *model_args)
+    return want, want64, t32, time.time() - t0 - t32
+
+
 def _compare(case, got, want, want64, extra=None):
     """the rule of the module docstring on full output arrays; returns the observed numbers"""
     err = np.abs(got - want)
@@ -121,13 +134,9 @@ def test_baseline_config_shapes_match_cpu_oracle(case):
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(DEV)
     assert ops.gru_fused_ok(model.rnn, torch.zeros(1, 1, 128, device=DEV))     # the HIP GRU kernels are the ones running
-    t0 = time.time()
     with torch.no_grad():
         got = model([x.to(DEV) for x in xs], adj)
-        want = TP.ctgcn(sd, xs, ref_adj, "GRU", c["model"], c["act"])
-        t1 = time.time()
-        sd64 = {k: v.double() for k, v in sd.items()}
-        want64 = TP.ctgcn(sd64, [x.double() for x in xs], [[a.double().coalesce() for a in l] for l in ref_adj], "GRU", c["model"], c["act"])
+    want, want64, t32, t64 = _oracle_fp32_and_fp64(sd, xs, ref_adj, "GRU", c["model"], c["act"])
     if c["model"] == "S":
         (got, got_tr), (want, want_tr), (want64, _) = got, want, want64
         for a, b in zip(got_tr, want_tr):
@@ -136,7 +145,7 @@ def test_baseline_config_shapes_match_cpu_oracle(case):
     got = got.cpu().numpy()
     want, want64 = want.numpy(), want64.numpy()
     assert got.shape == want.shape == (c["T"], c["n"], 128)
-    _compare(case, got, want, want64, dict(oracle_fp32_s=t1 - t0, oracle_fp64_s=time.time() - t1))
+    _compare(case, got, want, want64, dict(oracle_fp32_s=t32, oracle_fp64_s=t64))
 
 
 # ------------------------------------------------------------------------------------------ config 5 at full size
@@ -176,13 +185,9 @@ def config5():
     model = ctgcn_amd.CTGCN(n, 128, 128, 1, 2, len(graphs)).eval()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(DEV)
-    t0 = time.time()
-    with torch.no_grad():
-        want = TP.ctgcn(sd, xs, ref_adj)
-        t1 = time.time()
-        want64 = TP.ctgcn({k: v.double() for k, v in sd.items()}, [x.double() for x in xs], [[a.double().coalesce() for a in l] for l in ref_adj])
+    want, want64, t32, t64 = _oracle_fp32_and_fp64(sd, xs, ref_adj)
     return dict(model=model, adj=adj, xs=[x.to(DEV) for x in xs], want=want.numpy(), want64=want64.numpy(),
-                times=dict(oracle_fp32_s=t1 - t0, oracle_fp64_s=time.time() - t1), K=[len(a) for a in adj], nnz=[a.nnz for a in adj])
+                times=dict(oracle_fp32_s=t32, oracle_fp64_s=t64), K=[len(a) for a in adj], nnz=[a.nnz for a in adj])
 
 
 @pytest.mark.parametrize("path", ["inference", "autograd_forward", "hub_rows"])

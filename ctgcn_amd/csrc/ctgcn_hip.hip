@@ -2357,10 +2357,20 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
             }
             return;
         }
-        if (i == 0) sx_m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        else sx_m = fmaxf(sx_m, sx_p);                    // the exchange requested one slice (nine MFMAs) ago
-        if (i < 5) sx_p = __shfl_xor(sx_m, 1 << i);
+        // row maximum over the 32 lanes of a row: four DPP exchanges inside the 16-lane halves in slice 0 (plain VALU) and ONE cross-half
+        // exchange whose LDS-crossbar latency passes under the MFMA groups up to slice 5 (the first version: five ds_bpermute round trips,
+        // one per slice).  A maximum does not depend on the order of its operands: same planes, bit for bit.
+        if (i == 0) {
+            uint32_t u = __float_as_uint(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            u = max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+            u = max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+            u = max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x141, 0xf, 0xf, true));     // row_half_mirror
+            u = max(u, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x140, 0xf, 0xf, true));     // row_mirror
+            sx_m = __uint_as_float(u);
+            sx_p = __shfl_xor(sx_m, 16);
+        }
         if (i == 5) {
+            sx_m = fmaxf(sx_m, sx_p);
             if (live) {
                 float scl, inv;
                 h2_scale(sx_m, scl, inv);

@@ -28,7 +28,7 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 FRAC_SLACK = 1.25       # observed <= 1.16 (profiles/r03_parity_errors.json)
-WORST_SLACK = 1.5       # observed <= 1.28 (as_c4: 7.2e-6 vs 4.5e-6, inside the 2e-6 floor): the single worst of up to 2e8 entries is an extreme-value statistic; round 2 allowed 2.0
+WORST_SLACK = 1.5       # observed <= 1.40: the single worst of up to 2e8 entries is an extreme-value statistic; round 2 allowed 2.0
 
 
 def _record(case, **numbers):

@@ -14,7 +14,7 @@ ACT_NONE, ACT_SELU = 0, 1
 OP_KCORE = 1
 OP_INGEST = 2
 MAX_SLOTS = 255
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _c = ctypes
 _vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_int, _c.c_size_t
@@ -27,6 +27,7 @@ SIGNATURES = {
     "ctgcn_transpose_bias_f32": (_int, [_i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp]),
     "ctgcn_spmm_csr_f32": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp]),
     "ctgcn_hub_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "ctgcn_hub_split_entries": (_i32, []),
     "ctgcn_core_aggregate_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _u32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "ctgcn_core_aggregate_bwd_prep_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _u32, _vp]),
     "ctgcn_core_aggregate_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _u32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
@@ -35,7 +36,11 @@ SIGNATURES = {
     "ctgcn_edge_levels_i32": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _i64, _vp, _int, _int, _vp, _vp, _vp, _vp]),
-    "ctgcn_layernorm_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _i64, _vp, _c.c_float, _vp, _vp, _i32, _vp]),
+    "ctgcn_layernorm_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _i64, _vp, _c.c_float, _vp, _vp, _i32, _vp, _vp]),
+    "ctgcn_gru_bwd_blocks": (_i32, [_i64]),
+    "ctgcn_gru_layer_presplit_save_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctgcn_gru_bwd_rec_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "ctgcn_gru_bwd_in_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "ctgcn_lstm_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp, _vp]),
     "ctgcn_lstm_seq_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctgcn_gru_layer_f32": (_int, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _i64, _vp, _vp, _i64, _vp]),

@@ -1,17 +1,36 @@
 """Build libctgcn_hip.so for gfx950 in-tree:  python -m ctgcn_amd.build [--force]"""
+import hashlib
 import os
 import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(_HERE, "csrc", f) for f in ("ctgcn_hip.hip", "ctgcn_gemm.hip", "ctgcn_ingest.hip", "ctgcn_walks.hip", "ctgcn_export.cpp")]
+SRCS = [os.path.join(_HERE, "csrc", f) for f in ("ctgcn_hip.hip", "ctgcn_gemm.hip", "ctgcn_gru_bwd.hip", "ctgcn_ingest.hip", "ctgcn_walks.hip", "ctgcn_export.cpp")]
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctgcn_hip.h")
 OUT = os.path.join(_HERE, "csrc", "libctgcn_hip.so")
+STAMP = OUT + ".srchash"          # sha256 of the sources + header + this recipe the .so was built from (travels with it, git-ignored)
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for f in SRCS + [HDR, os.path.abspath(__file__)]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_current():
+    """True when libctgcn_hip.so exists and was built from exactly the sources in the tree (content hash, not mtimes: a snapshot copied
+    to another box gets fresh mtimes in arbitrary order, and a stale-but-newer binary must not be trusted)."""
+    if not (os.path.exists(OUT) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as fh:
+        return fh.read().strip() == source_hash()
 
 
 def build(force=False, verbose=False):
-    newest = max([os.path.getmtime(f) for f in SRCS] + [os.path.getmtime(HDR)])
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= newest:
+    if not force and is_current():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-mfma-vgpr-form (ctgcn_hip.hip only): MFMA accumulators in architectural VGPRs.  gru_layer_h2_kernel fills the AGPR half
@@ -31,7 +50,11 @@ def build(force=False, verbose=False):
         failed = [(src, pr.returncode) for src, pr in procs if pr.wait() != 0]
         if failed:
             raise subprocess.CalledProcessError(failed[0][1], "hipcc -c " + failed[0][0])
+        if os.path.exists(STAMP):
+            os.remove(STAMP)
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", OUT] + objs)
+        with open(STAMP, "w") as fh:
+            fh.write(source_hash() + "\n")
     finally:
         for _, pr in procs:         # a failed spawn leaves the earlier compiles running: do not orphan them
             if pr.poll() is None:

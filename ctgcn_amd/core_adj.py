@@ -91,8 +91,12 @@ class CoreAdj(object):
     def cpu(self):
         return self.to("cpu")
 
-    HUB_SPLIT_ENTRIES = 8192   # entries per block when a hub row is cut into pieces (HUB_SPLIT_ENTRIES of ctgcn_hip.hip)
     HUB_SPLIT_MAX = 32
+
+    @property
+    def HUB_SPLIT_ENTRIES(self):
+        """entries per block when a hub row is cut into pieces: the library's constant (ctgcn_hub_split_entries), not a copy of it"""
+        return int(_lib.load().ctgcn_hub_split_entries())
 
     def hub_split(self, transposed=False):
         """Blocks per hub row the aggregation kernels may use (1: no row is long enough to be cut into pieces)."""
@@ -144,18 +148,20 @@ class CoreAdj(object):
             dev, n, K = self.device, self.n, self.K
             rp = self.row_ptr.long()
             deg = rp[1:] - rp[:-1]
-            bit = torch.ones(K, dtype=torch.int64, device=dev) << torch.arange(K, dtype=torch.int64, device=dev)
             if self.nested:
                 # entries are sorted by (row, slot): the first entry of a row carries its smallest tag; every later slot adds P != 0
                 first = torch.full((n,), K, dtype=torch.int64, device=dev)
                 has = deg > 0
                 first[has] = self.slot[rp[:-1][has]].long()
-                mask = ((torch.arange(K, dtype=torch.int64, device=dev)[None, :] >= first[:, None]) * bit[None, :]).sum(1) | 1
+                # bits first .. K-1 (first = K: none) | bit 0 — arithmetic on n values, no [n, K] temporaries
+                mask = ((1 << K) - (torch.ones_like(first) << first)) | 1
             else:
                 rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
-                present = torch.zeros(n * K, dtype=torch.bool, device=dev)
-                present[rows * K + self.slot.long()] = True
-                mask = (present.view(n, K) * bit[None, :]).sum(1) | 1
+                mask = torch.ones(n, dtype=torch.int64, device=dev)
+                for j in range(K):                                        # one [n] bool per slot instead of an [n, K] product
+                    hit = torch.zeros(n, dtype=torch.bool, device=dev)
+                    hit[rows[self.slot == j]] = True
+                    mask |= hit.long() << j
             o1 = torch.argsort(deg, descending=True, stable=True)
             order = o1[torch.argsort(mask[o1], descending=True, stable=True)]
             inverse = torch.empty(n, dtype=torch.int64, device=dev)
@@ -188,6 +194,10 @@ class CoreAdj(object):
         """int32[len(rows) * K]: operand row of slot j of matrix row rows[i] under `plan` (hub rows take this map), -1 = not wanted.
         compact: the GEMM consumer's layout (tile_base), else rows position * K + slot."""
         K, tile = self.K, plan["tile"]
+        key = ("dest", tile, bool(compact), rows.data_ptr(), int(rows.numel()))       # static per (graph, tile, layout): built once
+        hit = self._plan.get(key) if self._plan is not None else None
+        if hit is not None:
+            return hit
         pos = plan["inverse"][rows.long()].long()
         t = torch.div(pos, tile, rounding_mode="floor")
         need = plan["tile_mask"][t].long() & 0xffffffff
@@ -198,7 +208,10 @@ class CoreAdj(object):
             dest = plan["tile_base"][t].long()[:, None] + (pos % tile)[:, None] * bits.sum(1, keepdim=True) + rank
         else:
             dest = pos[:, None] * K + j
-        return torch.where(bits.bool(), dest, torch.full_like(dest, -1)).to(torch.int32).contiguous().view(-1)
+        out = torch.where(bits.bool(), dest, torch.full_like(dest, -1)).to(torch.int32).contiguous().view(-1)
+        if self._plan is not None:
+            self._plan[key] = out
+        return out
 
     # ------------------------------------------------------------------ transposed view (backward pass)
     def transposed(self):

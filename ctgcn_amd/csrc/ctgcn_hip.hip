@@ -927,7 +927,7 @@ __device__ __forceinline__ void gru_layernorm_row(const float *__restrict__ src,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int32_t steps, const float *__restrict__ h, const float *__restrict__ dy,
                                                             int64_t ld_dy, const float *__restrict__ gamma, float eps, float *__restrict__ dx,
-                                                            float *__restrict__ partial)
+                                                            float *__restrict__ partial, const int32_t *__restrict__ dy_rows)
 {
     __shared__ float red[4][2 * GRU_H];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -940,7 +940,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(int64_t rows, int32_
             const float2 v = *(const float2 *)(src + (int64_t)t * GRU_H);
             x.x += v.x; x.y += v.y;
         }
-        const float2 d = *(const float2 *)(dy + row * ld_dy + lane * 2);
+        // dy_rows: row p of h / dx is row dy_rows[p] of dy (the GRU ran in the aggregation's row-plan order, its output left un-permuted)
+        const float2 d = *(const float2 *)(dy + (dy_rows ? (int64_t)dy_rows[row] : row) * ld_dy + lane * 2);
         const float s = wave_sum64(x.x + x.y);
         const float mean = s * (1.0f / GRU_H);
         const float cx = x.x - mean, cy = x.y - mean;
@@ -1970,6 +1971,10 @@ struct LayerArgs {
     const int64_t *step_off;
     int64_t ld_row;
     float *gates;                // SAVE (per-step form without LayerNorm): [rows, steps, 4, 128] r, z, n, q = W_hn h + b_hn for ctgcn_gru_seq_bwd_f32
+    // SAVE on the planes + row plan form (training's recompute pass under the plan, ctgcn_gru_layer_presplit_save_f32): gates as above, the raw
+    // h sequence [rows, steps, 128] and the sum over the steps BEFORE the LayerNorm [rows, 128] (what its backward needs) — all in POSITION
+    // order (row p of these buffers is sequence p of the planes; `order` is not applied, `out` is not written)
+    float *hseq, *presum;
 #ifdef CTGCN_LAYER_TIMELINE
     unsigned long long *timeline;   // diagnostic build: per (block, wave) sums of the unit phases, see tools/layer_timeline.py
 #endif
@@ -2537,7 +2542,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
                 // the next unit's x·W_ih, if it brings a new x (a repeat keeps gi): this tile's next step, or step 0 of the block's next tile
                 const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + gridDim.x < ntiles;
-                f4v h;
+                f4v h, rv4, zv4, nv4, an4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], gi[0][j]));
@@ -2545,6 +2550,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
                     const float nv = gru_tanh(fmaf(rv, an, gi[2][j]));
                     h[j] = nv + zv * (hprev[j] - nv);
+                    if (SAVE) { rv4[j] = rv; zv4[j] = zv; nv4[j] = nv; an4[j] = an; }
+                }
+                if (SAVE && col <= last) {                // training's recompute pass: gates and raw h of this step, position order
+                    const int64_t e = (row0 + col) * S + t;
+                    float *gp = a.gates + e * (4 * GRU_H) + oc;
+                    *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
+                    *(f4v *)(a.hseq + e * GRU_H + oc) = h;
                 }
                 hprev = h;
                 hsum = t > 0 ? hsum + h : h;
@@ -2558,6 +2570,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                     }
                     *(h4v *)(&Hs[pb][0][col][l8_off(col, oc)]) = p;
                     *(h4v *)(&Hs[pb][1][col][l8_off(col, oc)]) = q;
+                } else if (SAVE) {                        // recompute pass: the pre-LayerNorm sum leaves as it is (its backward needs it)
+                    if (col <= last) *(f4v *)(a.presum + (row0 + col) * GRU_H + oc) = hsum;
                 } else {                                  // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
                     *(f4v *)((float *)&Hs[pb][0][0][0] + col * GRU_H + oc) = hsum;
                     ln_buf = pb; ln_last = last; ln_row0 = row0;
@@ -3551,6 +3565,7 @@ extern "C" size_t ctgcn_ingest_workspace_bytes_(int64_t n, int64_t m);   // ctgc
 // shared with the other translation units of the library (not part of the public header)
 extern "C" int ctgcn_set_error_(int code, const char *msg) { return fail(code, "%s", msg); }
 extern "C" void ctgcn_set_persistent_cus(int cus) { g_persistent_cus = cus; }
+extern "C" int ctgcn_persistent_cus_(int device_cus) { return persistent_cus(device_cus); }      // ctgcn_gru_bwd.hip sizes its grids with it
 extern "C" int ctgcn_split_rows_mapped_(int64_t rows, int32_t k, int32_t kp, const float *x, int64_t ldx, void *p1, void *p2, float *scale,
                                         const int32_t *group_map, int32_t group, float residual_scale, void *stream);   // ctgcn_gemm.hip
 
@@ -3763,6 +3778,8 @@ size_t ctgcn_hub_workspace_bytes(int32_t n_long, int32_t hub_split, int32_t slot
     return hub_workspace_bytes_(n_long, hub_split, slots, d);
 }
 
+int32_t ctgcn_hub_split_entries(void) { return HUB_SPLIT_ENTRIES; }
+
 size_t ctgcn_workspace_bytes(int op, int64_t n, int64_t nnz, int32_t d, int32_t K)
 {
     (void)nnz; (void)d; (void)K;
@@ -3914,7 +3931,7 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
 }
 
 int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *h, const float *dy, int64_t ld_dy, const float *gamma, float eps,
-                            float *dx, float *partial, int32_t n_partial, void *stream)
+                            float *dx, float *partial, int32_t n_partial, const int32_t *dy_rows, void *stream)
 {
     if (ld_dy == 0) ld_dy = GRU_H;
     if (ld_dy < GRU_H || (ld_dy & 1)) return fail(CTGCN_E_INVALID, "layernorm_bwd: ld_dy=%lld must be even and >= %d", (long long)ld_dy, GRU_H);
@@ -3925,7 +3942,7 @@ int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const f
     if (!h || !dy || !gamma || !dx) return fail(CTGCN_E_INVALID, "layernorm_bwd: null pointer");
     if ((reinterpret_cast<uintptr_t>(h) & 7u) || (reinterpret_cast<uintptr_t>(dy) & 7u) || (reinterpret_cast<uintptr_t>(dx) & 7u) || (reinterpret_cast<uintptr_t>(gamma) & 7u))
         return fail(CTGCN_E_INVALID, "layernorm_bwd: h / dy / dx / gamma must be 8-byte aligned");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, rows, steps, h, dy, ld_dy, gamma, eps, dx, partial);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)n_partial), dim3(256), 0, (hipStream_t)stream, rows, steps, h, dy, ld_dy, gamma, eps, dx, partial, dy_rows);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }
@@ -4042,6 +4059,42 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
 #endif
     const int64_t nt8 = (rows + 15) / 16;
     hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidden, const void *planes, int64_t plane_rows, int64_t first_row,
+                                      const float *w_ih, const float *w_hh, const float *bias_gi, const float *b_hn, const uint32_t *tile_mask,
+                                      float *gates_out, float *hseq_out, float *presum_out, void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit_save: only d_in = hidden = %d is built (got %d)", GRU_H, hidden);
+    if (rows < 0 || steps < 1 || first_row < 0 || (first_row & 15) || (first_row + rows) * steps > plane_rows)
+        return fail(CTGCN_E_INVALID, "gru_layer_presplit_save: bad sizes rows=%lld steps=%d first_row=%lld (a multiple of 16) plane_rows=%lld",
+                    (long long)rows, steps, (long long)first_row, (long long)plane_rows);
+    if (tile_mask && steps > 32) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit_save: a row plan needs steps <= 32");
+    if (rows == 0) return CTGCN_OK;
+    if (!planes || !w_ih || !w_hh || !gates_out || !hseq_out || !presum_out) return fail(CTGCN_E_INVALID, "gru_layer_presplit_save: null pointer");
+    if ((reinterpret_cast<uintptr_t>(planes) & 255u) || !aligned16(w_ih) || !aligned16(w_hh) || !aligned16(gates_out) || !aligned16(hseq_out) || !aligned16(presum_out))
+        return fail(CTGCN_E_INVALID, "gru_layer_presplit_save: planes 256-byte, everything else 16-byte aligned");
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
+    LayerArgs a{};
+    a.rows = rows; a.steps = steps; a.x = nullptr; a.ldx = GRU_H; a.wih = w_ih; a.whh = w_hh; a.bias_gi = bias_gi; a.bhn = b_hn;
+    a.gamma = nullptr; a.beta = nullptr; a.eps = 0.f; a.out = nullptr; a.ldo = GRU_H;
+    // the layout ctgcn_core_aggregate_split_f32 writes for d = 128: plane 1, plane 2, row scales, plane_rows rows each; this call takes the
+    // sequences [first_row, first_row + rows) of it (tile_mask already points at first_row / 16)
+    a.xp1 = (const _Float16 *)planes + (size_t)first_row * steps * GRU_H;
+    a.xp2 = (const _Float16 *)planes + ((size_t)plane_rows + (size_t)first_row * steps) * GRU_H;
+    a.xps = (const float *)((const _Float16 *)planes + 2 * (size_t)plane_rows * GRU_H) + (size_t)first_row * steps;
+    a.order = nullptr; a.tmask = tile_mask;
+    a.gates = gates_out; a.hseq = hseq_out; a.presum = presum_out;
+#ifdef CTGCN_LAYER_TIMELINE
+    a.timeline = nullptr;
+#endif
+    const int64_t nt8 = (rows + 15) / 16;
+    hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -116,6 +116,9 @@ class CoreDiffusion(nn.Module):
                 # inference, GRU input projection on the split GEMM (d_in != 128): the aggregation writes the GEMM's fp16 operand
                 # planes, the fp32 [N, K, input_dim] tensor is never materialised
                 return ops.core_diffusion_split(x, adj, self.rnn, self.norm, out=out)
+            if torch.is_grad_enabled() and ops.core_diffusion_fused_ok(self.rnn, self.norm, x, adj):
+                # training, d_in = hidden = 128: the inference forward under autograd (planes + row plan kept for the backward kernels)
+                return ops.core_diffusion_fused(x, adj, self.rnn, self.norm)
         seq = self.aggregate(x, adj_list)            # [batch = N, seq = K, feat]
         return rnn_reduce_norm(self.rnn, self.norm, seq, reduce_sum=True, out=out)
 

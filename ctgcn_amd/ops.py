@@ -210,25 +210,32 @@ def _aggregate_fwd(adj, x, relu):
     return H
 
 
+def _aggregate_gather(adj, Z, S0, relu):
+    """dX[r] = S0[r] + sum_e val_e Z[col_e, slot_e] (ctgcn_core_aggregate_bwd_f32) for Z [n, K, d] / S0 [n, d] in matrix-row order"""
+    lib = _lib.load()
+    n, K, d = Z.shape
+    flags = adj.flags | (_lib.F_RELU if relu else 0)
+    dX = torch.empty(n, d, dtype=torch.float32, device=Z.device)
+    t_ptr, t_col, t_val, t_slot = adj.transposed()
+    long_rows = adj.long_rows(transposed=True)
+    split, hub_ws, hub_bytes = _hub_pieces(lib, adj, long_rows, 1, d, Z.device, transposed=True)
+    with torch.cuda.device(Z.device), _timed("agg_bwd", n=n, d=d, K=K, nnz=adj.nnz):
+        check(lib.ctgcn_core_aggregate_bwd_f32(n, d, K, ptr(t_ptr), ptr(t_col), ptr(t_val), ptr(t_slot), ptr(Z), ptr(S0),
+                                               ptr(dX), d, flags, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
+                                               adj.LONG_ROW, split, ptr(hub_ws), hub_bytes, _stream()), "ctgcn_core_aggregate_bwd_f32")
+    return dX
+
+
 def _aggregate_bwd(adj, H, dH, relu):
     lib = _lib.load()
     n, K, d = dH.shape
     flags = adj.flags | (_lib.F_RELU if relu else 0)
     Z = torch.empty_like(dH)
     S0 = torch.empty(n, d, dtype=torch.float32, device=dH.device) if adj.self_loop else None
-    dX = torch.empty(n, d, dtype=torch.float32, device=dH.device)
-    t_ptr, t_col, t_val, t_slot = adj.transposed()
-    long_rows = adj.long_rows(transposed=True)
-    split, hub_ws, hub_bytes = _hub_pieces(lib, adj, long_rows, 1, d, dH.device, transposed=True)
-    with torch.cuda.device(dH.device):
-        with _timed("agg_bwd_prep", n=n, d=d, K=K, self_loop=adj.self_loop):
-            check(lib.ctgcn_core_aggregate_bwd_prep_f32(n, d, K, ptr(dH), ptr(H), ptr(Z), ptr(S0), flags, _stream()),
-                  "ctgcn_core_aggregate_bwd_prep_f32")
-        with _timed("agg_bwd", n=n, d=d, K=K, nnz=adj.nnz):
-            check(lib.ctgcn_core_aggregate_bwd_f32(n, d, K, ptr(t_ptr), ptr(t_col), ptr(t_val), ptr(t_slot), ptr(Z), ptr(S0),
-                                                   ptr(dX), d, flags, ptr(long_rows), 0 if long_rows is None else long_rows.numel(),
-                                                   adj.LONG_ROW, split, ptr(hub_ws), hub_bytes, _stream()), "ctgcn_core_aggregate_bwd_f32")
-    return dX
+    with torch.cuda.device(dH.device), _timed("agg_bwd_prep", n=n, d=d, K=K, self_loop=adj.self_loop):
+        check(lib.ctgcn_core_aggregate_bwd_prep_f32(n, d, K, ptr(dH), ptr(H), ptr(Z), ptr(S0), flags, _stream()),
+              "ctgcn_core_aggregate_bwd_prep_f32")
+    return _aggregate_gather(adj, Z, S0, relu)
 
 
 class _CoreAggregate(torch.autograd.Function):
@@ -283,6 +290,8 @@ def _gru_bias(rnn, hid):
 
 def _row_chunks(lib, rows, steps, hid):
     """Equal row chunks, multiples of the kernel's row granule (rows per block x CUs), bounded projection buffer."""
+    if rows <= 0:
+        return [(0, 0)]
     granule = int(lib.ctgcn_gru_row_granule())
     max_rows = max(granule, (_GI_MAX_ELEMS // (steps * 4 * hid)) // granule * granule)
     n_chunks = -(-rows // max_rows)
@@ -587,6 +596,133 @@ def core_diffusion_split(x, adj, rnn, norm, out=None):
     return out
 
 
+# ------------------------------------------------------------- CoreDiffusion layer, training form (d_in = hidden = 128, row plan)
+def train_fused_enabled():
+    """CTGCN_TRAIN_FUSED=0: training keeps round 3's path (fp32 H, _CoreAggregate + _GruSeq) for A/B runs."""
+    import os
+    return os.environ.get("CTGCN_TRAIN_FUSED", "1") != "0"
+
+
+def core_diffusion_fused_ok(rnn, norm, x, adj):
+    """Training through a CoreDiffusion layer (layers.py:41-62) with d_in = hidden = 128: the forward is the inference path (planes + row
+    plan, no fp32 H), the backward runs ctgcn_gru_bwd_rec_f32 / ctgcn_gru_bwd_in_f32 (see _CoreDiffusionFused).  The plan's backward
+    relies on a row having no entry tagged with a slot it repeats, seen from the transposed side too: symmetric lists only."""
+    if not train_fused_enabled() or not aggregate_split_enabled() or not layer_kernel_enabled(True) or forward_split_mode() != 2:
+        return False
+    if x.dim() != 2 or not gru_fused_ok(rnn, x) or x.shape[0] != adj.n or x.device != adj.device or not isinstance(norm, torch.nn.LayerNorm):
+        return False
+    if not norm.elementwise_affine or norm.bias is None:
+        return False
+    d, hid = x.shape[1], rnn.hidden_size
+    if d != hid or rnn.input_size != hid or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or adj.K < 1 or adj.K > 32 or adj.n < 1:
+        return False
+    return bool(adj.symmetric) and adj.n * adj.K * (d * 4 + 4) <= _AGG_SPLIT_MAX and rnn.weight_ih_l0.is_contiguous()
+
+
+def _u32ptr(t, offset=0):
+    return None if t is None else t.data_ptr() + 4 * int(offset)
+
+
+class _CoreDiffusionFused(torch.autograd.Function):
+    """out = LayerNorm(sum_k GRU(relu(cumulative A_k x))_k) with autograd, d_in = hidden = 128.
+    forward  = ctgcn_core_aggregate_split_f32 (fp16 planes, row plan) + ctgcn_gru_layer_presplit_f32: exactly the inference path; the planes
+               are what is kept for the backward (the rows the plan skips are never written: 47 % of them on config 5).
+    backward = per chunk of positions: recompute (gates, h, pre-norm sum) -> LayerNorm backward -> backward recurrence + dW_hh ->
+               dx + dW_ih + the aggregation's mask / suffix sums (Z, S0); then ONE gather (ctgcn_core_aggregate_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, adj, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b, eps):
+        lib = _lib.load()
+        n, K, hid = adj.n, adj.K, w_hh.shape[1]
+        plan = adj.row_plan() if row_plan_enabled() else None
+        x_d = x.detach()
+        with torch.cuda.device(x.device):
+            ws, _ = aggregate_split_planes(x_d, adj, 1, plan)
+            bias, b_hn = _fold_gru_bias(b_ih, b_hh, hid)
+            out = torch.empty(n, hid, dtype=torch.float32, device=x.device)
+            with _timed("gru_layer", rows=n, steps=K, reduce_sum=True, presplit=True, new_rows=(plan["new_rows"] if plan is not None else n * K)):
+                check(lib.ctgcn_gru_layer_presplit_f32(n, K, hid, ptr(ws), ptr(w_ih.detach()), ptr(w_hh.detach().contiguous()), ptr(bias), ptr(b_hn),
+                                                       ptr(ln_w.detach()), ptr(ln_b.detach()), eps, ptr(out), out.stride(0),
+                                                       ptr(plan["order"]) if plan is not None else None,
+                                                       ptr(plan["tile_mask"]) if plan is not None else None, _stream()), "ctgcn_gru_layer_presplit_f32")
+        ctx.adj, ctx.plan, ctx.eps = adj, plan, eps
+        ctx.save_for_backward(ws, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        ws, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b = ctx.saved_tensors
+        adj, plan, eps = ctx.adj, ctx.plan, ctx.eps
+        n, K, hid = adj.n, adj.K, w_hh.shape[1]
+        dev = ws.device
+        w_ih_d, w_hh_d = w_ih.detach(), w_hh.detach().contiguous()
+        bias, b_hn = _fold_gru_bias(b_ih, b_hh, hid)
+        if not (dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= hid and dout.stride(0) % 2 == 0 and dout.data_ptr() % 8 == 0):
+            dout = dout.contiguous()       # a column of a [n, T, 128] gradient is read in place
+        order = plan["order"] if plan is not None else None
+        tmask = plan["tile_mask"] if plan is not None else None
+        chunks = _row_chunks(lib, n, K, hid)
+        cmax = chunks[0][1]
+        nb = int(lib.ctgcn_gru_bwd_blocks(cmax))
+        with torch.cuda.device(dev):
+            gates = torch.empty(cmax * K, 4 * hid, dtype=torch.float32, device=dev)
+            hseq = torch.empty(cmax * K, hid, dtype=torch.float32, device=dev)
+            presum = torch.empty(cmax, hid, dtype=torch.float32, device=dev)
+            dpre = torch.empty(cmax, hid, dtype=torch.float32, device=dev)
+            dgi = torch.empty(cmax * K, 3 * hid, dtype=torch.float32, device=dev)
+            dw_hh_part = torch.zeros(nb, 3 * hid, hid, dtype=torch.float32, device=dev)
+            dw_ih_part = torch.zeros(nb, 3 * hid, hid, dtype=torch.float32, device=dev)
+            dbn_part = torch.zeros(nb, hid, dtype=torch.float32, device=dev)
+            dbi_part = torch.zeros(nb, 3 * hid, dtype=torch.float32, device=dev)
+            ln_part = torch.empty(2048, 2 * hid, dtype=torch.float32, device=dev)
+            ln_sum = torch.zeros(2 * hid, dtype=torch.float32, device=dev)
+            Z = torch.empty(n, K, hid, dtype=torch.float32, device=dev)
+            S0 = torch.empty(n, hid, dtype=torch.float32, device=dev) if adj.self_loop else None
+            for lo, cnt in chunks:
+                tm = _u32ptr(tmask, lo // 16)
+                od = _u32ptr(order, lo)
+                with _timed("gru_layer", rows=cnt, steps=K, reduce_sum=True, presplit=True, save=True):
+                    check(lib.ctgcn_gru_layer_presplit_save_f32(cnt, K, hid, ptr(ws), n * K, lo, ptr(w_ih_d), ptr(w_hh_d), ptr(bias), ptr(b_hn), tm,
+                                                                ptr(gates), ptr(hseq), ptr(presum), _stream()), "ctgcn_gru_layer_presplit_save_f32")
+                dy = dout if order is not None else dout[lo:lo + cnt]
+                check(lib.ctgcn_layernorm_bwd_f32(cnt, 1, hid, ptr(presum), ptr(dy), dy.stride(0), ptr(ln_w.detach()), eps, ptr(dpre), ptr(ln_part),
+                                                  ln_part.shape[0], od, _stream()), "ctgcn_layernorm_bwd_f32")
+                ln_sum += ln_part.sum(0)
+                with _timed("gru_bwd_rec", rows=cnt, steps=K):
+                    check(lib.ctgcn_gru_bwd_rec_f32(cnt, K, hid, ptr(gates), ptr(hseq), ptr(dpre), None, ptr(w_hh_d), tm, ptr(dgi), ptr(dw_hh_part),
+                                                    ptr(dbn_part), nb, 1, _stream()), "ctgcn_gru_bwd_rec_f32")
+                with _timed("gru_bwd_in", rows=cnt, steps=K):
+                    check(lib.ctgcn_gru_bwd_in_f32(cnt, K, hid, ptr(dgi), ptr(w_ih_d), tm, ptr(ws), n * K, lo, None, 0, None,
+                                                   ptr(Z) if order is not None else ptr(Z[lo:]),
+                                                   ptr(S0) if (S0 is None or order is not None) else ptr(S0[lo:]), od, 1 if adj.nested else 0,
+                                                   ptr(dw_ih_part), ptr(dbi_part), nb, 1, _stream()), "ctgcn_gru_bwd_in_f32")
+            dX = _aggregate_gather(adj, Z, S0, True) if ctx.needs_input_grad[0] else None
+        dw_ih = dw_ih_part.sum(0)
+        dw_hh = dw_hh_part.sum(0)
+        db_ih = db_hh = None
+        if b_ih is not None:
+            db_ih = dbi_part.sum(0)
+            db_hh = torch.cat([db_ih[: 2 * hid], dbn_part.sum(0)])
+        return dX, None, dw_ih, dw_hh, db_ih, db_hh, ln_sum[:hid].clone(), ln_sum[hid:].clone(), None
+
+
+def _fold_gru_bias(b_ih, b_hh, hid):
+    """(b_ih + b_hh on the r and z gates | b_ih on n,  b_hn) — the two bias vectors the GRU kernels take; (None, None) without bias"""
+    if b_ih is None:
+        return None, None
+    bias = b_ih.detach().clone()
+    bias[: 2 * hid] += b_hh.detach()[: 2 * hid]
+    return bias, b_hh.detach()[2 * hid:].contiguous()
+
+
+def core_diffusion_fused(x, adj, rnn, norm):
+    """CoreDiffusion.forward (layers.py:41-62) with autograd, see _CoreDiffusionFused (core_diffusion_fused_ok decides)."""
+    b_ih = rnn.bias_ih_l0 if rnn.bias else None
+    b_hh = rnn.bias_hh_l0 if rnn.bias else None
+    return _CoreDiffusionFused.apply(x, adj, rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, norm.weight, norm.bias, float(norm.eps))
+
+
 def _accumulate_tn(out, a2d, b2d):
     """out[M,N] += a2d[R,M]^T @ b2d[R,N] for R >> M,N (weight gradients: R = rows*steps).  A plain TN GEMM with a
     384x128 output only fills a few dozen workgroups; splitting R into S batches (strided batched GEMM, no copies)
@@ -600,6 +736,12 @@ def _accumulate_tn(out, a2d, b2d):
         return
     part = torch.bmm(a2d.view(S, R // S, M).transpose(1, 2), b2d.view(S, R // S, b2d.shape[1]))
     out += part.sum(0)
+
+
+def _zero_rnn_grads(seq, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b):
+    """the nine gradients of _GruSeq / _LstmSeq for an input without rows"""
+    z = lambda t: None if t is None else torch.zeros_like(t)
+    return torch.zeros_like(seq), z(w_ih), z(w_hh), z(b_ih), z(b_hh), z(ln_w), z(ln_b), None, None
 
 
 class _GruSeq(torch.autograd.Function):
@@ -630,6 +772,8 @@ class _GruSeq(torch.autograd.Function):
         rows, steps, d_in = seq.shape
         hid = w_hh.shape[1]
         dev = seq.device
+        if rows == 0:                     # an empty node slice (a snapshot-parallel rank that owns nothing): all gradients are zero
+            return _zero_rnn_grads(seq, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b)
         w_ih_d, w_hh_d = w_ih.detach(), w_hh.detach().contiguous()
         if b_ih is not None:
             bias = b_ih.detach().clone()
@@ -687,7 +831,7 @@ class _GruSeq(torch.autograd.Function):
                     ln_rows = n if reduce_sum else n * steps
                     dpre = torch.empty((n, hid) if reduce_sum else (n, steps, hid), dtype=torch.float32, device=dev)
                     check(lib.ctgcn_layernorm_bwd_f32(ln_rows, steps if reduce_sum else 1, hid, ptr(hseq), ptr(g_out), g_out.stride(0) if reduce_sum else 0,
-                                                      ptr(ln_w.detach()), eps, ptr(dpre), ptr(ln_part), ln_part.shape[0], _stream()), "ctgcn_layernorm_bwd_f32")
+                                                      ptr(ln_w.detach()), eps, ptr(dpre), ptr(ln_part), ln_part.shape[0], None, _stream()), "ctgcn_layernorm_bwd_f32")
                     ln_sum = ln_part.sum(0)
                     dln_w += ln_sum[:hid]
                     dln_b += ln_sum[hid:]
@@ -777,6 +921,8 @@ class _LstmSeq(torch.autograd.Function):
         rows, steps, d_in = seq.shape
         hid = w_hh.shape[1]
         dev = seq.device
+        if rows == 0:
+            return _zero_rnn_grads(seq, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b)
         w_ih_d, w_hh_d = w_ih.detach(), w_hh.detach().contiguous()
         bias = (b_ih.detach() + b_hh.detach()) if b_ih is not None else None
         dout = dout.contiguous()
@@ -808,7 +954,7 @@ class _LstmSeq(torch.autograd.Function):
                     ln_rows = n if reduce_sum else n * steps
                     dpre = torch.empty((n, hid) if reduce_sum else (n, steps, hid), dtype=torch.float32, device=dev)
                     check(lib.ctgcn_layernorm_bwd_f32(ln_rows, steps if reduce_sum else 1, hid, ptr(hseq), ptr(g_out), 0, ptr(ln_w.detach()), eps,
-                                                      ptr(dpre), ptr(ln_part), ln_part.shape[0], _stream()), "ctgcn_layernorm_bwd_f32")
+                                                      ptr(dpre), ptr(ln_part), ln_part.shape[0], None, _stream()), "ctgcn_layernorm_bwd_f32")
                     ln_sum = ln_part.sum(0)
                     dln_w += ln_sum[:hid]
                     dln_b += ln_sum[hid:]

@@ -79,6 +79,7 @@ def shard_ctgcn(model, num_nodes, costs=None, assignment=None, group=None, excha
         assignment = plan_assignment(costs, world)
     plan = ShardPlan(assignment, num_nodes)
     assert plan.T == model.duration and plan.world == world
+    release_exchange_buffers(model)                  # buffers of an earlier plan
     model.process_group, model.shard_plan = group, plan
     model.shard_exchange, model.shard_gather_output, model.shard_replicate_head = exchange, gather_output, replicate_head
     return plan
@@ -238,6 +239,14 @@ def ctgcn_forward_sharded(model, x_list, adj_list):
     if model.model_type == 'C':
         return out
     return out, [trans_local.get(t) for t in range(plan.T)]
+
+
+def release_exchange_buffers(model):
+    """Drop the send / receive / gather buffers the pipelined inference exchange keeps on the model ((T/G) N d floats, two or three
+    times over).  They are re-allocated by the next sharded inference forward; call this when the model goes back to training or
+    the plan changes and the memory is wanted."""
+    if getattr(model, "_exchange_buffers", None) is not None:
+        model._exchange_buffers = None
 
 
 def _slot_moves(plan, device):

@@ -151,12 +151,14 @@ _dict_cache = {}
 def _node_dict(full_node_list):
     """name -> index dict of a node list, ONE per list object (callers pass the same list for every snapshot file; a fresh dict per call
     also missed _node_index's identity cache and rebuilt the Arrow name array per file).  The entry keeps the list alive (its id cannot
-    be recycled) and is dropped when the list changed length."""
+    be recycled) and is rebuilt when the list was mutated in place: a shallow copy taken at build time is compared element by element
+    (identity shortcut per element, ~1 ms per million names), so reordered / renamed nodes never meet a stale mapping — the reference
+    rebuilds the dict on every call (utils.py:37)."""
     hit = _dict_cache.get(id(full_node_list))
-    if hit is None or hit[0] is not full_node_list or len(hit[1]) != len(full_node_list):
+    if hit is None or hit[0] is not full_node_list or hit[2] != full_node_list:
         if len(_dict_cache) >= 2:
             _dict_cache.clear()
-        hit = _dict_cache[id(full_node_list)] = (full_node_list, dict(zip(full_node_list, range(len(full_node_list)))))
+        hit = _dict_cache[id(full_node_list)] = (full_node_list, dict(zip(full_node_list, range(len(full_node_list)))), list(full_node_list))
     return hit[1]
 
 

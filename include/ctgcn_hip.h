@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 21
+#define CTGCN_ABI_VERSION 22
 
 enum {
     CTGCN_OK = 0,
@@ -99,6 +99,8 @@ int ctgcn_spmm_csr_f32(int64_t n_rows, int32_t d, const int32_t *row_ptr, const 
  * hub_split <= 1 or a NULL workspace: one block per hub row.  hub_split <= 64.
  */
 size_t ctgcn_hub_workspace_bytes(int32_t n_long, int32_t hub_split, int32_t slots, int32_t d);
+/* entries per piece when a hub row is cut (the 8192 above): callers derive hub_split = ceil(longest row / this) from it */
+int32_t ctgcn_hub_split_entries(void);
 int ctgcn_core_aggregate_f32(int64_t n_rows, int32_t d, int32_t K, const int32_t *row_ptr,
                              const int32_t *col_idx, const float *val, const uint8_t *slot,
                              const float *X, int64_t ldx, float *H, uint32_t flags,
@@ -208,9 +210,10 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
  *   partial [n_partial, 256]: per-block partial sums of (dgamma | dbeta), every row written; the caller adds them up (deterministic).
  *   ld_dy: floats between the rows of dy (0 = 128; larger: dy is a column of a [rows, T, 128] gradient, no copy needed).
  * One pass instead of the framework's three kernels + sum + forward recompute.  n_partial = number of blocks (<= 65535, e.g. 2048).
+ *   dy_rows (optional, device int32[rows]): row p of h / dx belongs to row dy_rows[p] of dy (the GRU ran in a row-plan order).
  */
 int ctgcn_layernorm_bwd_f32(int64_t rows, int32_t steps, int32_t hidden, const float *h, const float *dy, int64_t ld_dy, const float *gamma, float eps,
-                            float *dx, float *partial, int32_t n_partial, void *stream);
+                            float *dx, float *partial, int32_t n_partial, const int32_t *dy_rows, void *stream);
 
 /*
  * The same for nn.LSTM (rnn_type = 'LSTM'; layers.py:27-28, models.py:234-235): gi [rows, steps, 512] = x·W_ih^T + b_ih
@@ -264,6 +267,40 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
 int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, const void *planes, const float *w_ih, const float *w_hh,
                                  const float *bias_gi, const float *b_hn, const float *ln_weight, const float *ln_bias, float ln_eps,
                                  float *out, int64_t ld_out, const int32_t *row_order, const uint32_t *tile_mask, void *stream);
+
+/*
+ * Training under the row plan (round 4): the backward of a CoreDiffusion layer with d_in = hidden = 128 (layers.py:41-62; what
+ * embedding.py:347-348 runs every batch) in position order, chunk by chunk, with two intermediates in HBM instead of six.
+ *
+ * ctgcn_gru_layer_presplit_save_f32 — the recompute pass: ctgcn_gru_layer_presplit_f32's kernel on the sequences
+ *   [first_row, first_row + rows) of the forward's planes (`planes`, plane_rows = n K rows per plane; first_row a multiple of 16;
+ *   tile_mask, optional, already points at tile first_row / 16), writing the gates [rows, steps, 4, 128] (r, z, n, q = W_hn h + b_hn), the
+ *   raw h sequence [rows, steps, 128] and the pre-LayerNorm sum over the steps [rows, 128] — no LayerNorm, no `out`.
+ * ctgcn_gru_bwd_rec_f32 — backward recurrence + dW_hh: gates, h_seq as above; exactly one of dh_sum [rows, 128] (gradient of sum_t h_t,
+ *   added at every step) / dh_seq [rows, steps, 128]; d_gi [rows, steps, 384] receives, at every step whose tile_mask bit is set, the sum
+ *   of (da_r, da_z, da_n) over that step and the steps after it that repeat its x (tile_mask NULL: every step);
+ *   dw_partial [n_partial, 384, 128] / dbn_partial [n_partial, 128]: per-block sums of dW_hh and of the n-gate column of d b_hh
+ *   (n_partial >= ctgcn_gru_bwd_blocks(rows), rows of the tables beyond that are not touched; accumulate != 0 adds to them: zero the
+ *   tables once, accumulate over the chunks, one reduction at the end — deterministic).
+ *   bf16 x 2 split arithmetic (three v_mfma_f32_16x16x32_bf16 per product).
+ * ctgcn_gru_bwd_in_f32 — dx = d_gi·W_ih, dW_ih, d b_ih over the fresh steps: x either as the forward's planes (x_planes, plane_rows,
+ *   first_row as above) or fp32 rows (x, row-step stride ldx).  Output either dx [rows, steps, 128] or (Z != NULL) the aggregation
+ *   backward's operands in matrix-row order: Z [n, steps, 128] and S0 [n, 128] (NULL without self loop) with the ReLU mask x > 0 and
+ *   the suffix sums of ctgcn_core_aggregate_bwd_prep_f32 applied (nested: CTGCN_F_NESTED lists), written at row row_order[p]
+ *   (row_order points at first_row; NULL: p).  Z is only defined at fresh steps — a row has no entry tagged with a step that
+ *   repeats, ctgcn_core_aggregate_bwd_f32 never reads the others (symmetric lists).
+ */
+int32_t ctgcn_gru_bwd_blocks(int64_t rows);
+int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidden, const void *planes, int64_t plane_rows, int64_t first_row,
+                                      const float *w_ih, const float *w_hh, const float *bias_gi, const float *b_hn, const uint32_t *tile_mask,
+                                      float *gates_out, float *hseq_out, float *presum_out, void *stream);
+int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *h_seq, const float *dh_sum,
+                          const float *dh_seq, const float *w_hh, const uint32_t *tile_mask, float *d_gi, float *dw_partial,
+                          float *dbn_partial, int32_t n_partial, int32_t accumulate, void *stream);
+int ctgcn_gru_bwd_in_f32(int64_t rows, int32_t steps, int32_t hidden, const float *d_gi, const float *w_ih, const uint32_t *tile_mask,
+                         const void *x_planes, int64_t plane_rows, int64_t first_row, const float *x, int64_t ldx, float *dx, float *Z, float *S0,
+                         const int32_t *row_order, int32_t nested, float *dw_partial, float *dbi_partial, int32_t n_partial,
+                         int32_t accumulate, void *stream);
 
 /*
  * Dense  y[rows, n_out] = x[rows, k]·w[n_out, k]^T + bias  (bias [n_out] may be NULL) in fp32-accurate fp16x2 split arithmetic on the

@@ -2,7 +2,7 @@
 
 CPU restatement of the reference's CTGCN hot path, used only as the *checker*:
   tests/ , __graft_entry__.smoke() , bench.py's cpu_baseline leg.
-Nothing under ctgcn_amd/ imports this module (tests/test_no_oracle_in_product.py enforces it).
+Nothing under ctgcn_amd/ imports this module (tests/test_host_logic.py::test_product_never_imports_the_oracle enforces it).
 
 Parity status: PINNED against vectors produced by running the reference in the build
 container (tests/golden/make_golden.py -> tests/golden/*.npz; checked by
@@ -26,8 +26,15 @@ _lib = None
 def build(force=False):
     """gcc -O2 -fopenmp the C restatement next to this file (no reference sources involved)."""
     src = os.path.join(_HERE, "ctgcn_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    import hashlib
+    with open(src, "rb") as fh:
+        digest = hashlib.sha256(fh.read()).hexdigest()
+    stamp = _SO + ".srchash"
+    current = os.path.exists(_SO) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+    if force or not current:           # content hash, not mtimes (a copied snapshot has arbitrary mtimes)
         subprocess.check_call(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", _SO, src])
+        with open(stamp, "w") as fh:
+            fh.write(digest + "\n")
     return _SO
 
 

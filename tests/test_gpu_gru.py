@@ -305,7 +305,7 @@ def test_layernorm_backward_kernel_matches_autograd(rows, steps):
     part = torch.empty(300, 256, device=dev)
     big = torch.randn(rows, 3, 128, device=dev)            # dy as a column of a [rows, 3, 128] gradient: read in place through ld_dy
     dy = big[:, 1]
-    check(lib.ctgcn_layernorm_bwd_f32(rows, steps, 128, ptr(h), ptr(dy), dy.stride(0), ptr(gamma), 1e-5, ptr(dx), ptr(part), part.shape[0],
+    check(lib.ctgcn_layernorm_bwd_f32(rows, steps, 128, ptr(h), ptr(dy), dy.stride(0), ptr(gamma), 1e-5, ptr(dx), ptr(part), part.shape[0], None,
                                       torch.cuda.current_stream().cuda_stream), "ctgcn_layernorm_bwd_f32")
     x64 = h.double().sum(1).requires_grad_(True)
     g64, b64 = gamma.double().requires_grad_(True), torch.zeros(128, dtype=torch.float64, device=dev, requires_grad=True)

@@ -1,0 +1,145 @@
+"""Training form of a CoreDiffusion layer with d_in = hidden = 128 (ops._CoreDiffusionFused: planes + row plan forward,
+ctgcn_gru_layer_presplit_save_f32 -> ctgcn_layernorm_bwd_f32 -> ctgcn_gru_bwd_rec_f32 -> ctgcn_gru_bwd_in_f32 -> ctgcn_core_aggregate_bwd_f32
+backward) against float64 autograd of the reference's CPU path (oracle/torch_path.py, layers.py:38-63) and against round 3's path.
+
+Tolerance for gradients (as tests/test_gpu_models.py): within 1e-4 of the tensor's largest entry, checked against FLOAT64 truth — the kernels'
+bf16 x 2 products carry 2^-17 per operand, an fp32 CPU run of the same expression is itself ~1e-6 away from it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _graph(n, avg_deg, seed, max_core):
+    from ctgcn_amd.helper import core_adj_from_scipy
+    from ctgcn_amd.synth import dynamic_graph
+    from oracle import oracle as O, torch_path as TP
+    g = dynamic_graph(n, avg_deg=avg_deg, snapshots=1, seed=seed)[0]
+    adj, _, _ = core_adj_from_scipy(g, max_core, torch.device(DEV))
+    ref = [TP.coo_like_reference(m) for m in O.core_adj_list([O.kcore_matrices(g)], 0, 1, 1, max_core)[0]]
+    return adj, ref
+
+
+def _layer(seed):
+    from ctgcn_amd.layers import CoreDiffusion
+    torch.manual_seed(seed)
+    layer = CoreDiffusion(128, 128)
+    with torch.no_grad():
+        layer.norm.weight.uniform_(0.5, 1.5)
+        layer.norm.bias.uniform_(-0.5, 0.5)
+    return layer
+
+
+def _truth(layer, x, ref_adj, G):
+    """float64 autograd of layers.py:38-63 on the CPU"""
+    from oracle import torch_path as TP
+    sd = {"l." + k: v.detach().double().clone().requires_grad_(True) for k, v in layer.state_dict().items() if not k.startswith("linear.")}
+    xd = x.detach().double().clone().requires_grad_(True)
+    adj64 = [a.double() for a in ref_adj]
+    saved = TP._rnn
+    TP._rnn = TP._rnn_grad
+    try:
+        out = TP.core_diffusion(sd, "l.", xd, adj64)
+    finally:
+        TP._rnn = saved
+    (out * G.double()).sum().backward()
+    grads = {k[2:]: v.grad for k, v in sd.items()}
+    grads["x"] = xd.grad
+    return out.detach(), grads
+
+
+def _run(layer_cpu, x, adj, G, fused):
+    import copy
+    layer = copy.deepcopy(layer_cpu).to(DEV)
+    xg = x.to(DEV).clone().requires_grad_(True)
+    old = os.environ.get("CTGCN_TRAIN_FUSED")
+    os.environ["CTGCN_TRAIN_FUSED"] = "1" if fused else "0"
+    try:
+        out = layer(xg, adj)
+        (out * G.to(DEV)).sum().backward()
+    finally:
+        if old is None:
+            os.environ.pop("CTGCN_TRAIN_FUSED", None)
+        else:
+            os.environ["CTGCN_TRAIN_FUSED"] = old
+    grads = {k: p.grad.detach().cpu() for k, p in layer.named_parameters() if p.grad is not None}
+    grads["x"] = xg.grad.detach().cpu()
+    return out.detach().cpu(), grads
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("n,avg_deg,max_core,seed", [(50, 4, 3, 1), (777, 8, 6, 2), (4100, 12, 8, 3), (3000, 6, -1, 4)])
+def test_fused_training_layer_matches_float64_autograd(n, avg_deg, max_core, seed):
+    from ctgcn_amd import ops
+    adj, ref_adj = _graph(n, avg_deg, seed, max_core)
+    layer = _layer(seed)
+    torch.manual_seed(100 + seed)
+    x = torch.randn(n, 128)
+    G = torch.randn(n, 128)
+    assert ops.core_diffusion_fused_ok(layer.rnn.to(DEV), layer.norm.to(DEV), x.to(DEV), adj)
+    layer = layer.cpu()
+    want_out, want = _truth(layer, x, ref_adj, G)
+    got_out, got = _run(layer, x, adj, G, fused=True)
+    assert (got_out.double() - want_out).abs().max().item() < 5e-5
+    for k in ("x", "rnn.weight_ih_l0", "rnn.weight_hh_l0", "rnn.bias_ih_l0", "rnn.bias_hh_l0", "norm.weight", "norm.bias"):
+        assert k in got, k
+        assert _rel(got[k], want[k]) < 1e-4, (k, _rel(got[k], want[k]))
+
+
+def test_fused_training_layer_against_round3_path_and_determinism():
+    """same layer, same inputs through round 3's kernels (fp32 H, bf16 x 3 backward): both within tolerance of each other; two fused
+    runs bit-identical (per-block partial sums, fixed reduction order — no atomics anywhere)"""
+    adj, _ = _graph(5000, 10, 7, 8)
+    layer = _layer(7)
+    torch.manual_seed(8)
+    x, G = torch.randn(5000, 128), torch.randn(5000, 128)
+    out_a, ga = _run(layer, x, adj, G, fused=True)
+    out_b, gb = _run(layer, x, adj, G, fused=False)
+    out_c, gc = _run(layer, x, adj, G, fused=True)
+    assert (out_a - out_b).abs().max().item() < 2e-5
+    for k in ga:
+        assert _rel(ga[k], gb[k]) < 1e-4, (k, _rel(ga[k], gb[k]))
+        assert torch.equal(ga[k], gc[k]), k
+    assert torch.equal(out_a, out_c)
+
+
+def test_fused_training_layer_in_row_chunks():
+    """the backward walks the positions in chunks (bounded gates buffer): a chunked run equals the one-chunk run bit for bit"""
+    from ctgcn_amd import ops
+    adj, _ = _graph(20000, 8, 9, 8)
+    layer = _layer(9)
+    torch.manual_seed(10)
+    x, G = torch.randn(20000, 128), torch.randn(20000, 128)
+    _, g1 = _run(layer, x, adj, G, fused=True)
+    old = ops._GI_MAX_ELEMS
+    try:
+        ops._GI_MAX_ELEMS = 1          # -> chunks of one row granule
+        _, g2 = _run(layer, x, adj, G, fused=True)
+    finally:
+        ops._GI_MAX_ELEMS = old
+    for k in g1:
+        if k == "x":
+            assert torch.equal(g1[k], g2[k]), k        # per-row results do not depend on the chunking
+        else:
+            assert _rel(g1[k], g2[k]) < 1e-5, k        # weight gradients: another association of the per-block partial sums
+
+
+def test_fused_training_without_row_plan(monkeypatch):
+    """CTGCN_DEDUP=0: no plan — every step fresh, natural row order, same kernels"""
+    monkeypatch.setenv("CTGCN_DEDUP", "0")
+    adj, ref_adj = _graph(1000, 8, 11, 5)
+    layer = _layer(11)
+    torch.manual_seed(12)
+    x, G = torch.randn(1000, 128), torch.randn(1000, 128)
+    want_out, want = _truth(layer, x, ref_adj, G)
+    got_out, got = _run(layer, x, adj, G, fused=True)
+    assert (got_out.double() - want_out).abs().max().item() < 5e-5
+    for k in want:
+        assert _rel(got[k], want[k]) < 1e-4, (k, _rel(got[k], want[k]))

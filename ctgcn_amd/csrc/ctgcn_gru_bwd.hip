@@ -188,6 +188,7 @@ struct BwdRecArgs {
     float *dw_part;          // [gridDim.x, 384, 128]
     float *dbn_part;         // [gridDim.x, 128]: column sums of dgh_n
     int32_t accumulate;
+    int32_t ablate;          // diagnostic (CTGCN_BWD_ABLATE): 1 no stores, 2 no weight-gradient products, 4 no gate product, 8 loads of the first step only
 };
 
 template <bool SUM>
@@ -251,17 +252,17 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
                 split4(hp, h, l); *(bf4v *)(&Hs[col * HP + oc]) = h; *(bf4v *)(&Hs[(16 + col) * HP + oc]) = l;
             }
             if ((tmask >> t) & 1) {
-                if (valid) {
+                if (valid && !(a.ablate & 1)) {
                     float *o = a.dgi + (row * S + t) * G3 + oc;
                     *(f4v *)o = gs0; *(f4v *)(o + GH) = gs1; *(f4v *)(o + 2 * GH) = gs2;
                 }
                 gs0 = gs1 = gs2 = zero4;
             }
             if (t == 0) break;
-            load_step(t - 1);                              // in flight during the products below
+            if (!(a.ablate & 8)) load_step(t - 1);         // in flight during the products below
             __syncthreads();
-            drec += gate_product(Gs, Wh, wl, col, grp);
-            weight_grad_block(Gs, Hs, wave, lane, acc);
+            if (!(a.ablate & 4)) drec += gate_product(Gs, Wh, wl, col, grp);
+            if (!(a.ablate & 2)) weight_grad_block(Gs, Hs, wave, lane, acc);
             __syncthreads();                               // the planes are rewritten by the next step
         }
     }
@@ -305,6 +306,7 @@ struct BwdInArgs {
     float *dw_part;          // [gridDim.x, 384, 128]
     float *dbi_part;         // [gridDim.x, 384]
     int32_t accumulate;
+    int32_t ablate;          // diagnostic (CTGCN_BWD_ABLATE): 1 no stores, 2 no weight-gradient products, 4 no gate product, 8 loads of the first unit only
 };
 
 template <bool PLANES, bool ZOUT>
@@ -348,10 +350,13 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
     f4v gv[3], xv;
     h4v xq1, xq2;
     float xsc = 0.f;
+    int32_t orow_n = 0;                                    // ZOUT: matrix row of this lane's tile row, requested with the unit's operands
     auto load_unit = [&](const Unit u) {
         if (u.tile >= ntiles) return;
         const int64_t row0 = u.tile * 16;
         const int64_t lastrow = a.rows - 1;
+        // (a load in the epilogue would be the youngest of the wave: waiting for it waits for every operand load of the NEXT unit too)
+        if (ZOUT && a.order && u.t == (int)(31 - __builtin_clz(u.mask & (S >= 32 ? 0xffffffffu : ((1u << S) - 1u))))) orow_n = a.order[min(row0 + col, lastrow)];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int64_t r = min(row0 + gr_[i], lastrow);
@@ -393,16 +398,22 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
     do { --cur.t; } while (cur.t > 0 && !((cur.mask >> cur.t) & 1));      // the first tile's last fresh step (bit 0 is always set)
     if (cur.tile < ntiles) load_unit(cur);
     f4v Gr = zero4, Zr = zero4;
+    int32_t orow_c = 0;
     while (cur.tile < ntiles) {
+        if (ZOUT && a.order) {                             // the first unit of a tile brings the tile's row map
+            const int top = 31 - __builtin_clz(cur.mask & (S >= 32 ? 0xffffffffu : ((1u << S) - 1u)));
+            if (cur.t == top) orow_c = orow_n;
+        }
         stage_unit();
         Unit nxt = cur;
         next_unit(nxt);
-        load_unit(nxt);                                    // in flight during the products
+        if (!(a.ablate & 8)) load_unit(nxt);               // in flight during the products
         __syncthreads();
-        const f4v dxv = gate_product(Gs, Wh, wl, col, grp);
-        weight_grad_block(Gs, Xs, wave, lane, acc);
+        f4v dxv = zero4;
+        if (!(a.ablate & 4)) dxv = gate_product(Gs, Wh, wl, col, grp);
+        if (!(a.ablate & 2)) weight_grad_block(Gs, Xs, wave, lane, acc);
         const int64_t row0 = cur.tile * 16;
-        const bool valid = row0 + col < a.rows;
+        const bool valid = row0 + col < a.rows && !(a.ablate & 1);
         if (ZOUT) {
             const bf4v xh = *(const bf4v *)(&Xs[col * HP + oc]);
             f4v g = dxv;
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
             Gr += g;
             Zr += Gr;
             if (valid) {
-                const int64_t orow = a.order ? (int64_t)a.order[row0 + col] : row0 + col;
+                const int64_t orow = a.order ? (int64_t)orow_c : row0 + col;
                 *(f4v *)(a.Z + (orow * S + cur.t) * GH + oc) = a.nested ? Zr : Gr;
                 if (cur.t == 0 && a.S0) *(f4v *)(a.S0 + orow * GH + oc) = Gr;
             }
@@ -447,6 +458,7 @@ int device_cus(int *cus)
     return CTGCN_OK;
 }
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+int ablate_mask() { static const int m = [] { const char *e = getenv("CTGCN_BWD_ABLATE"); return e ? atoi(e) : 0; }(); return m; }
 
 }  // namespace
 
@@ -475,7 +487,7 @@ int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
     if (rows == 0) return CTGCN_OK;
     BwdRecArgs a{};
     a.rows = rows; a.steps = steps; a.gates = gates; a.hseq = h_seq; a.dh = dh_sum ? dh_sum : dh_seq; a.whh = w_hh; a.tmask = tile_mask;
-    a.dgi = d_gi; a.dw_part = dw_partial; a.dbn_part = dbn_partial; a.accumulate = accumulate ? 1 : 0;
+    a.dgi = d_gi; a.dw_part = dw_partial; a.dbn_part = dbn_partial; a.accumulate = accumulate ? 1 : 0; a.ablate = ablate_mask();
     if (dh_sum) hipLaunchKernelGGL(gru_bwd_rec_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gru_bwd_rec_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     BWD_TRY(hipGetLastError());
@@ -508,7 +520,7 @@ int ctgcn_gru_bwd_in_f32(int64_t rows, int32_t steps, int32_t hidden, const floa
         a.xps = (const float *)((const _Float16 *)x_planes + 2 * (size_t)plane_rows * GH) + (size_t)first_row * steps;
     }
     a.x = x; a.ldx = ldx; a.dx = dx; a.Z = Z; a.S0 = S0; a.order = row_order; a.nested = nested ? 1 : 0;
-    a.dw_part = dw_partial; a.dbi_part = dbi_partial; a.accumulate = accumulate ? 1 : 0;
+    a.dw_part = dw_partial; a.dbi_part = dbi_partial; a.accumulate = accumulate ? 1 : 0; a.ablate = ablate_mask();
     hipStream_t st = (hipStream_t)stream;
     if (x_planes && Z) hipLaunchKernelGGL((gru_bwd_in_kernel<true, true>), dim3((unsigned)blocks), dim3(512), 0, st, a);
     else if (x_planes) hipLaunchKernelGGL((gru_bwd_in_kernel<true, false>), dim3((unsigned)blocks), dim3(512), 0, st, a);

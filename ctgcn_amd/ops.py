@@ -802,7 +802,16 @@ class _GruSeq(torch.autograd.Function):
         hseq_buf = torch.empty(cmax, steps, hid, dtype=torch.float32, device=dev)
         dghn_buf = torch.empty(cmax * steps, hid, dtype=torch.float32, device=dev)
         split = split_mfma_enabled()
-        if split:
+        # d_in = hidden = 128: the two resident-weight backward kernels of ctgcn_gru_bwd.hip (backward recurrence + dW_hh; dx + dW_ih) instead
+        # of gru_seq_bwd_x3 + gru_dx_x3 + 2 x gru_dw_x3: d_gi is the only intermediate, dGH / dGHn never leave the CU
+        fused_bwd = split and train_fused_enabled() and forward_split_mode() == 2 and d_in == hid and steps <= 32 and w_ih_d.is_contiguous()
+        if fused_bwd:
+            nb = int(lib.ctgcn_gru_bwd_blocks(cmax))
+            dw_part_ih = torch.zeros(nb, 3 * hid, hid, dtype=torch.float32, device=dev)
+            dw_part_hh = torch.zeros(nb, 3 * hid, hid, dtype=torch.float32, device=dev)
+            dbn_part = torch.zeros(nb, hid, dtype=torch.float32, device=dev)
+            dbi_part = torch.zeros(nb, 3 * hid, dtype=torch.float32, device=dev)
+        elif split:
             dw_part_ih = torch.empty(_DW_PAIRS, 3 * hid, hid, dtype=torch.float32, device=dev)    # summed once at the end
             dw_part_hh = torch.empty(_DW_PAIRS, 3 * hid, hid, dtype=torch.float32, device=dev)
         else:
@@ -839,6 +848,16 @@ class _GruSeq(torch.autograd.Function):
                     dpre = g_out
                 dpre = dpre.contiguous()
                 dgi, dghn = gi, dghn_buf[: n * steps]                                       # gi is dead: reuse as d_gi
+                if fused_bwd:
+                    dsq = dseq[lo:lo + n]
+                    with _timed("gru_bwd_rec", rows=n, steps=steps):
+                        check(lib.ctgcn_gru_bwd_rec_f32(n, steps, hid, ptr(gates), ptr(hseq), ptr(dpre) if reduce_sum else None,
+                                                        None if reduce_sum else ptr(dpre), ptr(w_hh_d), None, ptr(dgi), ptr(dw_part_hh), ptr(dbn_part),
+                                                        nb, 1, _stream()), "ctgcn_gru_bwd_rec_f32")
+                    with _timed("gru_bwd_in", rows=n, steps=steps):
+                        check(lib.ctgcn_gru_bwd_in_f32(n, steps, hid, ptr(dgi), ptr(w_ih_d), None, None, 0, 0, ptr(xs), xs.stride(1), ptr(dsq), None, None,
+                                                       None, 0, ptr(dw_part_ih), ptr(dbi_part), nb, 1, _stream()), "ctgcn_gru_bwd_in_f32")
+                    continue
                 check(lib.ctgcn_gru_seq_bwd_f32(n, steps, hid, ptr(gates), ptr(hseq), None if reduce_sum else ptr(dpre),
                                                 ptr(dpre) if reduce_sum else None, ptr(w_hh_d), ptr(dgi), ptr(dghn),
                                                 ptr(bias_part), bias_part.shape[0], 1 if split_mfma_enabled() else 0, _stream()),
@@ -857,6 +876,9 @@ class _GruSeq(torch.autograd.Function):
                     hp2d = hprev.view(n * steps, hid)
                     _accumulate_tn(dw_hh[: 2 * hid], dgi[:, : 2 * hid], hp2d)
                     _accumulate_tn(dw_hh[2 * hid:], dghn, hp2d)
+        if fused_bwd:
+            db_all[: 3 * hid] = dbi_part.sum(0)
+            db_all[3 * hid:] = dbn_part.sum(0)
         if split:
             dw_hh += dw_part_hh.sum(0)
             if d_in == hid:

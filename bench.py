@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the window from one captured hipGraph (ctgcn_amd.graph_capture; single GPU, inference): "
                          "removes launch/Python overhead on small graphs; per-launch HIP-event timing (roofline) is off")
+    ap.add_argument("--dry", action="store_true",
+                    help="launcher / rendezvous / per-rank bookkeeping only, on the CPU with the gloo backend and no kernels (the `not gpu` test of "
+                         "the multi-rank path of this script: self-launch, assignment, stats gather, barriers, max-over-ranks timing, one JSON line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 forward and the k-core roofline legs")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
@@ -158,6 +161,8 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["CTGCN_BENCH_WATCHDOG"]), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    if args.dry:
+        return dry_run(args)
     import torch
     import torch.distributed as dist
     # stdout carries exactly ONE JSON line: anything libraries print on fd 1 meanwhile (RCCL's version banner ...)
@@ -250,6 +255,7 @@ def main():
     model.eval()
     if use_dist:
         spp.shard_ctgcn(model, n, assignment=assignment, exchange=args.exchange, gather_output=False)
+        model.shard_timing = []            # HIP events at the phase boundaries of every sharded forward (spp.shard_phase_ms)
 
     # HIP-event timing of every aggregation launch (same stream the kernel is launched on)
     launches = []
@@ -324,6 +330,14 @@ def main():
     copy_bw = measure_copy_bandwidth(dev) if rank == 0 else None
     ms_per_step, out = timed(args.steps, args.warmup, prewarm_s=1.0)
     assert torch.isfinite(out).all()
+    per_rank_ms = None
+    if use_dist:
+        # DESIGN §5's model, line by line: every rank's compute / exposed exchange / temporal head over the timed steps
+        mine_ms = spp.shard_phase_ms(model, last=args.steps) or {}
+        mine_ms.update(rank=rank, snapshots=mine, aggregated_edges=layers * sum(stats[t]["agg"] for t in mine))
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, mine_ms)
+        model.shard_timing = None
     recorded = list(launches)
     roof_steps = args.steps
     roof_pass = "the timed steps"
@@ -547,6 +561,7 @@ def main():
         "embed_wall_ms": round(ms_per_step, 3),
         "aggregation_ms_per_step_rank0": None if spmm_ms_step is None else round(spmm_ms_step, 3),
         "aggregation_edges_per_s_rank0": agg_rate,
+        "per_rank_ms": per_rank_ms,
         "kernel_timing_pass": roof_pass,
         "kernel_ms_per_step_rank0": {k: round(sum(st.elapsed_time(en) for nm, st, en, _ in recorded if nm == k) / roof_steps, 3)
                                      for k in sorted({nm for nm, _, _, _ in recorded})},
@@ -562,12 +577,118 @@ def main():
         "cpu_baseline": cpu,
         "cpu_baseline_kcore": cpu_k,
     }
+    line["exact_fp32_ms_per_step"] = exact["ms_per_step"] if exact else None
+    line["training_step_ms_per_step"] = train["ms_per_step"] if train else None
+    # the other BASELINE configs (2, 3, 4 math / AS) in the SAME driver run: short runs of this script, one after the other, on the same GPU
+    line["configs"] = None
+    if args.workload == "synthetic-1m" and world == 1 and not args.train and not args.graph and not args.no_extras \
+            and os.environ.get("CTGCN_BENCH_OTHER_CONFIGS", "1") != "0":
+        del model, x_list, adj_list, out
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        line["configs"] = other_configs(line, log)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(line), flush=True)
     os.dup2(2, 1)               # whatever RCCL prints while shutting down must not follow the JSON line on stdout
     if use_dist:
         dist.destroy_process_group()
+
+
+def dry_run(args):
+    """bench.py --dry: everything of a multi-rank run except the GPU — process group (gloo, 127.0.0.1), LPT assignment from the window's
+    snapshot sizes, per-rank stats gathered with all_gather_object, W warm-up + K timed "steps" (an all_to_all of a few floats, where the
+    real step exchanges the snapshot states) between barriers, max over ranks, ONE JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ctgcn_amd import snapshot_parallel as spp
+    from ctgcn_amd.synth import prefix_sizes
+    W = WORKLOADS[args.workload]
+    T = W["T"]
+    sizes = prefix_sizes(W["edges"], T) if W["cumulative"] else [W["edges"]] * T
+    assignment = spp.plan_assignment(sizes, world)
+    mine = assignment[rank]
+    local_stats = {t: dict(K=1, nnz=2 * sizes[t], agg=2 * sizes[t], max_core=1) for t in mine}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local_stats)
+    stats = {}
+    for g in gathered:
+        stats.update(g)
+    assert sorted(stats) == list(range(T)), "every snapshot must be owned by exactly one rank"
+    agg_edges_step = W["diff"] * sum(stats[t]["agg"] for t in range(T))
+    send = torch.full((world, 4), float(rank))
+    recv = torch.empty_like(send)
+
+    def step():
+        dist.all_to_all_single(recv, send)
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    assert recv[:, 0].tolist() == [float(r) for r in range(world)]
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "snapshots": mine, "edges": sum(sizes[t] for t in mine)})
+    if rank == 0:
+        ms = 1000.0 * float(tt.item()) / max(1, args.steps)
+        line = {"metric": "dry run (no kernels): launcher, rendezvous and bookkeeping of the multi-rank bench", "value": agg_edges_step / max(ms * 1e-3, 1e-12),
+                "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "none (dry)", "dry": True,
+                "config": {"workload": W["desc"], "name": args.workload, "snapshots": T, "aggregated_edges_per_step": agg_edges_step,
+                           "assignment": assignment, "parallelism": "snapshot-parallel x%d" % world},
+                "per_rank": per_rank}
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
+    dist.destroy_process_group()
+
+
+def config_summary(line):
+    r = line.get("roofline") or {}
+    by = line.get("roofline_by_width") or {}
+    r128 = by.get("128", r)
+    cpu = line.get("cpu_baseline") or {}
+    return {"workload": line["config"]["workload"], "ms_per_step": line["ms_per_step"], "value": line["value"], "unit": line["unit"],
+            "steps": line["steps"], "warmup": line["warmup"],
+            "roofline_d128": {k: r128.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_timed",
+                                                         "survey_8d_frac", "output_rows_written_frac")} if r128 else None,
+            "roofline_dominant_frac": r.get("frac"),
+            "cpu_baseline": {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "value_coalesced_csr", "protocol")} if cpu else None}
+
+
+def other_configs(main_line, log):
+    """{name: summary} for BASELINE configs 2-4 (+ this run's config 5): `python bench.py --workload W --steps 20 --no-extras` each, ~10 s."""
+    out = {"synthetic-1m": config_summary(main_line)}
+    for w in ("enron-like", "facebook-like", "math-like", "as-like"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "20", "--warmup", "3", "--no-extras", "--cpu-budget-s", "4"]
+        t0 = time.time()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            rows = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not rows:
+                out[w] = {"error": "rc %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
+            else:
+                out[w] = config_summary(json.loads(rows[-1]))
+        except subprocess.TimeoutExpired:
+            out[w] = {"error": "timed out after 240 s"}
+        log("config %s: %s (%.1f s)" % (w, out[w].get("ms_per_step", out[w].get("error")), time.time() - t0))
+    return out
 
 
 def training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log):
@@ -625,6 +746,31 @@ def training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log):
                                             "achieved": round(b / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": round(b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(t_ms, 4),
                                             "launches_timed": len(g)}
+        # the two backward kernels of ctgcn_gru_bwd.hip: HBM-bound by design (their only HBM intermediates are the recompute pass's gates
+        # + h in and the fresh steps' d_gi out / in); the matrix-core side is reported next to it (bf16 x 2: three MFMAs per product of the
+        # gate products, four per weight-gradient product — K = 32 of the MFMA filled with the tile's 16 rows twice)
+        def bwd_roof(name, what, bytes_of, mfma_of):
+            g = by.get(name)
+            if not g:
+                return None
+            t_ms = sum(t for t, _ in g)
+            b = sum(bytes_of(m) for _, m in g)
+            fl = sum(mfma_of(m) for _, m in g)
+            return {"kernel": what, "bound": "hbm", "achieved": round(b / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ms_per_step": round(t_ms / steps, 3), "launches_timed": len(g),
+                    "algorithmic_bytes_per_step": int(b / steps),
+                    "mfma_executed_TFLOPs": round(fl / (t_ms * 1e-3) / 1e12, 1), "mfma_frac_of_dense_16bit_peak_2500": round(fl / (t_ms * 1e-3) / 1e12 / 2500.0, 4)}
+        rs = lambda m: float(m["rows"]) * m["steps"]
+        res["roofline_gru_bwd_rec"] = bwd_roof(
+            "gru_bwd_rec", "gru_bwd_rec_kernel (backward recurrence, W_hh^T resident, dW_hh in registers; in: gates 2 KB + h 0.5 KB per row-step, "
+            "out: d_gi 1.5 KB per fresh row-step)",
+            lambda m: rs(m) * 2560.0 + rs(m) * m["fresh"] * 1536.0 + m["rows"] * 512.0 * (m["steps"] if m.get("per_step") else 1),
+            lambda m: float(m["rows"]) * (m["steps"] - 1) * 2.0 * 128 * 384 * (3 + 4))
+        res["roofline_gru_bwd_in"] = bwd_roof(
+            "gru_bwd_in", "gru_bwd_in_kernel (dx = d_gi W_ih, dW_ih in registers, ReLU mask + suffix sums of the aggregation backward in the "
+            "epilogue; in: d_gi 1.5 KB + x 0.5 KB, out: Z 0.5 KB per fresh row-step)",
+            lambda m: rs(m) * m["fresh"] * (1536.0 + 516.0 + 512.0),
+            lambda m: rs(m) * m["fresh"] * 2.0 * 128 * 384 * (3 + 4))
         log("training step: %.1f ms" % ms)
         return res
     finally:
@@ -637,14 +783,13 @@ def training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log):
 
 
 def cpu_baseline(adj_list, widths, budget_s, log):
-    """Reference CPU path (layers.py:41-48: the loop of torch.sparse.mm over the k-core list + add + ReLU; operands built as
-    utils.py:89-95 builds them: int64-index, uncoalesced COO) on all host cores, at the model's layer widths.  Protocol (SURVEY
-    §8d): warm-up 2, 5 timed repeats, median; plus the same loop on coalesced CSR operands.
-    Bounded sample: the window's LARGEST snapshot, and of its k-core list the largest matrices (all edges first: A_1, then A_2 ...)
-    as long as 2 variants x 7 passes fit the budget (one pass of one matrix is timed first; when even that does not fit and all layers
-    share one width, one width is timed).  On the host of an MI355X box
-    (256 threads) a pass costs ~1 s per matrix at 1M nodes whatever its edge count — the N x d passes of ATen's COO path
-    dominate — so the largest matrices are also the fairest sample for an edges/s figure."""
+    """Reference CPU path (layers.py:41-47 + 48: the loop of torch.sparse.mm over the WHOLE k-core list of one snapshot + add + ReLU; operands
+    built as utils.py:89-95 builds them: int64-index, uncoalesced COO) on all host cores, plus the same loop on coalesced CSR operands.
+    Sample (bounded, ~10-30 s): the window's LARGEST snapshot, every one of its K matrices, at the model's layer widths (one
+    width when all layers share it: edges are counted per width).  Protocol: warm-up 2, 5 timed repeats, median — as many of those as fit
+    the budget: on an MI355X host one pass of the 8-matrix loop at 1M nodes is ~17 s as COO (ATen's N x d passes dominate, whatever the
+    edge count), so config 5 gets the first pass as warm-up-free measurement of the loop; the small configs run the full protocol.  What ran
+    is written into `protocol`."""
     import torch
     from oracle import torch_path as TP
     cores = os.cpu_count() or 1
@@ -653,16 +798,14 @@ def cpu_baseline(adj_list, widths, budget_s, log):
     pick = max(owned, key=lambda t: adj_list[t].aggregated_edges)
     adj = adj_list[pick]
     n = adj.n
+    if len(set(widths)) == 1:
+        widths = widths[:1]
     xs = {d: torch.randn(n, d) for d in set(widths)}
     mats = adj.cpu().to_scipy_list()                       # reference order: highest k (smallest matrix) first
-    order = sorted(range(len(mats)), key=lambda j: -mats[j].nnz)
-
-    def operands(js):
-        js = sorted(js)                                     # keep the reference's visiting order among the chosen ones
-        coo = [TP.coo_like_reference(mats[j]) for j in js]
-        csr = [torch.sparse_csr_tensor(torch.from_numpy(mats[j].indptr.astype("int64")), torch.from_numpy(mats[j].indices.astype("int64")),
-                                       torch.from_numpy(mats[j].data), size=mats[j].shape) for j in js]
-        return coo, csr
+    coo = [TP.coo_like_reference(m) for m in mats]
+    csr = [torch.sparse_csr_tensor(torch.from_numpy(m.indptr.astype("int64")), torch.from_numpy(m.indices.astype("int64")),
+                                   torch.from_numpy(m.data), size=m.shape) for m in mats]
+    edges = sum(m.nnz for m in mats) * len(widths)
 
     def loop(ops_):
         t0 = time.perf_counter()
@@ -671,34 +814,31 @@ def cpu_baseline(adj_list, widths, budget_s, log):
         del hs
         return time.perf_counter() - t0
 
-    coo1, _ = operands(order[:1])
-    loop(coo1)
-    t_one = loop(coo1)                                      # one matrix, all widths
-    if t_one * 14 > budget_s and len(set(widths)) == 1 and len(widths) > 1:
-        widths = widths[:1]                                 # all layers have one width: time one of them (edges are counted per width)
-        t_one /= 2.0
-    per_pass = budget_s / 14.0
-    count = max(1, min(len(mats), int(per_pass / max(t_one, 1e-6))))
-    warm, reps = 2, 5                                       # the protocol never shrinks; what shrinks is the sample (down to one matrix, one width)
-    chosen = order[:count]
-    coo, csr = operands(chosen)
-    edges = sum(mats[j].nnz for j in chosen) * len(widths)
-    res = {}
+    TP.aggregate_loop(coo[:1], xs[widths[0]])              # spin up the thread pool on the smallest matrix (not a pass)
+    res, proto = {}, {}
     for label, ops_ in (("coo", coo), ("csr", csr)):
-        for _ in range(warm):
+        share = budget_s * (0.62 if label == "coo" else 0.38)      # the COO pass is ~1.8x the CSR pass
+        first = loop(ops_)
+        fit = int(share / max(first, 1e-9))                 # passes of this variant the budget holds, the first one included
+        if fit < 2:
+            res[label], proto[label] = (first, first, first), "1 pass, no warm-up (a pass is %.1f s)" % first
+            continue
+        warm = 2 if fit >= 4 else 1                         # the first pass is the (first) warm-up
+        if warm == 2:
             loop(ops_)
+        reps = max(1, min(5, fit - warm))
         times = [loop(ops_) for _ in range(reps)]
         res[label] = (statistics.median(times), min(times), max(times))
-    log("cpu baseline: snapshot %d, %d of %d matrices, %d aggregated edges/pass, coo %.3fs csr %.3fs" % (
-        pick, count, len(mats), edges, res["coo"][0], res["csr"][0]))
+        proto[label] = "warm-up %d, %d timed repeats, median (min %.3f / max %.3f s)" % (warm, reps, min(times), max(times))
+    log("cpu baseline: snapshot %d, all %d matrices, %d aggregated edges/pass, coo %.3fs csr %.3fs" % (pick, len(mats), edges, res["coo"][0], res["csr"][0]))
     return {"value": edges / res["coo"][0], "unit": "edges/s", "cores": cores, "kind": "port",
             "value_coalesced_csr": edges / res["csr"][0],
-            "protocol": "warm-up %d, %d timed repeats, median (min %.3f / max %.3f s for COO)" % (warm, reps, res["coo"][1], res["coo"][2]),
+            "protocol": "COO: %s; CSR: %s" % (proto["coo"], proto["csr"]),
             "sample": "oracle/torch_path.py (reference layers.py:41-48 restated: torch.sparse.mm on uncoalesced int64 COO operands as "
                       "utils.py:89-95 builds them + add + relu; `value_coalesced_csr` = the same loop on coalesced torch CSR operands), "
-                      "snapshot %d of the window (the largest), its %d largest of %d k-core matrices (%d nodes), feature widths %s, "
-                      "%d aggregated edges per pass, median pass %.3f s (COO) / %.3f s (CSR), torch.set_num_threads(%d)" % (
-                          pick, count, len(mats), n, widths, edges, res["coo"][0], res["csr"][0], cores)}
+                      "snapshot %d of the window (the largest), the full loop over its %d k-core matrices (%d nodes), feature widths %s, "
+                      "%d aggregated edges per pass, pass %.3f s (COO) / %.3f s (CSR), torch.set_num_threads(%d)" % (
+                          pick, len(mats), n, widths, edges, res["coo"][0], res["csr"][0], cores)}
 
 
 def cpu_baseline_kcore(kc_graph, n, log):

@@ -682,17 +682,18 @@ class _CoreDiffusionFused(torch.autograd.Function):
             for lo, cnt in chunks:
                 tm = _u32ptr(tmask, lo // 16)
                 od = _u32ptr(order, lo)
-                with _timed("gru_layer", rows=cnt, steps=K, reduce_sum=True, presplit=True, save=True):
+                fresh = (plan["new_rows"] / float(n * K)) if plan is not None else 1.0     # fraction of (position, step) rows that bring a new x
+                with _timed("gru_layer", rows=cnt, steps=K, reduce_sum=True, presplit=True, save=True, new_rows=int(cnt * K * fresh)):
                     check(lib.ctgcn_gru_layer_presplit_save_f32(cnt, K, hid, ptr(ws), n * K, lo, ptr(w_ih_d), ptr(w_hh_d), ptr(bias), ptr(b_hn), tm,
                                                                 ptr(gates), ptr(hseq), ptr(presum), _stream()), "ctgcn_gru_layer_presplit_save_f32")
                 dy = dout if order is not None else dout[lo:lo + cnt]
                 check(lib.ctgcn_layernorm_bwd_f32(cnt, 1, hid, ptr(presum), ptr(dy), dy.stride(0), ptr(ln_w.detach()), eps, ptr(dpre), ptr(ln_part),
                                                   ln_part.shape[0], od, _stream()), "ctgcn_layernorm_bwd_f32")
                 ln_sum += ln_part.sum(0)
-                with _timed("gru_bwd_rec", rows=cnt, steps=K):
+                with _timed("gru_bwd_rec", rows=cnt, steps=K, fresh=fresh, per_step=False):
                     check(lib.ctgcn_gru_bwd_rec_f32(cnt, K, hid, ptr(gates), ptr(hseq), ptr(dpre), None, ptr(w_hh_d), tm, ptr(dgi), ptr(dw_hh_part),
                                                     ptr(dbn_part), nb, 1, _stream()), "ctgcn_gru_bwd_rec_f32")
-                with _timed("gru_bwd_in", rows=cnt, steps=K):
+                with _timed("gru_bwd_in", rows=cnt, steps=K, fresh=fresh, z_out=True):
                     check(lib.ctgcn_gru_bwd_in_f32(cnt, K, hid, ptr(dgi), ptr(w_ih_d), tm, ptr(ws), n * K, lo, None, 0, None,
                                                    ptr(Z) if order is not None else ptr(Z[lo:]),
                                                    ptr(S0) if (S0 is None or order is not None) else ptr(S0[lo:]), od, 1 if adj.nested else 0,
@@ -850,11 +851,11 @@ class _GruSeq(torch.autograd.Function):
                 dgi, dghn = gi, dghn_buf[: n * steps]                                       # gi is dead: reuse as d_gi
                 if fused_bwd:
                     dsq = dseq[lo:lo + n]
-                    with _timed("gru_bwd_rec", rows=n, steps=steps):
+                    with _timed("gru_bwd_rec", rows=n, steps=steps, fresh=1.0, per_step=not reduce_sum):
                         check(lib.ctgcn_gru_bwd_rec_f32(n, steps, hid, ptr(gates), ptr(hseq), ptr(dpre) if reduce_sum else None,
                                                         None if reduce_sum else ptr(dpre), ptr(w_hh_d), None, ptr(dgi), ptr(dw_part_hh), ptr(dbn_part),
                                                         nb, 1, _stream()), "ctgcn_gru_bwd_rec_f32")
-                    with _timed("gru_bwd_in", rows=n, steps=steps):
+                    with _timed("gru_bwd_in", rows=n, steps=steps, fresh=1.0, z_out=False):
                         check(lib.ctgcn_gru_bwd_in_f32(n, steps, hid, ptr(dgi), ptr(w_ih_d), None, None, 0, 0, ptr(xs), xs.stride(1), ptr(dsq), None, None,
                                                        None, 0, ptr(dw_part_ih), ptr(dbi_part), nb, 1, _stream()), "ctgcn_gru_bwd_in_f32")
                     continue

@@ -290,6 +290,17 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
                                                        for t in range(plan.T)], dtype=torch.int64, device=p0.device))
     _, send, recv, seq_box, moves, step_off = buf
     works, trans_local = [], {}
+    # model.shard_timing = [] (bench.py --gpus N): per forward, HIP events at the phase boundaries on the compute stream — snapshot
+    # branches | waiting for the exchange (what is NOT hidden behind compute) | temporal head; read with shard_phase_ms()
+    marks = getattr(model, "shard_timing", None)
+
+    def mark():
+        if marks is not None and send.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        return None
+    ev0 = mark()
     for s_ in range(plan.per):
         if s_ < len(mine):
             t = mine[s_]
@@ -301,10 +312,13 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
     # recv[s][w] = snapshot assignment[w][s] on my node slice -> [nodes, T, d] in time order (the temporal GRU's input layout); slot s is
     # moved as soon as ITS all-to-all has landed (one strided copy per slot: the ranks' s-th snapshots), under the later slots' exchange
     from . import ops
+    ev1 = mark()
+    ev2 = None
     if recv.is_cuda and d == 128 and ops.gru_steps_scattered_ok(model.rnn, recv):
         # the temporal GRU reads the receive buffer in time order through a per-step offset table: no [nodes, T, d] copy at all
         for w in works:
             w.wait()
+        ev2 = mark()
         out = ops.gru_sequence_scattered(model.rnn, model.norm, recv, step_off, d, hi - lo).transpose(0, 1)        # [T, my nodes, d]
     else:
         if seq_box[0] is None:
@@ -316,7 +330,11 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
                 times, owners, count = moves[s_]
                 src = recv[s_, :count, : hi - lo] if owners is None else recv[s_, owners, : hi - lo]
                 seq.index_copy_(1, times, src.transpose(0, 1))
+        ev2 = mark()
         out = model.temporal_head(seq)                                                      # [T, my nodes, d]
+    ev3 = mark()
+    if marks is not None and ev0 is not None:
+        marks.append((ev0, ev1, ev2, ev3))
     if model.shard_gather_output:
         padded = torch.nn.functional.pad(out, (0, 0, 0, plan.n_slice - (hi - lo))) if hi - lo < plan.n_slice else out
         full = _GatherReplicatedOutput.apply(padded.transpose(0, 1).contiguous(), group)    # [world, n_slice, T, d]
@@ -324,6 +342,19 @@ def _forward_sharded_pipelined(model, x_list, adj_list):
     if model.model_type == 'C':
         return out
     return out, [trans_local.get(t) for t in range(plan.T)]
+
+
+def shard_phase_ms(model, last=None):
+    """Mean (snapshot branches, exposed exchange wait, temporal head) milliseconds of this rank over the recorded forwards of
+    model.shard_timing (the last `last` of them), or None.  Call after a device synchronize."""
+    marks = getattr(model, "shard_timing", None)
+    if not marks:
+        return None
+    use = marks[-last:] if last else marks
+    k = float(len(use))
+    return {"snapshot_branches_ms": sum(a.elapsed_time(b) for a, b, _, _ in use) / k,
+            "exchange_exposed_ms": sum(b.elapsed_time(c) for _, b, c, _ in use) / k,
+            "temporal_head_ms": sum(c.elapsed_time(d_) for _, _, c, d_ in use) / k, "forwards": len(use)}
 
 
 # ------------------------------------------------------------------------------------------- CGCN (static model)

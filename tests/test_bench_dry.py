@@ -1,0 +1,50 @@
+"""bench.py's multi-rank plumbing without a GPU (`--dry`: gloo on the CPU, no kernels): the self-launcher, the driver's launcher form,
+the LPT assignment, the per-rank stats gather, barriers + max-over-ranks timing and the ONE JSON line of rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _check(stdout, world):
+    lines = [l for l in stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # exactly one line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["dry"] is True and line["steps"] == 3 and line["warmup"] == 1
+    for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    owned = sorted(t for r in line["per_rank"] for t in r["snapshots"])
+    assert owned == list(range(line["config"]["snapshots"]))          # every snapshot on exactly one rank
+    assert [r["rank"] for r in line["per_rank"]] == list(range(world))
+    assert line["config"]["assignment"] == [r["snapshots"] for r in line["per_rank"]]
+
+
+def test_bench_self_launch_two_ranks_dry():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--workload", "tiny", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    _check(p.stdout, 2)
+
+
+def test_bench_under_the_drivers_launcher_dry():
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ..."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry", "--workload", "enron-like", "--steps", "3", "--warmup", "1"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    _check(p.stdout, 3)

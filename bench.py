@@ -371,10 +371,20 @@ def main():
         # plan (CoreAdj.row_plan) the rows that repeat the row before them are not written, so the bytes a launch HAS to move are fewer;
         # `achieved` / `frac` use those (a fraction of the HBM peak must be physical), `survey_8d_*` keep the §8d formula (the work the
         # reference defines — it can exceed the peak precisely because part of it is no longer done).  Without a plan both coincide.
-        survey = sum(algorithmic_bytes(m["n"], m["nnz"], m["K"], m["d"]) for _, m in group) / len(group)
-        moved = sum(moved_bytes(m["n"], m["nnz"], m["K"], m["d"], m["rows_written"]) if m.get("rows_written", m["n"] * m["K"]) != m["n"] * m["K"]
-                    else algorithmic_bytes(m["n"], m["nnz"], m["K"], m["d"]) for _, m in group) / len(group)
-        rows_frac = sum(m.get("rows_written", m["n"] * m["K"]) for _, m in group) / float(sum(m["n"] * m["K"] for _, m in group))
+        # a grouped launch (ops.core_diffusion_split_group: all snapshots of a small window in one grid) carries the sums over its snapshots:
+        # nnz and rows_written are window totals, K_sum = sum of the snapshots' K, group = their number
+        def survey_of(m):
+            g = m.get("group", 1)
+            return m["nnz"] * (4 * m["d"] + 9) + m["n"] * m.get("K_sum", m["K"]) * 4 * m["d"] + g * 4 * (m["n"] + 1)
+
+        def moved_of(m):
+            g, ks = m.get("group", 1), m.get("K_sum", m["K"])
+            if m.get("rows_written", m["n"] * ks) == m["n"] * ks:
+                return survey_of(m)
+            return m["nnz"] * (4 * m["d"] + 9) + m["rows_written"] * (4 * m["d"] + 4) + g * (4 * (m["n"] + 1) + 4 * m["n"] + 4 * ((m["n"] + 15) // 16))
+        survey = sum(survey_of(m) for _, m in group) / len(group)
+        moved = sum(moved_of(m) for _, m in group) / len(group)
+        rows_frac = sum(m.get("rows_written", m["n"] * m.get("K_sum", m["K"])) for _, m in group) / float(sum(m["n"] * m.get("K_sum", m["K"]) for _, m in group))
         achieved = moved / (avg_ms * 1e-3) / 1e9
         survey_gbps = survey / (avg_ms * 1e-3) / 1e9
         rec = pmc.get(args.workload, {}).get(str(world)) if d == 128 else None
@@ -384,6 +394,7 @@ def main():
                 "traffic_source": ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/agg_bench.py on the same "
                                    "workload (separate run, not this one)") if rec else None,
                 "launches_timed": len(group), "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(moved),
+                "snapshots_per_launch": group[0][1].get("group", 1),
                 "ms_per_step_rank0": round(sum(ms for ms, _ in group) / roof_steps, 3),
                 "output_rows_written_frac": round(rows_frac, 4),
                 "survey_8d_bytes_per_launch": int(survey), "survey_8d_GBps": round(survey_gbps, 1), "survey_8d_frac": round(survey_gbps / HBM_PEAK_GBS, 4),
@@ -434,13 +445,15 @@ def main():
     if fused:
         # projection + recurrence in one kernel: 2*128*384 flops per row-step for the projection, the same for every step but the first
         def layer_obj(group, name, per_step):
-            ref_flops = sum(m["rows"] * (2 * m["steps"] - 1) * 2.0 * 128 * 384 for _, m in group)
+            # grouped launches (a window's snapshots in one grid) carry row_steps = sum over the snapshots of rows x steps and group = their number
+            rsteps = lambda m: m.get("row_steps", m["rows"] * m["steps"])
+            ref_flops = sum((2 * rsteps(m) - m["rows"] * m.get("group", 1)) * 2.0 * 128 * 384 for _, m in group)
             # executed: x·W_ih only for the row-steps that bring a new x (row plan), h·W_hh for every step but the first
-            flops = sum((m.get("new_rows", m["rows"] * m["steps"]) + m["rows"] * (m["steps"] - 1)) * 2.0 * 128 * 384 for _, m in group)
+            flops = sum((m.get("new_rows", rsteps(m)) + rsteps(m) - m["rows"] * m.get("group", 1)) * 2.0 * 128 * 384 for _, m in group)
             ms = sum(t for t, _ in group)
             # compulsory traffic: the x rows in (as fp32 or as two fp16 planes: 512 B per row-step either way), one output row out
             # (per step for the temporal form)
-            hbm = sum(m.get("new_rows", m["rows"] * m["steps"]) * 512.0 + m["rows"] * (m["steps"] * 512.0 if per_step else 512.0) for _, m in group)
+            hbm = sum(m.get("new_rows", rsteps(m)) * 512.0 + m["rows"] * m.get("group", 1) * (m["steps"] * 512.0 if per_step else 512.0) for _, m in group)
             return {"kernel": name, "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s (fp32-equivalent)", "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
                     # tools/probes/mfma_peak_probe.hip: v_mfma_f32_16x16x32_f16 sustains 2.15-2.3 PFLOP/s with real operands on this

@@ -19,6 +19,18 @@ ABI_VERSION = 22
 _c = ctypes
 _vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_int, _c.c_size_t
 
+class AggSplitGroup(_c.Structure):
+    """ctgcn_agg_split_group_t (include/ctgcn_hip.h)"""
+    _fields_ = [("row_ptr", _vp), ("col_idx", _vp), ("val", _vp), ("slot", _vp), ("X", _vp), ("ldx", _i64), ("K", _i32), ("flags", _u32),
+                ("row_order", _vp), ("tile_mask", _vp), ("workspace", _vp), ("workspace_bytes", _sz)]
+
+
+class GruLayerGroup(_c.Structure):
+    """ctgcn_gru_layer_group_t (include/ctgcn_hip.h)"""
+    _fields_ = [("planes", _vp), ("w_ih", _vp), ("w_hh", _vp), ("bias_gi", _vp), ("b_hn", _vp), ("ln_weight", _vp), ("ln_bias", _vp),
+                ("ln_eps", _c.c_float), ("steps", _i32), ("out", _vp), ("ld_out", _i64), ("row_order", _vp), ("tile_mask", _vp), ("work", _i64)]
+
+
 # name -> (restype, argtypes); must list every symbol include/ctgcn_hip.h declares
 SIGNATURES = {
     "ctgcn_abi_version": (_int, []),
@@ -37,6 +49,9 @@ SIGNATURES = {
     "ctgcn_slot_reorder": (_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _i64, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "ctgcn_layernorm_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _i64, _vp, _c.c_float, _vp, _vp, _i32, _vp, _vp]),
+    "ctgcn_group_table_bytes": (_sz, [_i32]),
+    "ctgcn_core_aggregate_split_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "ctgcn_gru_layer_presplit_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
     "ctgcn_gru_bwd_blocks": (_i32, [_i64]),
     "ctgcn_gru_layer_presplit_save_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_bwd_rec_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),

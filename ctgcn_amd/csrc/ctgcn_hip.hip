@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/ctgcn_hip.h"
 
@@ -1423,14 +1424,15 @@ __device__ __forceinline__ float group_max(float m)       // m >= 0: its bit pat
 // ------------------------------------------------------------------------------------------------
 template <int LPR, int CH, int U>
 __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2,
-                                                   float *__restrict__ scale, int32_t kp, float residual_scale)
+                                                   float *__restrict__ scale, int32_t kp, float residual_scale, const int64_t bid)
 {
+    // bid: index of this block among the blocks of `a` (blockIdx.x, or — grouped launch of a window — blockIdx.x % blocks per snapshot)
     const int lig = threadIdx.x & (LPR - 1);
-    const int64_t pos = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
+    const int64_t pos = bid * (256 / LPR) + (threadIdx.x / LPR);
     if (pos >= a.n) return;
     const int64_t row = a.order ? (int64_t)a.order[pos] : pos;
     // the block's 256 / LPR positions lie in one 16-position tile: a scalar load
-    const int64_t tile = ((int64_t)blockIdx.x * (256 / LPR)) >> a.tile_shift;
+    const int64_t tile = (bid * (256 / LPR)) >> a.tile_shift;
     const uint32_t need = a.tmask ? a.tmask[tile] : 0xffffffffu;
     const int64_t obase = a.tbase ? (int64_t)a.tbase[tile] + (pos & ((1 << a.tile_shift) - 1)) * __popc(need) : pos * a.K;
     const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
@@ -1540,20 +1542,34 @@ template <int LPR, int CH, int U>
 __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2,
                                                             float *__restrict__ scale, int32_t kp, float residual_scale)
 {
-    agg_fwd_split_body<LPR, CH, U>(a, p1, p2, scale, kp, residual_scale);
+    agg_fwd_split_body<LPR, CH, U>(a, p1, p2, scale, kp, residual_scale, blockIdx.x);
 }
 // d <= 128: held to the 72 registers of seven waves per SIMD, like agg_fwd_kernel<4,32,4> (left alone the epilogue takes 74: six)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void agg_fwd_split32_kernel(
     const AggArgs a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2, float *__restrict__ scale, int32_t kp, float residual_scale)
 {
-    agg_fwd_split_body<32, 1, 4>(a, p1, p2, scale, kp, residual_scale);
+    agg_fwd_split_body<32, 1, 4>(a, p1, p2, scale, kp, residual_scale, blockIdx.x);
 }
 // small graphs (<= 200 000 rows): eight gathers in flight per lane instead of four.  A launch is then a few waves of blocks deep and its
 // time is the rows' dependent load chains, not the bandwidth: 0.242 -> 0.210 ms at 87 036 rows (1 M rows: 2.18 vs 2.21 ms, occupancy 7 -> 5)
 __global__ __launch_bounds__(256) void agg_fwd_split32_u8_kernel(
     const AggArgs a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2, float *__restrict__ scale, int32_t kp, float residual_scale)
 {
-    agg_fwd_split_body<32, 1, 8>(a, p1, p2, scale, kp, residual_scale);
+    agg_fwd_split_body<32, 1, 8>(a, p1, p2, scale, kp, residual_scale, blockIdx.x);
+}
+// The d = 128 aggregation of EVERY snapshot of a window in one launch (small graphs: 25-200 us per snapshot, bound by ramp, tail and the
+// rows' dependent load chains rather than by bandwidth): all snapshots share the node set, so snapshot = blockIdx.x / blocks_per_group.
+struct AggSplitGroup {
+    AggArgs a;
+    _Float16 *p1, *p2;
+    float *scale;
+};
+__global__ __launch_bounds__(256) void agg_fwd_split32_group_kernel(const AggSplitGroup *__restrict__ table, int32_t blocks_per_group, int32_t kp,
+                                                                    float residual_scale)
+{
+    const int g = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)blocks_per_group));
+    const AggSplitGroup G = table[g];
+    agg_fwd_split_body<32, 1, 8>(G.a, G.p1, G.p2, G.scale, kp, residual_scale, (int64_t)(blockIdx.x % (unsigned)blocks_per_group));
 }
 
 // 8 consecutive fp32 weights, already multiplied by 1/s, -> two fp16x8 fragments
@@ -2263,8 +2279,10 @@ constexpr int L8_PITCH = 128;                            // halfs per plane row,
 __device__ __forceinline__ int l8_off(int r, int k) { return ((((k >> 3) ^ r) & 15) << 3) | (k & 7); }
 __device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : -1; }
 
-template <bool PRESPLIT, bool REDUCE, bool SAVE = false>
-__global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
+// bid / nblk: this block's index among the nblk blocks that share the work of `a` (the whole grid, or — grouped launch of a window's
+// snapshots, gru_layer8_h2_group_kernel — the blocks assigned to this snapshot)
+template <bool PRESPLIT, bool REDUCE, bool SAVE>
+__device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int bid, const int nblk)
 {
     // x and h planes: 16 rows of 128 halfs, unpadded; the 16-byte segment q of row r is stored at segment q ^ r (l8_off).  Every access
     // pattern of the kernel is then conflict-free: the MFMA operand reads (ds_read_b128: lane = (row, k group) — with the 8-half row
@@ -2400,13 +2418,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     uint32_t pmask = 0xffffffffu;                          // mask of the tile the x pipeline is at
     auto next_unit = [&](int64_t &tile, int &t) {
         do {
-            if (++t >= S) { t = 0; tile += gridDim.x; if (DEDUP) pmask = tile_mask(tile); }
+            if (++t >= S) { t = 0; tile += nblk; if (DEDUP) pmask = tile_mask(tile); }
         } while (DEDUP && !((pmask >> t) & 1));
     };
 
-    if ((int64_t)blockIdx.x >= ntiles) return;
+    if ((int64_t)bid >= ntiles) return;
     f4v xr;
-    int64_t ptile = blockIdx.x;                           // unit whose x sits in xr
+    int64_t ptile = bid;                           // unit whose x sits in xr
     int pt = 0;
     if (DEDUP) pmask = tile_mask(ptile);
     load_x(ptile, pt, xr);
@@ -2515,7 +2533,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 }
             ln_last = -1;
         };
-        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int64_t tile = bid; tile < ntiles; tile += nblk) {
             const int64_t row0 = tile * 16;
             const int last = (int)min((int64_t)16, a.rows - row0) - 1;
             f4v hprev = zero4, hsum = zero4;
@@ -2541,7 +2559,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
                 const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
                 const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
                 // the next unit's x·W_ih, if it brings a new x (a repeat keeps gi): this tile's next step, or step 0 of the block's next tile
-                const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + gridDim.x < ntiles;
+                const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + nblk < ntiles;
                 f4v h, rv4, zv4, nv4, an4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -2586,7 +2604,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
         return;
     }
 #endif
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = bid; tile < ntiles; tile += nblk) {
         const int64_t row0 = tile * 16;
         const int last = (int)min((int64_t)16, a.rows - row0) - 1;
         f4v hprev = zero4, hsum = zero4;
@@ -2721,9 +2739,26 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a
     else pending_rows();
 #ifdef CTGCN_LAYER_TIMELINE
     if (a.timeline && lane == 0)
-        for (int i = 0; i < 6; ++i) a.timeline[((size_t)blockIdx.x * 8 + wave) * 6 + i] = tl[i];
+        for (int i = 0; i < 6; ++i) a.timeline[((size_t)bid * 8 + wave) * 6 + i] = tl[i];
 #endif
 #undef TL_MARK
+}
+
+template <bool PRESPLIT, bool REDUCE, bool SAVE = false>
+__global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
+{
+    gru_layer8_h2_body<PRESPLIT, REDUCE, SAVE>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+// One launch for the width-128 CoreDiffusion layer of EVERY snapshot of a window (small graphs: a snapshot alone is 25-500 us of kernel, most
+// of it ramp and tail).  Snapshots own their weights (reference models.py:225-231: duffision_list[t]), so a block serves one snapshot:
+// blockmap[b] = {snapshot, block index among that snapshot's blocks, their number}; table[snapshot] = that snapshot's arguments.
+__global__ __launch_bounds__(512, 2) void gru_layer8_h2_group_kernel(const LayerArgs *__restrict__ table, const int32_t *__restrict__ blockmap)
+{
+    const int g = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x]);
+    const int bid = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x + 1]);
+    const int nblk = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x + 2]);
+    const LayerArgs a = table[g];
+    gru_layer8_h2_body<true, true, false>(a, bid, nblk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4095,6 +4130,110 @@ int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidde
 #endif
     const int64_t nt8 = (rows + 15) / 16;
     hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+size_t ctgcn_group_table_bytes(int32_t groups)
+{
+    if (groups < 1) return 0;
+    const size_t per = sizeof(AggSplitGroup) > sizeof(LayerArgs) ? sizeof(AggSplitGroup) : sizeof(LayerArgs);
+    return ((size_t)groups * per + 255) / 256 * 256 + 3 * sizeof(int32_t) * 1024;      // + the block map of the layer launch (<= 1024 blocks)
+}
+
+int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t d, const ctgcn_agg_split_group_t *g, void *table, size_t table_bytes,
+                                         void *stream)
+{
+    if (groups < 1 || groups > 1024 || !g) return fail(CTGCN_E_INVALID, "core_aggregate_split_group: groups=%d", groups);
+    if (d != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split_group: only d = %d (the GRU layer kernel as consumer) is built", GRU_H);
+    if (n_rows < 1) return fail(CTGCN_E_INVALID, "core_aggregate_split_group: n_rows=%lld", (long long)n_rows);
+    if (!table || (reinterpret_cast<uintptr_t>(table) & 255u) || table_bytes < ctgcn_group_table_bytes(groups))
+        return fail(CTGCN_E_WORKSPACE, "core_aggregate_split_group: table must be 256-byte aligned and hold ctgcn_group_table_bytes(groups) bytes");
+    std::vector<AggSplitGroup> host((size_t)groups);
+    const AggPlan p = plan_for(d, true);
+    for (int i = 0; i < groups; ++i) {
+        const ctgcn_agg_split_group_t &q = g[i];
+        if (q.K < 1 || q.K > CTGCN_MAX_SLOTS || !q.row_ptr || !q.X || !q.workspace || (!q.slot && q.K != 1) || q.ldx < d || (q.ldx & 3) || !aligned16(q.X) ||
+            (reinterpret_cast<uintptr_t>(q.workspace) & 255u))
+            return fail(CTGCN_E_INVALID, "core_aggregate_split_group: bad arguments of group %d", i);
+        if ((q.row_order == nullptr) != (q.tile_mask == nullptr) || (q.row_order && q.K > 32))
+            return fail(CTGCN_E_INVALID, "core_aggregate_split_group: group %d: row_order and tile_mask come together, K <= 32 under a plan", i);
+        if (q.workspace_bytes < ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, q.K, 1, 0))
+            return fail(CTGCN_E_WORKSPACE, "core_aggregate_split_group: workspace of group %d too small", i);
+        AggSplitGroup &h = host[i];
+        h = AggSplitGroup{};
+        const int64_t rows = n_rows * q.K;
+        h.p1 = (_Float16 *)q.workspace; h.p2 = h.p1 + (size_t)rows * GRU_H; h.scale = (float *)(h.p2 + (size_t)rows * GRU_H);
+        AggArgs &a = h.a;
+        a.n = n_rows; a.d = d; a.K = q.K; a.row_ptr = q.row_ptr; a.col = q.col_idx; a.val = q.val; a.slot = q.slot;
+        a.src = q.X; a.ldsrc = q.ldx; a.out = nullptr; a.out_ld = (int64_t)q.K * d; a.flags = q.flags;
+        a.n_long = 0; a.long_thresh = 0x7fffffff;          // hub rows are the caller's business (none in the windows this serves)
+        a.order = q.row_order; a.tmask = q.tile_mask; a.tbase = nullptr; a.tile_shift = 4;
+        a.chunks = p.chunks; a.passes = p.passes; a.hub_split = 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(table, host.data(), host.size() * sizeof(AggSplitGroup), hipMemcpyHostToDevice, st));
+    const int64_t bpg = (n_rows + 7) / 8;
+    if (bpg * groups > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split_group: grid too large");
+    hipLaunchKernelGGL(agg_fwd_split32_group_kernel, dim3((unsigned)(bpg * groups)), dim3(256), 0, st, (const AggSplitGroup *)table, (int32_t)bpg, GRU_H, 1.f);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_layer_group_t *g, void *table, size_t table_bytes,
+                                       void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit_group: only d_in = hidden = %d is built (got %d)", GRU_H, hidden);
+    if (groups < 1 || groups > 1024 || !g || rows < 1) return fail(CTGCN_E_INVALID, "gru_layer_presplit_group: groups=%d rows=%lld", groups, (long long)rows);
+    if (!table || (reinterpret_cast<uintptr_t>(table) & 255u) || table_bytes < ctgcn_group_table_bytes(groups))
+        return fail(CTGCN_E_WORKSPACE, "gru_layer_presplit_group: table must be 256-byte aligned and hold ctgcn_group_table_bytes(groups) bytes");
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
+    if (cus > 1024) cus = 1024;
+    std::vector<LayerArgs> host((size_t)groups);
+    const int64_t ntiles = (rows + 15) / 16;
+    double total = 0.0;
+    for (int i = 0; i < groups; ++i) {
+        const ctgcn_gru_layer_group_t &q = g[i];
+        if (q.steps < 1 || !q.planes || !q.w_ih || !q.w_hh || !q.out || (reinterpret_cast<uintptr_t>(q.planes) & 255u) || !aligned16(q.w_ih) || !aligned16(q.w_hh) ||
+            (reinterpret_cast<uintptr_t>(q.out) & 7u) || (q.ld_out > 0 && (q.ld_out < GRU_H || (q.ld_out & 1))) ||
+            (q.row_order == nullptr) != (q.tile_mask == nullptr) || (q.row_order && q.steps > 32))
+            return fail(CTGCN_E_INVALID, "gru_layer_presplit_group: bad arguments of group %d", i);
+        LayerArgs &a = host[i];
+        a = LayerArgs{};
+        a.rows = rows; a.steps = q.steps; a.x = nullptr; a.ldx = GRU_H; a.wih = q.w_ih; a.whh = q.w_hh; a.bias_gi = q.bias_gi; a.bhn = q.b_hn;
+        a.gamma = q.ln_weight; a.beta = q.ln_bias; a.eps = q.ln_eps; a.out = q.out; a.ldo = q.ld_out > 0 ? q.ld_out : GRU_H;
+        const size_t nrow = (size_t)rows * q.steps;
+        a.xp1 = (const _Float16 *)q.planes; a.xp2 = a.xp1 + nrow * GRU_H; a.xps = (const float *)(a.xp2 + nrow * GRU_H);
+        a.order = q.row_order; a.tmask = q.tile_mask;
+        total += q.work > 0 ? (double)q.work : 1.0;
+    }
+    // blocks per snapshot in proportion to its work (cumulative snapshots grow with t), at least one, at most its tiles; <= one block per CU in total
+    std::vector<int32_t> nb((size_t)groups), map;
+    int64_t used = 0;
+    if (groups > cus) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit_group: more snapshots (%d) than CUs (%d): split the window", groups, cus);
+    for (int i = 0; i < groups; ++i) {
+        const double w = g[i].work > 0 ? (double)g[i].work : 1.0;
+        int64_t b = (int64_t)(w / total * (cus - groups)) + 1;
+        if (b > ntiles) b = ntiles;
+        nb[i] = (int32_t)b;
+        used += b;
+    }
+    map.reserve((size_t)used * 3);
+    // interleave the snapshots' blocks (block b of every snapshot before block b + 1 of any): neighbours in dispatch order start on different snapshots
+    for (int32_t b = 0, more = 1; more; ++b) {
+        more = 0;
+        for (int i = 0; i < groups; ++i)
+            if (b < nb[i]) { map.push_back(i); map.push_back(b); map.push_back(nb[i]); more = 1; }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *tb = (char *)table;
+    const size_t map_off = ((size_t)groups * (sizeof(AggSplitGroup) > sizeof(LayerArgs) ? sizeof(AggSplitGroup) : sizeof(LayerArgs)) + 255) / 256 * 256;
+    HIP_TRY(hipMemcpyAsync(tb, host.data(), host.size() * sizeof(LayerArgs), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(tb + map_off, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gru_layer8_h2_group_kernel, dim3((unsigned)used), dim3(512), 0, st, (const LayerArgs *)tb, (const int32_t *)(tb + map_off));
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -211,6 +211,47 @@ class CTGCN(nn.Module):
                     return False                                # ops.aggregate_split_ok would send it to the fp32 H + library path
         return True
 
+    def _group_start(self, adj_list, T):
+        """Index of the first CoreDiffusion layer from which every later layer of every snapshot is 128 -> 128 (the shape of the grouped
+        launches, ops.core_diffusion_split_group), or None: 'C' configs -> their second layer, 'S' -> their only one."""
+        from . import ops
+        if not ops.group_launch_enabled() or T < 2 or self.rnn_type != 'GRU' or self.output_dim != 128 or not hasattr(adj_list[0], "n"):
+            return None
+        if adj_list[0].n > ops._GROUP_MAX_NODES:
+            return None
+        L = self.diffusion_num
+        g0 = L
+        for l in reversed(range(L)):
+            if all(cdn.diffusion_list[l].input_dim == 128 and cdn.diffusion_list[l].output_dim == 128 for cdn in self.duffision_list):
+                g0 = l
+            else:
+                break
+        return g0 if g0 < L else None
+
+    def _grouped_layers(self, g0, hs, adj_list, seq):
+        """CoreDiffusion layers g0 .. of every snapshot, one aggregation launch + one GRU launch per layer for the whole window (reference
+        models.py:243-247 loops over the snapshots); the last layer writes column t of the temporal GRU's input."""
+        from . import ops
+        from .layers import as_core_adj
+        T, L = len(hs), self.diffusion_num
+        adjs = [as_core_adj(adj_list[t], hs[t].device) for t in range(T)]
+        for l in range(g0, L):
+            mods = [self.duffision_list[t].diffusion_list[l] for t in range(T)]
+            last = l == L - 1
+            outs = [seq[:, t] if last else torch.empty(hs[t].shape[0], self.output_dim, dtype=hs[t].dtype, device=hs[t].device) for t in range(T)]
+            rnns, norms = [m.rnn for m in mods], [m.norm for m in mods]
+            if ops.core_diffusion_group_ok(hs, adjs, rnns, norms):
+                ops.core_diffusion_split_group(hs, adjs, rnns, norms, outs)
+            else:                                        # e.g. a hub row in one snapshot: that window takes the per-snapshot launches
+                for t in range(T):
+                    r = mods[t](hs[t], adjs[t], out=outs[t] if last else None)
+                    if last and r.data_ptr() != outs[t].data_ptr():
+                        outs[t].copy_(r)
+                    elif not last:
+                        outs[t] = r
+            hs = outs
+        return hs
+
     def forward(self, x_list, adj_list):
         if self.process_group is not None:
             return sp_par.ctgcn_forward_sharded(self, x_list, adj_list)
@@ -224,7 +265,35 @@ class CTGCN(nn.Module):
             p0 = next(self.parameters())
             seq = torch.empty(n, T, self.output_dim, dtype=p0.dtype, device=p0.device)
         lanes = self._snapshot_streams(seq, n if seq is not None else 0, T, x_list)
-        if lanes:
+        g0 = self._group_start(adj_list, T) if (seq is not None and seq.is_cuda) else None
+        if g0 is not None:
+            # small window: the MLP and the layers before g0 per snapshot (on the lanes), then the width-128 layers of ALL snapshots per launch
+            def head(t):
+                tr = self.mlp_list[t](x_list[t])
+                h = tr
+                for l in range(g0):
+                    h = self.duffision_list[t].diffusion_list[l](h, adj_list[t])
+                return h, tr
+            if lanes:
+                main = torch.cuda.current_stream(seq.device)
+                for s_ in lanes:
+                    s_.wait_stream(main)
+                for t in range(T):
+                    with torch.cuda.stream(lanes[t % len(lanes)]):
+                        h, tr = head(t)
+                        h.record_stream(main)
+                        tr.record_stream(main)
+                    hx.append(h)
+                    trans.append(tr)
+                for s_ in lanes:
+                    main.wait_stream(s_)
+            else:
+                for t in range(T):
+                    h, tr = head(t)
+                    hx.append(h)
+                    trans.append(tr)
+            self._grouped_layers(g0, hx, adj_list, seq)
+        elif lanes:
             # inference on a small graph: the snapshot branches are independent until the temporal GRU (models.py:243-247) and their
             # kernels are too short to fill the chip one after the other — run them on a few HIP streams, join before the head
             main = torch.cuda.current_stream(seq.device)

@@ -724,6 +724,87 @@ def core_diffusion_fused(x, adj, rnn, norm):
     return _CoreDiffusionFused.apply(x, adj, rnn.weight_ih_l0, rnn.weight_hh_l0, b_ih, b_hh, norm.weight, norm.bias, float(norm.eps))
 
 
+# ------------------------------------------------------------- a window of small snapshots: one launch per kernel
+_GROUP_MAX_NODES = 200_000
+
+
+def group_launch_enabled():
+    """CTGCN_GROUP=0: every snapshot launches its own kernels (round 3's path: four HIP streams overlap the tails) for A/B runs."""
+    import os
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return False               # the grouped calls copy their descriptor tables from host memory: not capturable into a hipGraph
+    return os.environ.get("CTGCN_GROUP", "1") != "0"
+
+
+def core_diffusion_group_ok(xs, adjs, rnns, norms):
+    """The width-128 CoreDiffusion layer of a window's snapshots in ONE aggregation launch + ONE GRU layer launch
+    (ctgcn_core_aggregate_split_group_f32 / ctgcn_gru_layer_presplit_group_f32): inference, >= 2 snapshots of a small graph that share
+    the node set, no hub rows, every snapshot fit for the per-snapshot split path."""
+    if not group_launch_enabled() or len(xs) < 2 or len(xs) > 200:
+        return False
+    n = adjs[0].n
+    if n > _GROUP_MAX_NODES:
+        return False
+    planned = None
+    for x, adj, rnn, norm in zip(xs, adjs, rnns, norms):
+        if adj.n != n or x.dim() != 2 or x.shape[1] != 128 or rnn.hidden_size != 128 or not aggregate_split_ok(rnn, x, adj):
+            return False
+        if adj.K > 32 or adj.long_rows() is not None or not isinstance(norm, torch.nn.LayerNorm) or norm.weight is None or norm.bias is None:
+            return False
+        p = (adj.row_plan() is not None) if row_plan_enabled() else False
+        if planned is None:
+            planned = p
+        if p != planned:
+            return False
+    return True
+
+
+def core_diffusion_split_group(xs, adjs, rnns, norms, outs):
+    """outs[t] = LayerNorm(sum_k GRU_t(relu(cumulative A_{t,k} xs[t]))_k) for every snapshot t of the window — core_diffusion_split(d = 128)
+    per snapshot, as two launches for the whole window.  Bit-identical to the per-snapshot calls (same kernels' code per snapshot)."""
+    lib = _lib.load()
+    T = len(xs)
+    n = adjs[0].n
+    dev = xs[0].device
+    agg = (_lib.AggSplitGroup * T)()
+    lay = (_lib.GruLayerGroup * T)()
+    keep = []                                         # tensors the descriptors point at, alive until the launches are queued
+    use_plan = row_plan_enabled()
+    with torch.cuda.device(dev):
+        tb_bytes = int(lib.ctgcn_group_table_bytes(T))
+        table = torch.empty(tb_bytes, dtype=torch.uint8, device=dev)
+        for t, (x, adj, rnn, norm, out) in enumerate(zip(xs, adjs, rnns, norms, outs)):
+            K = adj.K
+            plan = adj.row_plan() if use_plan else None
+            ws_bytes = int(lib.ctgcn_core_aggregate_split_workspace_bytes(n, 128, K, 1, 0))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            bias, b_hn = _gru_bias(rnn, 128)
+            w_ih, w_hh = rnn.weight_ih_l0.detach(), rnn.weight_hh_l0.detach().contiguous()
+            keep.append((ws, bias, b_hn, w_hh, x))
+            a = agg[t]
+            a.row_ptr, a.col_idx, a.val, a.slot = ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot)
+            a.X, a.ldx, a.K, a.flags = ptr(x), x.stride(0), K, adj.flags | _lib.F_RELU
+            a.row_order = ptr(plan["order"]) if plan is not None else None
+            a.tile_mask = ptr(plan["tile_mask"]) if plan is not None else None
+            a.workspace, a.workspace_bytes = ptr(ws), ws_bytes
+            g = lay[t]
+            g.planes, g.w_ih, g.w_hh, g.bias_gi, g.b_hn = ptr(ws), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(b_hn)
+            g.ln_weight, g.ln_bias, g.ln_eps, g.steps = ptr(norm.weight), ptr(norm.bias), float(norm.eps), K
+            g.out, g.ld_out = ptr(out), out.stride(0)
+            g.row_order, g.tile_mask = a.row_order, a.tile_mask
+            g.work = (plan["new_rows"] if plan is not None else n * K) + n * K
+        nnz = sum(adj.nnz for adj in adjs)
+        rows_written = sum((adj.row_plan()["new_rows"] if use_plan else n * adj.K) for adj in adjs)
+        with _timed("agg_fwd", n=n, d=128, K=max(adj.K for adj in adjs), nnz=nnz, split=True, group=T, rows_written=rows_written,
+                    K_sum=sum(adj.K for adj in adjs)):
+            check(lib.ctgcn_core_aggregate_split_group_f32(T, n, 128, agg, ptr(table), tb_bytes, _stream()), "ctgcn_core_aggregate_split_group_f32")
+        with _timed("gru_layer", rows=n, steps=max(adj.K for adj in adjs), reduce_sum=True, presplit=True, group=T, new_rows=rows_written,
+                    row_steps=sum(n * adj.K for adj in adjs)):
+            check(lib.ctgcn_gru_layer_presplit_group_f32(T, n, 128, lay, ptr(table), tb_bytes, _stream()), "ctgcn_gru_layer_presplit_group_f32")
+    del keep
+    return outs
+
+
 def _accumulate_tn(out, a2d, b2d):
     """out[M,N] += a2d[R,M]^T @ b2d[R,N] for R >> M,N (weight gradients: R = rows*steps).  A plain TN GEMM with a
     384x128 output only fills a few dozen workgroups; splitting R into S batches (strided batched GEMM, no copies)

@@ -303,6 +303,48 @@ int ctgcn_gru_bwd_in_f32(int64_t rows, int32_t steps, int32_t hidden, const floa
                          int32_t accumulate, void *stream);
 
 /*
+ * One launch per kernel for a whole WINDOW of small snapshots (reference models.py:243-247 loops over the snapshots; at 6 828 - 87 036 nodes a
+ * snapshot's aggregation is 25 - 200 us of kernel, mostly ramp, tail and dependent load chains): the width-128 CoreDiffusion layer of `groups`
+ * snapshots that share the node set (n_rows each), every snapshot with its own graph, inputs, weights and outputs.
+ *   ctgcn_core_aggregate_split_group_f32   = ctgcn_core_aggregate_split_f32(d = 128, n_out = 1, no hub rows) per group, one grid
+ *   ctgcn_gru_layer_presplit_group_f32     = ctgcn_gru_layer_presplit_f32 per group, one persistent grid of <= one block per CU: a block serves
+ *                                            one snapshot (its weights stay resident), blocks are dealt out in proportion to `work`
+ * Same kernels' code per snapshot: bit-identical to the per-snapshot calls.  g: HOST array of `groups` descriptors; table: device scratch,
+ * 256-byte aligned, ctgcn_group_table_bytes(groups) bytes, written by an asynchronous copy on `stream` before the launch (do not reuse it for
+ * another call before that call's kernel has run — same stream: fine).  Hub rows (longer than the caller's long-row threshold) are not
+ * handled here: windows that have any take the per-snapshot calls.
+ */
+typedef struct {
+    const int32_t *row_ptr, *col_idx;
+    const float *val;
+    const uint8_t *slot;
+    const float *X;
+    int64_t ldx;
+    int32_t K;
+    uint32_t flags;
+    const int32_t *row_order;      /* row plan (both or neither), as ctgcn_core_aggregate_split_f32 */
+    const uint32_t *tile_mask;
+    void *workspace;               /* planes + row scales: ctgcn_core_aggregate_split_workspace_bytes(n_rows, 128, K, 1, 0) bytes, 256-byte aligned */
+    size_t workspace_bytes;
+} ctgcn_agg_split_group_t;
+typedef struct {
+    const void *planes;            /* the group's aggregation workspace */
+    const float *w_ih, *w_hh, *bias_gi, *b_hn, *ln_weight, *ln_bias;
+    float ln_eps;
+    int32_t steps;                 /* K of the snapshot */
+    float *out;
+    int64_t ld_out;
+    const int32_t *row_order;
+    const uint32_t *tile_mask;
+    int64_t work;                  /* relative cost (e.g. (position, step) rows that bring a new x + rows x steps); <= 0: equal shares */
+} ctgcn_gru_layer_group_t;
+size_t ctgcn_group_table_bytes(int32_t groups);
+int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t d, const ctgcn_agg_split_group_t *g, void *table, size_t table_bytes,
+                                         void *stream);
+int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_layer_group_t *g, void *table, size_t table_bytes,
+                                       void *stream);
+
+/*
  * Dense  y[rows, n_out] = x[rows, k]·w[n_out, k]^T + bias  (bias [n_out] may be NULL) in fp32-accurate fp16x2 split arithmetic on the
  * matrix cores (CTGCN_SPLIT_F16X2: operand rows scaled by a power of two and written as two fp16 terms, three
  * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation) - the GRU input projection for d_in != 128 (layers.py:59 with

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
     for (int ut = 0; ut < 3; ++ut)
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) acc[ut][jt] = zero4;
-    f4v bs[3] = {zero4, zero4, zero4};
+    f4v bsum = zero4;                                      // threads 0-95: column sums of dgi (4 gate columns each) over the block's units
 
     // staging roles: dgi 16 rows x 96 float4 -> three per thread (same columns for every unit: the bias sums stay per thread);
     // x 16 rows x 32 lanes x 4 values
@@ -379,7 +379,6 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
             split4(gv[i], h, l);
             *(bf4v *)(&Gs[gr_[i] * GP + gc_[i]]) = h;
             *(bf4v *)(&Gs[(16 + gr_[i]) * GP + gc_[i]]) = l;
-            bs[i] += gv[i];
         }
         f4v x;
         if (PLANES) {
@@ -412,6 +411,16 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
         f4v dxv = zero4;
         if (!(a.ablate & 4)) dxv = gate_product(Gs, Wh, wl, col, grp);
         if (!(a.ablate & 2)) weight_grad_block(Gs, Xs, wave, lane, acc);
+        if (tid < 96) {
+            // d b_ih: column sums of the unit's dgi rows, read back from the planes (hi + lo = the value to 2^-17: what the products see);
+            // 96 threads x 4 columns — per-thread sums over the staging registers cost 12 registers on every thread and spilled
+#pragma unroll 4
+            for (int r = 0; r < 16; ++r) {
+                const bf4v h = *(const bf4v *)(&Gs[r * GP + 4 * tid]), l = *(const bf4v *)(&Gs[(16 + r) * GP + 4 * tid]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bsum[j] += (float)h[j] + (float)l[j];
+            }
+        }
         const int64_t row0 = cur.tile * 16;
         const bool valid = row0 + col < a.rows && !(a.ablate & 1);
         if (ZOUT) {
@@ -434,17 +443,9 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
         cur = nxt;
     }
     store_weight_grad(a.dw_part, wave, lane, a.accumulate, acc);
-    // bias sums: thread tid holds columns gc_[i] .. +3 of staging rows gr_[i]; add the 16 (or 5 / 6: 512 threads over 96 columns) rows
-    __syncthreads();
-    float *red = (float *)Gs;                              // 3 x 512 float4 = 24 KB of scratch
-#pragma unroll
-    for (int i = 0; i < 3; ++i) *(f4v *)(&red[(i * 512 + tid) * 4]) = bs[i];
-    __syncthreads();
     if (tid < 96) {
-        f4v s = zero4;
-        for (int idx = tid; idx < 1536; idx += 96) s += *(const f4v *)(&red[idx * 4]);     // idx = staging slot: column (idx % 96) * 4
         f4v *o = (f4v *)(a.dbi_part + (int64_t)blockIdx.x * G3 + tid * 4);
-        *o = a.accumulate ? *o + s : s;
+        *o = a.accumulate ? *o + bsum : bsum;
     }
 }
 

@@ -251,6 +251,9 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
                 split4(dgn, h, l); *(bf4v *)(&Gs[col * GP + 2 * GH + oc]) = h; *(bf4v *)(&Gs[(16 + col) * GP + 2 * GH + oc]) = l;
                 split4(hp, h, l); *(bf4v *)(&Hs[col * HP + oc]) = h; *(bf4v *)(&Hs[(16 + col) * HP + oc]) = l;
             }
+            // the next step's operands are requested BEFORE this step's stores: memory operations retire in order, a wait for the loads would
+            // otherwise wait for the stores' round trip as well
+            if (t > 0 && !(a.ablate & 8)) load_step(t - 1);   // in flight during the products below
             if ((tmask >> t) & 1) {
                 if (valid && !(a.ablate & 1)) {
                     float *o = a.dgi + (row * S + t) * G3 + oc;
@@ -259,7 +262,6 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
                 gs0 = gs1 = gs2 = zero4;
             }
             if (t == 0) break;
-            if (!(a.ablate & 8)) load_step(t - 1);         // in flight during the products below
             __syncthreads();
             if (!(a.ablate & 4)) drec += gate_product(Gs, Wh, wl, col, grp);
             if (!(a.ablate & 2)) weight_grad_block(Gs, Hs, wave, lane, acc);
@@ -360,9 +362,8 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int64_t r = min(row0 + gr_[i], lastrow);
-            gv[i] = *(const f4v *)(a.dgi + (r * S + u.t) * G3 + gc_[i]);
-            if (row0 + gr_[i] > lastrow) gv[i] = zero4;
-        }
+            gv[i] = *(const f4v *)(a.dgi + (r * S + u.t) * G3 + gc_[i]);      // rows past the end are zeroed when they are STAGED: a select
+        }                                                                        // here would wait for the load it follows
         const int64_t e = min(row0 + xr, lastrow) * S + u.t;
         if (PLANES) {
             xq1 = *(const h4v *)(a.xp1 + e * GH + xc);
@@ -372,11 +373,11 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
             xv = *(const f4v *)(a.x + e * a.ldx + xc);
         }
     };
-    auto stage_unit = [&]() {
+    auto stage_unit = [&](const Unit u) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             bf4v h, l;
-            split4(gv[i], h, l);
+            split4(u.tile * 16 + gr_[i] < a.rows ? gv[i] : zero4, h, l);
             *(bf4v *)(&Gs[gr_[i] * GP + gc_[i]]) = h;
             *(bf4v *)(&Gs[(16 + gr_[i]) * GP + gc_[i]]) = l;
         }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
             const int top = 31 - __builtin_clz(cur.mask & (S >= 32 ? 0xffffffffu : ((1u << S) - 1u)));
             if (cur.t == top) orow_c = orow_n;
         }
-        stage_unit();
+        stage_unit(cur);
         Unit nxt = cur;
         next_unit(nxt);
         if (!(a.ablate & 8)) load_unit(nxt);               // in flight during the products

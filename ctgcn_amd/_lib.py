@@ -60,6 +60,10 @@ SIGNATURES = {
     "ctgcn_lstm_seq_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "ctgcn_gru_layer_f32": (_int, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _i64, _vp, _vp, _i64, _vp]),
     "ctgcn_linear_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "ctgcn_split_planes_bytes": (_sz, [_i64, _i32]),
+    "ctgcn_split_rows_f32": (_int, [_i64, _i32, _vp, _i64, _vp, _sz, _vp]),
+    "ctgcn_chain_planes_bytes": (_sz, [_i64, _i32]),
+    "ctgcn_linear_planes_f32": (_int, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _sz, _vp]),
     "ctgcn_linear_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _sz, _vp]),
     "ctgcn_core_aggregate_split_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "ctgcn_core_aggregate_split_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _u32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp, _sz, _vp]),

@@ -150,6 +150,14 @@ struct GemmArgs {
     int64_t ldy;
     int64_t mtiles;
     int32_t ntiles;
+    // chained layers (round 4, ctgcn_linear_planes_f32 with x_scale_blocks > 1 / planes out): the A operand's scales are per (row, block of
+    // 128 k) — sa[m * sa_blocks + k / 128] — as a producer GEMM's 128-column tiles write them; the accumulators are rescaled (exactly: the
+    // scales are powers of two) where the block changes.  o1 != null: instead of y the epilogue writes the NEXT layer's operand: planes
+    // o1 / o2 [M, okp] and scales os [M, ntiles], this block's 128 columns under one scale per row.
+    int32_t sa_blocks;
+    _Float16 *o1, *o2;
+    float *os;
+    int32_t okp;
 #ifdef CTGCN_GEMM_TIMELINE
     unsigned long long *timeline;   // diagnostic build (-DCTGCN_GEMM_TIMELINE): 8 words per block, see tools/gemm_timeline.py
 #endif
@@ -178,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const f16v (&ac
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) sc[i][v] = a.sa[mbase + i * 32 + 8 * (v / 4) + (v % 4)];
+            for (int v = 0; v < 16; ++v) sc[i][v] = a.sa[(mbase + i * 32 + 8 * (v / 4) + (v % 4)) * a.sa_blocks + (a.sa_blocks - 1)];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             sb[j] = a.sb[nbase + j * 32];
@@ -205,8 +213,73 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const f16v (&ac
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int64_t m = mbase + i * 32 + 8 * (v / 4) + (v % 4);
-                if (m < a.M) a.y[m * a.ldy + n] = gemm_act(fmaf(acc[i][j][v], a.sa[m] * sb, bs), a.act);
+                if (m < a.M) a.y[m * a.ldy + n] = gemm_act(fmaf(acc[i][j][v], a.sa[m * a.sa_blocks + (a.sa_blocks - 1)] * sb, bs), a.act);
             }
+    }
+}
+
+// Epilogue of a chained layer: the block's 128 x 128 tile of act(acc sa sb + bias) leaves as the next GEMM's operand — per row ONE power-of-two
+// scale for the tile's 128 columns + two fp16 planes (split_rows_h2_kernel's split under a per-(row, 128-column block) scale).  The tile goes
+// through LDS in two halves of 64 rows (the k loop's stages are free by then): the waves of a half write their 64 x 64 fp32 tiles, then thread
+// (row, quarter) takes 32 columns of a row — row maximum across the row's four threads, scale, split, 2 x 64 bytes out.
+__device__ __forceinline__ void gemm_epilogue_planes(const GemmArgs &a, const f16v (&acc)[2][2], float *tile /* [64][132] */, int64_t m0, int n0, int nt,
+                                                     int wm, int wn, int tid, int lane)
+{
+    constexpr int TP = 132;
+    const int nb = (lane & 31);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                  // LDS free: the k loop's last reads (half 0) / the previous half's reads are done
+        if (wm == half) {
+            const int64_t mbase = m0 + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + nb;
+                const bool live = n < a.N;
+                const float sb = live ? a.sb[n] : 0.f, bs = (live && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int r = i * 32 + 8 * (v / 4) + (v % 4);
+                        const int64_t m = min(mbase + r, a.M - 1);
+                        const float y = live ? gemm_act(fmaf(acc[i][j][v], a.sa[m * a.sa_blocks + (a.sa_blocks - 1)] * sb, bs), a.act) : 0.f;
+                        tile[(r + 4 * (lane >> 5)) * TP + wn * 64 + j * 32 + nb] = y;
+                    }
+            }
+        }
+        __syncthreads();
+        const int r = tid >> 2, q = tid & 3;              // 64 rows x 4 quarters of 32 columns
+        const int64_t m = m0 + half * 64 + r;
+        f4v v[8];
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            v[c] = *(const f4v *)(&tile[r * TP + q * 32 + 4 * c]);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[c][0]), fabsf(v[c][1])), fmaxf(fabsf(v[c][2]), fabsf(v[c][3]))));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        float sc, inv;
+        h2_scale(mx, sc, inv);
+        if (m < a.M) {
+            if (q == 0) a.os[m * a.ntiles + nt] = sc;
+            const int k0 = n0 + q * 32;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (k0 + 8 * c < a.okp) {                 // okp is a multiple of 64: a 8-column group is inside or outside as a whole
+                    h8v p, qv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xs = v[2 * c + e / 4][e % 4] * inv;
+                        p[e] = (_Float16)xs;
+                        qv[e] = (_Float16)(xs - (float)p[e]);
+                    }
+                    *(h8v *)(a.o1 + m * a.okp + k0 + 8 * c) = p;
+                    *(h8v *)(a.o2 + m * a.okp + k0 + 8 * c) = qv;
+                }
+            }
+        }
     }
 }
 
@@ -227,6 +300,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const f16v (&ac
 // The matrix pipe itself sustains 1.93 PFLOP/s on v_mfma_f32_32x32x16_f16 with real operands (tools/probes/mfma_peak_probe.hip),
 // not the 2.5 of the data sheet.  Measured and NOT faster: a 256 x 128 tile with 64 x 128 wave tiles at one wave per SIMD (1.09 vs
 // 1.08 ms per projection, slower on the short MLP shapes), tile-contiguous global addresses (-6 %), staggered block starts (0).
+// CHAIN: the layer-chain form (per-block A scales and / or planes out); the plain form keeps round 2's code and registers untouched
+template <bool CHAIN>
 __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 {
     constexpr int BM = 128;
@@ -335,15 +410,39 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 #ifdef CTGCN_GEMM_TIMELINE
     T1 = wall_clock64();
 #endif
-    for (int kt = 0; kt < nk; kt += 2) {                  // unrolled by two: each register set keeps its registers
-        step(kt, 1);
-        step(kt + 1, 0);
+    if (CHAIN && a.sa_blocks > 1) {
+        // A operand scaled per (row, block of 128 k = 4 k steps): entering block b the accumulators change units, acc *= s[m][b-1] / s[m][b]
+        // (powers of two: exact).  D layout: lane l holds rows 8 (v / 4) + 4 (l >> 5) + v % 4 of each 32-row tile.
+        const int64_t mrow = m0 + wm * 64 + 4 * (lane >> 5);
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt > 0 && (kt & 3) == 0) {
+                const int b = kt >> 2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int64_t m = min(mrow + i * 32 + 8 * (v / 4) + (v % 4), a.M - 1);
+                        const float ratio = a.sa[m * a.sa_blocks + b - 1] * __builtin_amdgcn_rcpf(a.sa[m * a.sa_blocks + b]);
+                        acc[i][0][v] *= ratio;
+                        acc[i][1][v] *= ratio;
+                        if ((v & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four rows at a time: hoisting all 64 scale loads spills the k loop
+                    }
+            }
+            step(kt, 1);
+            step(kt + 1, 0);
+        }
+    } else {
+        for (int kt = 0; kt < nk; kt += 2) {              // unrolled by two: each register set keeps its registers
+            step(kt, 1);
+            step(kt + 1, 0);
+        }
     }
 
 #ifdef CTGCN_GEMM_TIMELINE
     T2 = wall_clock64();
 #endif
-    gemm_epilogue<2, 2>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, m0 + BM <= a.M && n0 + BN <= a.N);
+    if (CHAIN && a.o1) gemm_epilogue_planes(a, acc, (float *)&As[0][0][0][0], m0, n0, nt, wm, wn, tid, lane);
+    else gemm_epilogue<2, 2>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, m0 + BM <= a.M && n0 + BN <= a.N);
 #ifdef CTGCN_GEMM_TIMELINE
     if (a.timeline && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)");           // the block's stores have left
@@ -414,6 +513,7 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
     launch_split(n_out, k, kp, w, ldw, b1, b2, sb, nullptr, 1, 1.f, st);
     GemmArgs g{};
     g.M = rows; g.N = n_out; g.Kp = kp; g.a1 = a1; g.a2 = a2; g.b1 = b1; g.b2 = b2; g.sa = sa; g.sb = sb; g.bias = bias; g.act = act; g.y = y; g.ldy = ldy;
+    g.sa_blocks = 1;
     g.ntiles = (n_out + BN - 1) / BN;
     g.mtiles = (rows + 127) / 128;
     const int64_t blocks = (g.mtiles + 7) / 8 * 8 * g.ntiles;
@@ -427,7 +527,7 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
         (void)hipMemsetAsync(g.timeline, 0, (size_t)blocks * 64, st);
     }
 #endif
-    hipLaunchKernelGGL(gemm_h2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gemm_h2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
 #ifdef CTGCN_GEMM_TIMELINE
     if (g.timeline) {
         (void)hipStreamSynchronize(st);
@@ -440,6 +540,74 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
         (void)hipFree(g.timeline);
     }
 #endif
+    GEMM_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+size_t ctgcn_split_planes_bytes(int64_t rows, int32_t k)
+{
+    if (rows < 0 || k < 1) return 0;
+    const size_t kp = align_up((size_t)k, 2 * BK);
+    return align_up((size_t)rows * kp * 4 + (size_t)rows * 4, 256);
+}
+
+int ctgcn_split_rows_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, void *planes, size_t planes_bytes, void *stream)
+{
+    if (rows < 0 || k < 1 || ldx < k) return ctgcn_set_error_(CTGCN_E_INVALID, "split_rows: bad sizes");
+    if (rows == 0) return CTGCN_OK;
+    if (!x || !planes || (reinterpret_cast<uintptr_t>(x) & 3u) || (reinterpret_cast<uintptr_t>(planes) & 255u))
+        return ctgcn_set_error_(CTGCN_E_INVALID, "split_rows: x 4-byte aligned, planes 256-byte aligned");
+    if (planes_bytes < ctgcn_split_planes_bytes(rows, k)) return ctgcn_set_error_(CTGCN_E_WORKSPACE, "split_rows: planes buffer too small (ctgcn_split_planes_bytes)");
+    const int32_t kp = (int32_t)align_up((size_t)k, 2 * BK);
+    _Float16 *p1 = (_Float16 *)planes, *p2 = p1 + (size_t)rows * kp;
+    float *sc = (float *)(p2 + (size_t)rows * kp);
+    launch_split(rows, k, kp, x, ldx, p1, p2, sc, nullptr, 1, 1.f, (hipStream_t)stream);
+    GEMM_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+size_t ctgcn_chain_planes_bytes(int64_t rows, int32_t n_out)
+{
+    if (rows < 0 || n_out < 1) return 0;
+    const size_t kp = align_up((size_t)n_out, 2 * BK), nblk = (size_t)(n_out + BN - 1) / BN;
+    return align_up((size_t)rows * kp * 4 + (size_t)rows * nblk * 4, 256);
+}
+
+int ctgcn_linear_planes_f32(int64_t rows, int32_t n_out, int32_t k, const void *x_planes, int32_t x_scale_blocks, const void *w_planes,
+                            const float *bias, int32_t activation, float *y, int64_t ldy, void *y_planes, size_t y_planes_bytes, void *stream)
+{
+    if (rows < 0 || n_out < 1 || k < 1 || (y && ldy < n_out) || ((y == nullptr) == (y_planes == nullptr)))
+        return ctgcn_set_error_(CTGCN_E_INVALID, "linear_planes: bad sizes (exactly one of y / y_planes)");
+    {
+        const int32_t kp_ = (int32_t)align_up((size_t)k, 2 * BK);
+        if (x_scale_blocks < 1 || (x_scale_blocks > 1 && x_scale_blocks != (kp_ + 127) / 128))
+            return ctgcn_set_error_(CTGCN_E_INVALID, "linear_planes: x_scale_blocks must be 1 or ceil(kp / 128)");
+        if (y_planes && ((reinterpret_cast<uintptr_t>(y_planes) & 255u) || y_planes_bytes < ctgcn_chain_planes_bytes(rows, n_out)))
+            return ctgcn_set_error_(CTGCN_E_WORKSPACE, "linear_planes: y_planes must be 256-byte aligned and hold ctgcn_chain_planes_bytes(rows, n_out) bytes");
+    }
+    if (activation != CTGCN_ACT_NONE && activation != CTGCN_ACT_SELU) return ctgcn_set_error_(CTGCN_E_INVALID, "linear_planes: unknown activation");
+    if (rows == 0) return CTGCN_OK;
+    if (!x_planes || !w_planes || (reinterpret_cast<uintptr_t>(x_planes) & 255u) || (reinterpret_cast<uintptr_t>(w_planes) & 255u))
+        return ctgcn_set_error_(CTGCN_E_INVALID, "linear_planes: null or misaligned (256 bytes) plane buffers");
+    const int32_t kp = (int32_t)align_up((size_t)k, 2 * BK);
+    GemmArgs g{};
+    g.M = rows; g.N = n_out; g.Kp = kp;
+    g.a1 = (const _Float16 *)x_planes; g.a2 = g.a1 + (size_t)rows * kp; g.sa = (const float *)(g.a2 + (size_t)rows * kp);
+    g.b1 = (const _Float16 *)w_planes; g.b2 = g.b1 + (size_t)n_out * kp; g.sb = (const float *)(g.b2 + (size_t)n_out * kp);
+    g.bias = bias; g.act = activation; g.y = y; g.ldy = ldy; g.sa_blocks = x_scale_blocks;
+    if (y_planes) {
+        g.okp = (int32_t)align_up((size_t)n_out, 2 * BK);
+        g.o1 = (_Float16 *)y_planes; g.o2 = g.o1 + (size_t)rows * g.okp; g.os = (float *)(g.o2 + (size_t)rows * g.okp);
+    }
+    g.ntiles = (n_out + BN - 1) / BN;
+    g.mtiles = (rows + 127) / 128;
+    const int64_t blocks = (g.mtiles + 7) / 8 * 8 * g.ntiles;
+    if (blocks > 0x7fffffffLL) return ctgcn_set_error_(CTGCN_E_INVALID, "linear_planes: too many tiles for one launch; split the rows");
+#ifdef CTGCN_GEMM_TIMELINE
+    g.timeline = nullptr;
+#endif
+    if (x_scale_blocks > 1 || y_planes) hipLaunchKernelGGL(gemm_h2_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gemm_h2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

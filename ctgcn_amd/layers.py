@@ -140,13 +140,13 @@ class MLP(nn.Module):
             self.linears = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(widths[:-1], widths[1:]))
 
     @staticmethod
-    def _apply_linear(layer, h, selu=False):
+    def _apply_linear(layer, h, selu=False, static_x=False):
         """layer(h), followed by F.selu when asked (fused into the split GEMM's epilogue on that path)"""
-        out, fused = MLP._linear(layer, h, selu)
+        out, fused = MLP._linear(layer, h, selu, static_x)
         return F.selu(out) if (selu and not fused) else out
 
     @staticmethod
-    def _linear(layer, h, selu):
+    def _linear(layer, h, selu, static_x=False):
         """(layer(h), whether the activation was already applied)"""
         if h.is_sparse:          # one-hot / sparse features (helper.py:161-172)
             if _is_identity(h):  # Linear(I) = W^T + b: one pass over W instead of an N x N SpMM
@@ -158,11 +158,16 @@ class MLP(nn.Module):
         needs_grad = torch.is_grad_enabled() and (h.requires_grad or any(p.requires_grad for p in layer.parameters()))
         if not needs_grad and h.dim() == 2 and ops.linear_split_ok(h, layer.weight):
             # fp32-accurate split GEMM on the 16-bit matrix cores (inference), SELU in its epilogue
-            return ops.linear_split(h, layer.weight, layer.bias, selu=selu), bool(selu)
+            return ops.linear_split(h, layer.weight, layer.bias, selu=selu, static_x=static_x), bool(selu)
         return layer(h), False
 
     def forward(self, x):
         stack = [self.linear] if self.layer_num == 1 else list(self.linears)
-        for layer in stack:
-            x = self._apply_linear(layer, x, selu=self.activate_type == 'N')
+        if torch.is_tensor(x) and not x.is_sparse and x.is_cuda and len(stack) > 1 and not (
+                torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))) and ops.mlp_chain_ok(x, stack):
+            return ops.mlp_chain_split(x, stack, selu=self.activate_type == 'N', static_x=True)     # inference: layer to layer in operand form
+        for i, layer in enumerate(stack):
+            # the first layer's operand is the module's input — node features the callers build once and pass to every forward
+            # (train.py:72-76, embedding.py:318): its operand planes are kept between calls (ops._PlaneCache, validated by the version counter)
+            x = self._apply_linear(layer, x, selu=self.activate_type == 'N', static_x=(i == 0))
         return x

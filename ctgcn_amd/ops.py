@@ -347,9 +347,60 @@ def linear_split_ok(x2d, weight):
             and x2d.shape[0] > 0 and x2d.shape[1] >= 32 and x2d.stride(0) >= x2d.shape[1] and weight.stride(0) >= weight.shape[1])
 
 
-def linear_split(x2d, weight, bias, out=None, selu=False):
+class _PlaneCache(object):
+    """Operand planes (ctgcn_split_rows_f32) of tensors that do not change between forwards: the weights of an inference run and the node
+    features the reference builds once and feeds to every batch (train.py:72-76 -> embedding.py:318).  Keyed by storage address + shape +
+    strides, validated by identity (weak reference) and by the tensor's version counter (an in-place update — optimizer.step() — re-splits).
+    Entries die with their tensor; at most `limit` bytes are kept (least recently used first out)."""
+
+    def __init__(self, limit=48 << 30):
+        import collections
+        self.limit, self.bytes, self.entries = limit, 0, collections.OrderedDict()
+
+    def _drop(self, key):
+        e = self.entries.pop(key, None)
+        if e is not None:
+            self.bytes -= e[3]
+
+    def planes(self, t, lib):
+        import weakref
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device))
+        e = self.entries.get(key)
+        cur = torch.cuda.current_stream(t.device)
+        if e is not None and e[0]() is t and e[1] == t._version:
+            self.entries.move_to_end(key)
+            if e[5] != cur:                      # split on another stream: order behind it, keep the buffer alive for this stream too
+                cur.wait_event(e[4])
+                e[2].record_stream(cur)
+            return e[2]
+        self._drop(key)
+        rows, k = t.shape
+        nbytes = int(lib.ctgcn_split_planes_bytes(rows, k))
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+        check(lib.ctgcn_split_rows_f32(rows, k, ptr(t), t.stride(0), ptr(buf), nbytes, _stream()), "ctgcn_split_rows_f32")
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.entries[key] = (weakref.ref(t, lambda _r, key=key: self._drop(key)), t._version, buf, nbytes, ev, cur)
+        self.bytes += nbytes
+        while self.bytes > self.limit and len(self.entries) > 1:
+            self._drop(next(iter(self.entries)))
+        return buf
+
+
+_plane_cache = _PlaneCache()
+
+
+def plane_cache_enabled():
+    """CTGCN_PLANE_CACHE=0: ctgcn_linear_f32 splits both operands on every call (round 3's behaviour) for A/B runs."""
+    import os
+    return os.environ.get("CTGCN_PLANE_CACHE", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+
+
+def linear_split(x2d, weight, bias, out=None, selu=False, static_x=False):
     """out[rows, n_out] = x2d @ weight^T + bias in fp32-accurate fp16x2 split arithmetic on the matrix cores (ctgcn_linear_f32);
-    selu: F.selu applied in the GEMM's epilogue (one pass over the output less)."""
+    selu: F.selu applied in the GEMM's epilogue (one pass over the output less).
+    The weight's operand planes are split once per weight version (_PlaneCache); static_x: x2d is a tensor the caller feeds to every
+    forward unchanged (the model's input features): its planes are kept too."""
     lib = _lib.load()
     rows, k = x2d.shape
     n_out = weight.shape[0]
@@ -359,6 +410,19 @@ def linear_split(x2d, weight, bias, out=None, selu=False):
     chunk = max(128, (_LINEAR_WS_MAX // (kp * 4 + 4)) // 128 * 128)
     b = None if bias is None else bias.detach().contiguous()
     w = weight.detach()
+    if rows <= chunk and plane_cache_enabled():
+        with torch.cuda.device(x2d.device):
+            wp = _plane_cache.planes(weight, lib)
+            if static_x and not x2d.requires_grad:
+                xp = _plane_cache.planes(x2d, lib)
+            else:
+                nbytes = int(lib.ctgcn_split_planes_bytes(rows, k))
+                xp = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
+                check(lib.ctgcn_split_rows_f32(rows, k, ptr(x2d), x2d.stride(0), ptr(xp), nbytes, _stream()), "ctgcn_split_rows_f32")
+            with _timed("linear_split", rows=rows, k=k, n_out=n_out, planes=True):
+                check(lib.ctgcn_linear_planes_f32(rows, n_out, k, ptr(xp), 1, ptr(wp), ptr(b), _lib.ACT_SELU if selu else _lib.ACT_NONE, ptr(out),
+                                                  out.stride(0), None, 0, _stream()), "ctgcn_linear_planes_f32")
+        return out
     with torch.cuda.device(x2d.device):
         ws_bytes = int(lib.ctgcn_linear_workspace_bytes(min(rows, chunk), n_out, k))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2d.device)
@@ -368,6 +432,65 @@ def linear_split(x2d, weight, bias, out=None, selu=False):
             with _timed("linear_split", rows=n, k=k, n_out=n_out):
                 check(lib.ctgcn_linear_f32(n, n_out, k, ptr(xs), xs.stride(0), ptr(w), w.stride(0), ptr(b), _lib.ACT_SELU if selu else _lib.ACT_NONE,
                                            ptr(ys), ys.stride(0), ptr(ws), ws_bytes, _stream()), "ctgcn_linear_f32")
+    return out
+
+
+def mlp_chain_ok(x2d, layers):
+    """A stack of nn.Linear layers (layers.py:95-106) as one chain of split GEMMs whose epilogues write the next layer's operand planes."""
+    # default OFF: measured on the Facebook-like window (profiles/r04_mlp_chain_ab.txt) the chain is SLOWER than layer-by-layer with cached
+    # planes (30.5 vs 26.7 ms): the 500-wide layers are 16 k steps long, and the planes epilogue (tile through LDS in two halves) + the
+    # accumulator rescales cost more than the two split passes they remove.  CTGCN_MLP_CHAIN=1 runs it (tests/test_gpu_gemm.py does).
+    if len(layers) < 2 or not plane_cache_enabled() or os_environ_get("CTGCN_MLP_CHAIN", "0") != "1":
+        return False
+    if x2d.dim() != 2 or x2d.shape[0] * (-(-x2d.shape[1] // 64) * 64 * 4 + 4) > _LINEAR_WS_MAX:
+        return False
+    width = x2d.shape[1]
+    probe = x2d
+    for lin in layers:
+        if lin.weight.shape[1] != width or not linear_split_ok(probe, lin.weight) or lin.weight.shape[0] < 32:
+            return False
+        width = lin.weight.shape[0]
+        probe = torch.empty(1, width, dtype=torch.float32, device=x2d.device)
+    return True
+
+
+def os_environ_get(k, d):
+    import os
+    return os.environ.get(k, d)
+
+
+def mlp_chain_split(x2d, layers, selu, static_x=False):
+    """selu?(Linear_n(... selu?(Linear_1(x)))) — MLP.forward (layers.py:95-106) on dense features, inference: every layer is
+    ctgcn_linear_planes_f32; all but the last write fp16 operand planes + per-(row, 128-column) scales for the next one instead of fp32
+    activations (no split pass, no fp32 round trip between the layers).  The last layer's output is fp32."""
+    lib = _lib.load()
+    rows, k = x2d.shape
+    act = _lib.ACT_SELU if selu else _lib.ACT_NONE
+    with torch.cuda.device(x2d.device):
+        if static_x and not x2d.requires_grad:
+            xp = _plane_cache.planes(x2d, lib)
+        else:
+            nbytes = int(lib.ctgcn_split_planes_bytes(rows, k))
+            xp = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
+            check(lib.ctgcn_split_rows_f32(rows, k, ptr(x2d), x2d.stride(0), ptr(xp), nbytes, _stream()), "ctgcn_split_rows_f32")
+        blocks = 1
+        out = None
+        for i, lin in enumerate(layers):
+            n_out = lin.weight.shape[0]
+            wp = _plane_cache.planes(lin.weight, lib)
+            b = None if lin.bias is None else lin.bias.detach().contiguous()
+            last = i == len(layers) - 1
+            with _timed("linear_split", rows=rows, k=k, n_out=n_out, planes=True, chain=True):
+                if last:
+                    out = torch.empty(rows, n_out, dtype=torch.float32, device=x2d.device)
+                    check(lib.ctgcn_linear_planes_f32(rows, n_out, k, ptr(xp), blocks, ptr(wp), ptr(b), act, ptr(out), n_out, None, 0, _stream()),
+                          "ctgcn_linear_planes_f32")
+                else:
+                    ybytes = int(lib.ctgcn_chain_planes_bytes(rows, n_out))
+                    yp = torch.empty(ybytes, dtype=torch.uint8, device=x2d.device)
+                    check(lib.ctgcn_linear_planes_f32(rows, n_out, k, ptr(xp), blocks, ptr(wp), ptr(b), act, None, 0, ptr(yp), ybytes, _stream()),
+                          "ctgcn_linear_planes_f32")
+                    xp, k, blocks = yp, n_out, -(-n_out // 128)
     return out
 
 
@@ -586,8 +709,13 @@ def core_diffusion_split(x, adj, rnn, norm, out=None):
         rows = plan["operand_rows"] if plan is not None else n * K          # under a plan the GEMM only sees rows that bring a new x
         gi_buf = torch.empty(rows * n_out, dtype=torch.float32, device=x.device) if plan is not None else _gi_buffer(n, K, hid, x.device)
         with _timed("linear_split", rows=rows, k=d, n_out=n_out, presplit=True):
-            check(lib.ctgcn_linear_presplit_f32(rows, n_out, d, ptr(w_ih), w_ih.stride(0), ptr(bias), ptr(gi_buf), n_out, ptr(ws), ws_bytes,
-                                                _stream()), "ctgcn_linear_presplit_f32")
+            if plane_cache_enabled():          # W_ih's planes: split once per weight version, not per call
+                wp = _plane_cache.planes(rnn.weight_ih_l0, lib)
+                check(lib.ctgcn_linear_planes_f32(rows, n_out, d, ptr(ws), 1, ptr(wp), ptr(bias), _lib.ACT_NONE, ptr(gi_buf), n_out, None, 0, _stream()),
+                      "ctgcn_linear_planes_f32")
+            else:
+                check(lib.ctgcn_linear_presplit_f32(rows, n_out, d, ptr(w_ih), w_ih.stride(0), ptr(bias), ptr(gi_buf), n_out, ptr(ws), ws_bytes,
+                                                    _stream()), "ctgcn_linear_presplit_f32")
         with _timed("gru_seq", rows=n, steps=K):
             check(lib.ctgcn_gru_seq_f32(n, K, hid, ptr(gi_buf), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps, 1, ptr(out), out.stride(0),
                                         None, forward_split_mode(), 0, ptr(plan["order"]) if plan is not None else None,

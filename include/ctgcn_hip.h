@@ -354,6 +354,23 @@ int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hid
  * workspace: ctgcn_linear_workspace_bytes(rows, n_out, k) bytes, 256-byte aligned (the fp16 planes + row scales of x and w).
  */
 size_t ctgcn_linear_workspace_bytes(int64_t rows, int32_t n_out, int32_t k);
+/*
+ * The same product with the operands' planes kept by the caller (round 4): an operand that does not change between calls — the weights of an
+ * inference run, the node features x_list the reference builds once and feeds to every batch (train.py:72-76) — is split ONCE:
+ *   ctgcn_split_rows_f32      rows x k fp32 (row stride ldx) -> `planes`: plane 1 | plane 2 | row scales, ctgcn_split_planes_bytes(rows, k)
+ *                             bytes, 256-byte aligned (the layout of ctgcn_linear_f32's workspace halves)
+ *   ctgcn_linear_planes_f32   y = x·w^T + bias (+ activation) from the planes of x [rows, k] and w [n_out, k]
+ * Same split, same kernel as ctgcn_linear_f32: bit-identical results.
+ * Chained layers (layers.py:95-106: Linear -> SELU -> Linear ...): with y_planes instead of y the epilogue writes the NEXT layer's operand —
+ * two fp16 planes [rows, kp(n_out)] and one power-of-two scale per (row, 128-column tile), ctgcn_chain_planes_bytes(rows, n_out) bytes — and the
+ * next call takes them with x_scale_blocks = ceil(kp / 128) (1: one scale per row, ctgcn_split_rows_f32's layout): its accumulators are rescaled
+ * exactly where the k block changes.  The fp32 activations between the layers and their split passes do not exist.
+ */
+size_t ctgcn_split_planes_bytes(int64_t rows, int32_t k);
+size_t ctgcn_chain_planes_bytes(int64_t rows, int32_t n_out);
+int ctgcn_split_rows_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, void *planes, size_t planes_bytes, void *stream);
+int ctgcn_linear_planes_f32(int64_t rows, int32_t n_out, int32_t k, const void *x_planes, int32_t x_scale_blocks, const void *w_planes,
+                            const float *bias, int32_t activation, float *y, int64_t ldy, void *y_planes, size_t y_planes_bytes, void *stream);
 int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
                      int32_t activation, float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
 

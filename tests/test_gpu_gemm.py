@@ -86,3 +86,66 @@ def test_rows_that_are_only_4_byte_aligned_and_selu_epilogue(rows, k, n_out):
     want = torch.nn.functional.selu(got)
     assert torch.allclose(act, want, rtol=2e-6, atol=1e-7), float((act - want).abs().max())
     assert bool((act[got > 0] > 0).all()) and bool((act[got < 0] < 0).all())
+
+
+def test_operand_plane_cache_follows_the_tensors(monkeypatch):
+    """ops._PlaneCache: planes of the weights / static inputs are split once, an in-place update re-splits them, results equal the
+    uncached call bit for bit"""
+    import torch
+    from ctgcn_amd import ops
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    x = torch.randn(777, 1737, device=dev)
+    w = torch.nn.Parameter(torch.randn(500, 1737, device=dev) * 0.05)
+    b = torch.randn(500, device=dev)
+    monkeypatch.setenv("CTGCN_PLANE_CACHE", "0")
+    ref = ops.linear_split(x, w, b, selu=True)
+    monkeypatch.setenv("CTGCN_PLANE_CACHE", "1")
+    ops._plane_cache.entries.clear(); ops._plane_cache.bytes = 0
+    a1 = ops.linear_split(x, w, b, selu=True, static_x=True)
+    assert len(ops._plane_cache.entries) == 2
+    a2 = ops.linear_split(x, w, b, selu=True, static_x=True)
+    assert torch.equal(a1, ref) and torch.equal(a2, ref)
+    with torch.no_grad():
+        w.mul_(2.0)                      # what optimizer.step() does: in place, version counter bumps
+        x[0, 0] = 5.0
+    monkeypatch.setenv("CTGCN_PLANE_CACHE", "0")
+    ref2 = ops.linear_split(x, w, b, selu=True)
+    monkeypatch.setenv("CTGCN_PLANE_CACHE", "1")
+    a3 = ops.linear_split(x, w, b, selu=True, static_x=True)
+    assert torch.equal(a3, ref2) and not torch.equal(a3, ref)
+    del x, w
+    import gc
+    gc.collect()
+    assert len(ops._plane_cache.entries) == 0        # entries die with their tensors
+
+
+def test_mlp_chain_matches_float64(monkeypatch):
+    """ops.mlp_chain_split: three Linear + SELU layers with operand planes handed from epilogue to main loop (per-(row, 128-column) scales,
+    accumulators rescaled at the k-block boundaries) against float64, and against the layer-by-layer path"""
+    import torch
+    from ctgcn_amd.layers import MLP
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    for rows, widths in ((1000, (1737, 500, 500, 128)), (333, (96, 200, 64)), (70, (64, 130, 500, 32))):
+        mlp = MLP(widths[0], widths[1], widths[-1], len(widths) - 1, activate_type='N')
+        # give the hidden widths of the test (MLP builds in -> hid ... hid -> out)
+        lins = [torch.nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:])]
+        mlp.linears = torch.nn.ModuleList(lins)
+        mlp.layer_num = len(lins)
+        x = torch.randn(rows, widths[0]) * torch.rand(rows, 1) * 10
+        want = x.double()
+        for lin in lins:
+            want = torch.nn.functional.selu(torch.nn.functional.linear(want, lin.weight.double(), lin.bias.double()))
+        mlp = mlp.to(dev).eval()
+        xg = x.to(dev)
+        with torch.no_grad():
+            monkeypatch.setenv("CTGCN_MLP_CHAIN", "1")
+            got = mlp(xg)
+            monkeypatch.setenv("CTGCN_MLP_CHAIN", "0")
+            ref = mlp(xg)
+        scale = want.abs().max().item()
+        e_chain = (got.double().cpu() - want).abs().max().item() / scale
+        e_layer = (ref.double().cpu() - want).abs().max().item() / scale
+        assert e_chain < 2e-6, (widths, e_chain, e_layer)
+        assert e_chain < 4 * e_layer + 1e-7, (widths, e_chain, e_layer)

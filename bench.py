@@ -557,6 +557,10 @@ def main():
                       "matrix cores (22 mantissa bits per operand, 3 MFMAs per product, fp32 accumulate; error vs fp64 asserted <= a plain fp32 "
                       "GEMM's in tests/), and in inference the aggregation hands its rows over in that split form. `exact_fp32` times the same "
                       "forward without any 16-bit operand",
+        "operand_plane_cache": "the fp16 operand planes of the dense layers' WEIGHTS and of the model's INPUT feature tensors (x_list: built once by the "
+                               "caller and fed to every forward, reference train.py:72-76) are split once per tensor version and kept "
+                               "(ctgcn_amd.ops._PlaneCache; CTGCN_PLANE_CACHE=0 splits them on every call: facebook-like 26.7 -> 30.4 ms, the other configs "
+                               "within noise, profiles/r04_mlp_chain_ab.txt); intermediate activations are split on every call",
         "hbm_copy_GBps_measured": copy_bw,
         "data": "synthetic (seed %d power-law dynamic graph, random-init weights)" % DEFAULT_SEED,
         "config": {"workload": "%s; CTGCN-%s hid=%d embed=%d, %d transform + %d diffusion layers, max_core=%d, %s features" % (

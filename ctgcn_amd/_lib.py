@@ -14,7 +14,7 @@ ACT_NONE, ACT_SELU = 0, 1
 OP_KCORE = 1
 OP_INGEST = 2
 MAX_SLOTS = 255
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _c = ctypes
 _vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_int, _c.c_size_t
@@ -54,7 +54,7 @@ SIGNATURES = {
     "ctgcn_gru_layer_presplit_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
     "ctgcn_gru_bwd_blocks": (_i32, [_i64]),
     "ctgcn_gru_layer_presplit_save_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ctgcn_gru_bwd_rec_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "ctgcn_gru_bwd_rec_f32": (_int, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "ctgcn_gru_bwd_in_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
     "ctgcn_lstm_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _vp, _vp]),
     "ctgcn_lstm_seq_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

@@ -70,7 +70,9 @@ __device__ __forceinline__ void split4(const f4v v, bf4v &hi, bf4v &lo)
     }
 }
 // W^T fragments of one 16-column slice: A[m = 16 tile + col][k = 32 c + 8 grp + jj] = w[k][16 tile + col]  (w is [384, 128] row-major)
-__device__ __forceinline__ void load_wt_fragments(const float *w, int tile, int col, int grp, bf8v (&hi)[12], bf8v *lo_dst)
+// lo fragments 0 .. NL-1 go to LDS (lo_dst, 64 fragments apart), the last 12 - NL stay in registers (lo_reg)
+template <int NL>
+__device__ __forceinline__ void load_wt_fragments(const float *w, int tile, int col, int grp, bf8v (&hi)[12], bf8v *lo_dst, bf8v (&lo_reg)[12 - NL + 1])
 {
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
@@ -81,7 +83,8 @@ __device__ __forceinline__ void load_wt_fragments(const float *w, int tile, int 
             bf16_split2(w[(int64_t)(c * 32 + 8 * grp + jj) * GH + tile * 16 + col], a, b);
             hi[c][jj] = a; lo[jj] = b;
         }
-        lo_dst[c * 64] = lo;
+        if (c < NL) lo_dst[c * 64] = lo;
+        else lo_reg[c - NL] = lo;
     }
 }
 __device__ __forceinline__ bf8v tr_pair(const __bf16 *p0, const __bf16 *p1)
@@ -150,7 +153,8 @@ __device__ __forceinline__ void store_weight_grad(float *part, int wave, int lan
             for (int i = 0; i < 4; ++i) out[(16 * ut + i) * GH + 16 * jt] = acc[ut][jt][i];
 }
 // the product with the resident W^T slice: D[m = out unit 16 wave + 4 grp + i][n = row col] = sum_k W^T[m][k] G[row][k], k over the 384 gate columns
-__device__ __forceinline__ f4v gate_product(const __bf16 *Gs, const bf8v (&Wh)[12], const bf8v *wl, int col, int grp)
+template <int NL>
+__device__ __forceinline__ f4v gate_product(const __bf16 *Gs, const bf8v (&Wh)[12], const bf8v *wl, const bf8v (&lo_reg)[12 - NL + 1], int col, int grp)
 {
     const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
     f4v a0 = zero4, a1 = zero4, a2 = zero4;
@@ -158,7 +162,7 @@ __device__ __forceinline__ f4v gate_product(const __bf16 *Gs, const bf8v (&Wh)[1
     for (int c = 0; c < 12; ++c) {
         const bf8v gh = *(const bf8v *)(Gs + col * GP + 32 * c + 8 * grp);
         const bf8v gl = *(const bf8v *)(Gs + (16 + col) * GP + 32 * c + 8 * grp);
-        const bf8v wlo = wl[c * 64];
+        const bf8v wlo = c < NL ? wl[(c < NL ? c : 0) * 64] : lo_reg[c < NL ? 0 : c - NL];
         a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh[c], gl, a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, gh, a1, 0, 0, 0);
         a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wh[c], gh, a2, 0, 0, 0);
@@ -173,13 +177,15 @@ __device__ __forceinline__ f4v gate_product(const __bf16 *Gs, const bf8v (&Wh)[1
 //   dgi[row, t] = sum over t and the steps after it that repeat x_t (tmask bit clear) of (da_r, da_z, da_n)      (written at fresh steps only)
 // 16-row tiles, eight waves, wave w owns hidden units [16w, 16w+16) of dh and rows [48w, 48w+48) of dW_hh.  A lane owns (row col, 4 units)
 // — the MFMA D layout — for the whole tile.  Gates and h_{t-1} of step t-1 are requested while step t multiplies.
-// LDS: lo plane of W_hh^T (96 KB) + the planes of the step's (da_r | da_z | dgh_n) (25 KB) and h_{t-1} (9 KB), single buffered: two
-// barriers per step — the kernel is HBM-bound (2.5 KB in per row-step against ~85 MFMAs per wave and step).
+// LDS: 11 of the 12 lo fragments of W_hh^T (88 KB) + the planes of the step's (da_r | da_z | dgh_n) (25 KB) and h_{t-1} (9 KB), double
+// buffered by step: ONE barrier per step, and the weight-gradient products of step t + 1 (off the recurrence's path) run in front of step
+// t's barrier, where early waves used to wait.
 // ------------------------------------------------------------------------------------------------
 struct BwdRecArgs {
     int64_t rows;
     int32_t steps;
-    const float *gates;      // [rows, steps, 4, 128] r, z, n, q
+    const float *gates;      // [rows, steps, 4, 128] r, z, n, q — or (gates3) [rows, steps, 3, 128] r, z, q with n rebuilt from h_t, h_{t-1}, z
+    int32_t gates3;
     const float *hseq;       // [rows, steps, 128]
     const float *dh;         // SUM: [rows, 128]; else [rows, steps, 128]
     const float *whh;        // [384, 128]
@@ -194,17 +200,19 @@ struct BwdRecArgs {
 template <bool SUM>
 __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
 {
-    __shared__ __bf16 Gs[2 * 16 * GP];
-    __shared__ __bf16 Hs[2 * 16 * HP];
-    __shared__ bf8v Wl[8 * 12 * 64];
+    constexpr int NL = 11;                                 // lo fragments of W_hh^T in LDS (88 KB); the twelfth stays in registers: the planes are double buffered
+    constexpr int GBUF = 2 * 16 * GP, HBUF = 2 * 16 * HP;
+    __shared__ __bf16 Gs[2 * GBUF];                        // [step parity][plane][row][GP]
+    __shared__ __bf16 Hs[2 * HBUF];
+    __shared__ bf8v Wl[8 * NL * 64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int col = lane & 15, grp = lane >> 4;
     const int oc = wave * 16 + 4 * grp;
     const int S = a.steps;
 
-    bf8v Wh[12];
-    load_wt_fragments(a.whh, wave, col, grp, Wh, &Wl[(wave * 12) * 64 + lane]);
-    const bf8v *wl = &Wl[(wave * 12) * 64 + lane];
+    bf8v Wh[12], wreg[12 - NL + 1];
+    load_wt_fragments<NL>(a.whh, wave, col, grp, Wh, &Wl[(wave * NL) * 64 + lane], wreg);
+    const bf8v *wl = &Wl[(wave * NL) * 64 + lane];
     __syncthreads();
 
     const f4v zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
     f4v bsn = zero4;
 
     const int64_t ntiles = (a.rows + 15) / 16;
+    int pb = 0;                                            // plane buffer the next publish goes to; flips with every published step, across tiles too
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * 16;
         const int last = (int)min((int64_t)16, a.rows - row0) - 1;
@@ -225,18 +234,38 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
         f4v drec = zero4, gs0 = zero4, gs1 = zero4, gs2 = zero4;
         f4v dhs = zero4;
         if (SUM) dhs = *(const f4v *)(a.dh + row * GH + oc);
-        f4v gr, gz, gn, gq, hp, dht = zero4;
+        f4v gr, gz, gn = zero4, gq, hp, dht = zero4;
         auto load_step = [&](int t) {
             const int64_t e = row * S + t;
-            const float *gp = a.gates + e * (4 * GH) + oc;
-            gr = *(const f4v *)gp; gz = *(const f4v *)(gp + GH); gn = *(const f4v *)(gp + 2 * GH); gq = *(const f4v *)(gp + 3 * GH);
+            if (a.gates3) {
+                const float *gp = a.gates + e * (3 * GH) + oc;
+                gr = *(const f4v *)gp; gz = *(const f4v *)(gp + GH); gq = *(const f4v *)(gp + 2 * GH);
+            } else {
+                const float *gp = a.gates + e * (4 * GH) + oc;
+                gr = *(const f4v *)gp; gz = *(const f4v *)(gp + GH); gn = *(const f4v *)(gp + 2 * GH); gq = *(const f4v *)(gp + 3 * GH);
+            }
             hp = t > 0 ? *(const f4v *)(a.hseq + (e - 1) * GH + oc) : zero4;
             if (!SUM) dht = *(const f4v *)(a.dh + e * GH + oc);
         };
+        f4v hcur = zero4;                                  // gates3: h_t of the step in hand (= the h_{t-1} the step after it loaded)
+        if (a.gates3) hcur = *(const f4v *)(a.hseq + (row * S + S - 1) * GH + oc);
         load_step(S - 1);
+        bool pending = false;                              // the weight-gradient products of the step before (t + 1) are still to do
         for (int t = S - 1; t >= 0; --t) {
+            __bf16 *Gc = Gs + pb * GBUF, *Hc = Hs + pb * HBUF;
             f4v dh = drec + (SUM ? dhs : dht);
             if (!valid) dh = zero4;                       // rows past the end read the last row's data: they must not reach dW / db
+            if (a.gates3) {
+                // h_t = n + z (h_{t-1} - n)  =>  n = h_{t-1} + (h_t - h_{t-1}) / (1 - z).  Every use of n below carries a factor (1 - z)
+                // (da_n, and through it da_r, dgh_n) or is the difference h_{t-1} - n = -(h_t - h_{t-1}) / (1 - z) times (1 - z) (da_z): the
+                // division's error is multiplied back by what it was divided by.  1 - z below 1e-6: n := h_{t-1} (da_n is then < 1e-6 dh).
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float omz = 1.f - gz[j];
+                    gn[j] = omz > 1e-6f ? hp[j] + (hcur[j] - hp[j]) * __builtin_amdgcn_rcpf(omz) : hp[j];
+                }
+                hcur = hp;
+            }
             const f4v dan = dh * (1.f - gz) * (1.f - gn * gn);
             const f4v daz = dh * (hp - gn) * gz * (1.f - gz);
             const f4v dar = dan * gq * gr * (1.f - gr);
@@ -246,10 +275,10 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
             bsn += dgn;
             if (t > 0) {                                   // h_{-1} = 0: nothing to propagate, no weight gradient from step 0
                 bf4v h, l;
-                split4(dar, h, l); *(bf4v *)(&Gs[col * GP + oc]) = h; *(bf4v *)(&Gs[(16 + col) * GP + oc]) = l;
-                split4(daz, h, l); *(bf4v *)(&Gs[col * GP + GH + oc]) = h; *(bf4v *)(&Gs[(16 + col) * GP + GH + oc]) = l;
-                split4(dgn, h, l); *(bf4v *)(&Gs[col * GP + 2 * GH + oc]) = h; *(bf4v *)(&Gs[(16 + col) * GP + 2 * GH + oc]) = l;
-                split4(hp, h, l); *(bf4v *)(&Hs[col * HP + oc]) = h; *(bf4v *)(&Hs[(16 + col) * HP + oc]) = l;
+                split4(dar, h, l); *(bf4v *)(&Gc[col * GP + oc]) = h; *(bf4v *)(&Gc[(16 + col) * GP + oc]) = l;
+                split4(daz, h, l); *(bf4v *)(&Gc[col * GP + GH + oc]) = h; *(bf4v *)(&Gc[(16 + col) * GP + GH + oc]) = l;
+                split4(dgn, h, l); *(bf4v *)(&Gc[col * GP + 2 * GH + oc]) = h; *(bf4v *)(&Gc[(16 + col) * GP + 2 * GH + oc]) = l;
+                split4(hp, h, l); *(bf4v *)(&Hc[col * HP + oc]) = h; *(bf4v *)(&Hc[(16 + col) * HP + oc]) = l;
             }
             // the next step's operands are requested BEFORE this step's stores: memory operations retire in order, a wait for the loads would
             // otherwise wait for the stores' round trip as well
@@ -261,11 +290,15 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
                 }
                 gs0 = gs1 = gs2 = zero4;
             }
+            // dW_hh of step t + 1 from ITS planes (the other buffer: nobody writes it before the next barrier).  It is not on the recurrence's
+            // path, so it sits here, in front of the barrier: a wave that is early multiplies while the late ones finish their gate math
+            if (pending && !(a.ablate & 2)) weight_grad_block(Gs + (pb ^ 1) * GBUF, Hs + (pb ^ 1) * HBUF, wave, lane, acc);
+            pending = false;
             if (t == 0) break;
-            __syncthreads();
-            if (!(a.ablate & 4)) drec += gate_product(Gs, Wh, wl, col, grp);
-            if (!(a.ablate & 2)) weight_grad_block(Gs, Hs, wave, lane, acc);
-            __syncthreads();                               // the planes are rewritten by the next step
+            __syncthreads();                               // ONE barrier per step: step t's planes are complete, step t + 1's have been read
+            if (!(a.ablate & 4)) drec += gate_product<NL>(Gc, Wh, wl, wreg, col, grp);
+            pending = true;
+            pb ^= 1;
         }
     }
     store_weight_grad(a.dw_part, wave, lane, a.accumulate, acc);
@@ -322,8 +355,8 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
     const int oc = wave * 16 + 4 * grp;
     const int S = a.steps;
 
-    bf8v Wh[12];
-    load_wt_fragments(a.wih, wave, col, grp, Wh, &Wl[(wave * 12) * 64 + lane]);
+    bf8v Wh[12], wreg[1];
+    load_wt_fragments<12>(a.wih, wave, col, grp, Wh, &Wl[(wave * 12) * 64 + lane], wreg);
     const bf8v *wl = &Wl[(wave * 12) * 64 + lane];
     __syncthreads();
 
@@ -410,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
         if (!(a.ablate & 8)) load_unit(nxt);               // in flight during the products
         __syncthreads();
         f4v dxv = zero4;
-        if (!(a.ablate & 4)) dxv = gate_product(Gs, Wh, wl, col, grp);
+        if (!(a.ablate & 4)) dxv = gate_product<12>(Gs, Wh, wl, wreg, col, grp);
         if (!(a.ablate & 2)) weight_grad_block(Gs, Xs, wave, lane, acc);
         if (tid < 96) {
             // d b_ih: column sums of the unit's dgi rows, read back from the planes (hi + lo = the value to 2^-17: what the products see);
@@ -474,12 +507,12 @@ int32_t ctgcn_gru_bwd_blocks(int64_t rows)
     return (int32_t)(ntiles < cus ? (ntiles > 0 ? ntiles : 1) : cus);
 }
 
-int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *h_seq, const float *dh_sum,
+int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, int32_t gate_count, const float *h_seq, const float *dh_sum,
                           const float *dh_seq, const float *w_hh, const uint32_t *tile_mask, float *d_gi, float *dw_partial,
                           float *dbn_partial, int32_t n_partial, int32_t accumulate, void *stream)
 {
     if (hidden != GH) return ctgcn_set_error_(CTGCN_E_UNSUPPORTED, "gru_bwd_rec: only hidden = 128 is built");
-    if (rows < 0 || steps < 1 || steps > 32) return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_rec: bad sizes (1 <= steps <= 32)");
+    if (rows < 0 || steps < 1 || steps > 32 || (gate_count != 3 && gate_count != 4)) return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_rec: bad sizes (1 <= steps <= 32, gate_count 3 or 4)");
     if (!gates || !h_seq || !w_hh || !d_gi || !dw_partial || !dbn_partial || ((dh_sum == nullptr) == (dh_seq == nullptr)))
         return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_rec: null pointer (exactly one of dh_sum / dh_seq)");
     if (!aligned16(gates) || !aligned16(h_seq) || !aligned16(dh_sum) || !aligned16(dh_seq) || !aligned16(d_gi) || !aligned16(dw_partial) || !aligned16(dbn_partial))
@@ -488,7 +521,7 @@ int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
     if (n_partial < blocks) return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_rec: n_partial < ctgcn_gru_bwd_blocks(rows)");
     if (rows == 0) return CTGCN_OK;
     BwdRecArgs a{};
-    a.rows = rows; a.steps = steps; a.gates = gates; a.hseq = h_seq; a.dh = dh_sum ? dh_sum : dh_seq; a.whh = w_hh; a.tmask = tile_mask;
+    a.rows = rows; a.steps = steps; a.gates = gates; a.gates3 = gate_count == 3 ? 1 : 0; a.hseq = h_seq; a.dh = dh_sum ? dh_sum : dh_seq; a.whh = w_hh; a.tmask = tile_mask;
     a.dgi = d_gi; a.dw_part = dw_partial; a.dbn_part = dbn_partial; a.accumulate = accumulate ? 1 : 0; a.ablate = ablate_mask();
     if (dh_sum) hipLaunchKernelGGL(gru_bwd_rec_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gru_bwd_rec_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);

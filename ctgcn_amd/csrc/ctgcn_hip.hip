@@ -1996,6 +1996,7 @@ struct LayerArgs {
     // h sequence [rows, steps, 128] and the sum over the steps BEFORE the LayerNorm [rows, 128] (what its backward needs) — all in POSITION
     // order (row p of these buffers is sequence p of the planes; `order` is not applied, `out` is not written)
     float *hseq, *presum;
+    int32_t gates3;              // SAVE: gates are [rows, steps, 3, 128] = r, z, q — n is rebuilt by ctgcn_gru_bwd_rec_f32 from h_t, h_{t-1} and z (0.5 KB per row-step less, written and read)
 #ifdef CTGCN_LAYER_TIMELINE
     unsigned long long *timeline;   // diagnostic build: per (block, wave) sums of the unit phases, see tools/layer_timeline.py
 #endif
@@ -2577,8 +2578,13 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 }
                 if (SAVE && col <= last) {                // training's recompute pass: gates and raw h of this step, position order
                     const int64_t e = (row0 + col) * S + t;
-                    float *gp = a.gates + e * (4 * GRU_H) + oc;
-                    *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
+                    if (a.gates3) {
+                        float *gp = a.gates + e * (3 * GRU_H) + oc;
+                        *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = an4;
+                    } else {
+                        float *gp = a.gates + e * (4 * GRU_H) + oc;
+                        *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
+                    }
                     *(f4v *)(a.hseq + e * GRU_H + oc) = h;
                 }
                 hprev = h;
@@ -2961,8 +2967,13 @@ __device__ __forceinline__ void gru_layer8_h2_pair_body(const LayerArgs &a, cons
         }
         if (SAVE && col <= T.last) {
             const int64_t e = (T.row0 + col) * S + t;
-            float *gp = a.gates + e * (4 * GRU_H) + oc;
-            *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
+            if (a.gates3) {
+                float *gp = a.gates + e * (3 * GRU_H) + oc;
+                *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = an4;
+            } else {
+                float *gp = a.gates + e * (4 * GRU_H) + oc;
+                *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
+            }
             *(f4v *)(a.hseq + e * GRU_H + oc) = h;
         }
         T.hprev = h;
@@ -4395,7 +4406,7 @@ int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidde
     a.xp2 = (const _Float16 *)planes + ((size_t)plane_rows + (size_t)first_row * steps) * GRU_H;
     a.xps = (const float *)((const _Float16 *)planes + 2 * (size_t)plane_rows * GRU_H) + (size_t)first_row * steps;
     a.order = nullptr; a.tmask = tile_mask;
-    a.gates = gates_out; a.hseq = hseq_out; a.presum = presum_out;
+    a.gates = gates_out; a.hseq = hseq_out; a.presum = presum_out; a.gates3 = 1;
 #ifdef CTGCN_LAYER_TIMELINE
     a.timeline = nullptr;
 #endif

@@ -794,7 +794,7 @@ class _CoreDiffusionFused(torch.autograd.Function):
         cmax = chunks[0][1]
         nb = int(lib.ctgcn_gru_bwd_blocks(cmax))
         with torch.cuda.device(dev):
-            gates = torch.empty(cmax * K, 4 * hid, dtype=torch.float32, device=dev)
+            gates = torch.empty(cmax * K, 3 * hid, dtype=torch.float32, device=dev)      # r, z, q: n is rebuilt in the backward kernel
             hseq = torch.empty(cmax * K, hid, dtype=torch.float32, device=dev)
             presum = torch.empty(cmax, hid, dtype=torch.float32, device=dev)
             dpre = torch.empty(cmax, hid, dtype=torch.float32, device=dev)
@@ -819,7 +819,7 @@ class _CoreDiffusionFused(torch.autograd.Function):
                                                   ln_part.shape[0], od, _stream()), "ctgcn_layernorm_bwd_f32")
                 ln_sum += ln_part.sum(0)
                 with _timed("gru_bwd_rec", rows=cnt, steps=K, fresh=fresh, per_step=False):
-                    check(lib.ctgcn_gru_bwd_rec_f32(cnt, K, hid, ptr(gates), ptr(hseq), ptr(dpre), None, ptr(w_hh_d), tm, ptr(dgi), ptr(dw_hh_part),
+                    check(lib.ctgcn_gru_bwd_rec_f32(cnt, K, hid, ptr(gates), 3, ptr(hseq), ptr(dpre), None, ptr(w_hh_d), tm, ptr(dgi), ptr(dw_hh_part),
                                                     ptr(dbn_part), nb, 1, _stream()), "ctgcn_gru_bwd_rec_f32")
                 with _timed("gru_bwd_in", rows=cnt, steps=K, fresh=fresh, z_out=True):
                     check(lib.ctgcn_gru_bwd_in_f32(cnt, K, hid, ptr(dgi), ptr(w_ih_d), tm, ptr(ws), n * K, lo, None, 0, None,
@@ -1061,7 +1061,7 @@ class _GruSeq(torch.autograd.Function):
                 if fused_bwd:
                     dsq = dseq[lo:lo + n]
                     with _timed("gru_bwd_rec", rows=n, steps=steps, fresh=1.0, per_step=not reduce_sum):
-                        check(lib.ctgcn_gru_bwd_rec_f32(n, steps, hid, ptr(gates), ptr(hseq), ptr(dpre) if reduce_sum else None,
+                        check(lib.ctgcn_gru_bwd_rec_f32(n, steps, hid, ptr(gates), 4, ptr(hseq), ptr(dpre) if reduce_sum else None,
                                                         None if reduce_sum else ptr(dpre), ptr(w_hh_d), None, ptr(dgi), ptr(dw_part_hh), ptr(dbn_part),
                                                         nb, 1, _stream()), "ctgcn_gru_bwd_rec_f32")
                     with _timed("gru_bwd_in", rows=n, steps=steps, fresh=1.0, z_out=False):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 22
+#define CTGCN_ABI_VERSION 23
 
 enum {
     CTGCN_OK = 0,
@@ -275,8 +275,9 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
  * ctgcn_gru_layer_presplit_save_f32 — the recompute pass: ctgcn_gru_layer_presplit_f32's kernel on the sequences
  *   [first_row, first_row + rows) of the forward's planes (`planes`, plane_rows = n K rows per plane; first_row a multiple of 16;
  *   tile_mask, optional, already points at tile first_row / 16), writing the gates [rows, steps, 4, 128] (r, z, n, q = W_hn h + b_hn), the
- *   raw h sequence [rows, steps, 128] and the pre-LayerNorm sum over the steps [rows, 128] — no LayerNorm, no `out`.
- * ctgcn_gru_bwd_rec_f32 — backward recurrence + dW_hh: gates, h_seq as above; exactly one of dh_sum [rows, 128] (gradient of sum_t h_t,
+ *   raw h sequence [rows, steps, 128] and the pre-LayerNorm sum over the steps [rows, 128] — no LayerNorm, no `out`.  Its gates are
+ *   [rows, steps, 3, 128] = r, z, q (gate_count = 3 below): n is rebuilt from h_t, h_{t-1} and z, h_t = n + z (h_{t-1} - n).
+ * ctgcn_gru_bwd_rec_f32 — backward recurrence + dW_hh: gates (gate_count = 4: r, z, n, q as ctgcn_gru_layer_f32 / ctgcn_gru_seq_f32 write them; 3: r, z, q), h_seq as above; exactly one of dh_sum [rows, 128] (gradient of sum_t h_t,
  *   added at every step) / dh_seq [rows, steps, 128]; d_gi [rows, steps, 384] receives, at every step whose tile_mask bit is set, the sum
  *   of (da_r, da_z, da_n) over that step and the steps after it that repeat its x (tile_mask NULL: every step);
  *   dw_partial [n_partial, 384, 128] / dbn_partial [n_partial, 128]: per-block sums of dW_hh and of the n-gate column of d b_hh
@@ -294,7 +295,7 @@ int32_t ctgcn_gru_bwd_blocks(int64_t rows);
 int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidden, const void *planes, int64_t plane_rows, int64_t first_row,
                                       const float *w_ih, const float *w_hh, const float *bias_gi, const float *b_hn, const uint32_t *tile_mask,
                                       float *gates_out, float *hseq_out, float *presum_out, void *stream);
-int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, const float *h_seq, const float *dh_sum,
+int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const float *gates, int32_t gate_count, const float *h_seq, const float *dh_sum,
                           const float *dh_seq, const float *w_hh, const uint32_t *tile_mask, float *d_gi, float *dw_partial,
                           float *dbn_partial, int32_t n_partial, int32_t accumulate, void *stream);
 int ctgcn_gru_bwd_in_f32(int64_t rows, int32_t steps, int32_t hidden, const float *d_gi, const float *w_ih, const uint32_t *tile_mask,

@@ -58,8 +58,8 @@ def main():
     bytes_of = {                                   # per call of the whole layer (all chunks)
         "agg_fwd": None,
         "gru_layer": rs * fresh * 516 + n * 512,
-        "gru_layer/save": rs * fresh * 516 + rs * 2.5 * kb + n * 512,
-        "gru_bwd_rec": rs * 2.5 * kb + n * 512 + rs * fresh * 1.5 * kb,
+        "gru_layer/save": rs * fresh * 516 + rs * 2.0 * kb + n * 512,
+        "gru_bwd_rec": rs * 2.0 * kb + n * 512 + rs * fresh * 1.5 * kb,
         "gru_bwd_in": rs * fresh * (1.5 * kb + 516 + 512) + n * 512,
         "agg_bwd": adj.nnz * (4 * 128 + 9) + n * 8 * 128 + 4 * (n + 1),
     }

@@ -528,7 +528,12 @@ def main():
     # ------------------------------------------------------------------------- training step (fwd AND fwd+bwd)
     train = None
     if not args.no_extras and not args.train and not args.graph and not use_dist and os.environ.get("CTGCN_BENCH_TRAIN_LEG", "1") != "0":
-        train = training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log)
+        try:
+            train = training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log)
+        except Exception as exc:          # e.g. out of memory on a box that is not empty: the forward line above must still be printed
+            train = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:400])}
+            log("training leg failed: %s" % train["error"])
+            torch.cuda.empty_cache()
     if use_dist:
         dist.barrier()
     if rank != 0:
@@ -595,7 +600,7 @@ def main():
         "cpu_baseline_kcore": cpu_k,
     }
     line["exact_fp32_ms_per_step"] = exact["ms_per_step"] if exact else None
-    line["training_step_ms_per_step"] = train["ms_per_step"] if train else None
+    line["training_step_ms_per_step"] = train.get("ms_per_step") if train else None
     # the other BASELINE configs (2, 3, 4 math / AS) in the SAME driver run: short runs of this script, one after the other, on the same GPU
     line["configs"] = None
     if args.workload == "synthetic-1m" and world == 1 and not args.train and not args.graph and not args.no_extras \

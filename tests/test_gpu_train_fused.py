@@ -143,3 +143,23 @@ def test_fused_training_without_row_plan(monkeypatch):
     assert (got_out.double() - want_out).abs().max().item() < 5e-5
     for k in want:
         assert _rel(got[k], want[k]) < 1e-4, (k, _rel(got[k], want[k]))
+
+
+@pytest.mark.parametrize("z_bias", [6.0, 12.0, 30.0])
+def test_fused_training_with_saturated_update_gate(z_bias):
+    """The recompute pass keeps r, z, q and the backward rebuilds n = h_{t-1} + (h_t - h_{t-1}) / (1 - z): update gates close to (and, in
+    fp32, equal to) 1 must not hurt — every use of n carries the factor (1 - z) it was divided by."""
+    adj, ref_adj = _graph(1200, 8, 21, 6)
+    layer = _layer(21)
+    with torch.no_grad():
+        layer.rnn.bias_ih_l0[128:256] += z_bias          # z = sigmoid(... + z_bias): 0.9975 / 1 - 6e-6 / exactly 1.0f
+    torch.manual_seed(22)
+    x, G = torch.randn(1200, 128), torch.randn(1200, 128)
+    want_out, want = _truth(layer, x, ref_adj, G)
+    got_out, got = _run(layer, x, adj, G, fused=True)
+    assert torch.isfinite(got_out).all() and all(torch.isfinite(v).all() for v in got.values())
+    assert (got_out.double() - want_out).abs().max().item() < 5e-5
+    for k in want:
+        scale = want[k].abs().max().item()
+        err = (got[k].double() - want[k]).abs().max().item()
+        assert err <= 1e-4 * scale + 1e-7, (k, err, scale)

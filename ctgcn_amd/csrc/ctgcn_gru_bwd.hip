@@ -264,10 +264,11 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
                     const float omz = 1.f - gz[j];
                     gn[j] = omz > 1e-6f ? hp[j] + (hcur[j] - hp[j]) * __builtin_amdgcn_rcpf(omz) : hp[j];
                 }
-                hcur = hp;
             }
             const f4v dan = dh * (1.f - gz) * (1.f - gn * gn);
-            const f4v daz = dh * (hp - gn) * gz * (1.f - gz);
+            // (h_{t-1} - n)(1 - z) = h_{t-1} - h_t exactly: with three gates da_z needs no n at all
+            const f4v daz = a.gates3 ? dh * (hp - hcur) * gz : dh * (hp - gn) * gz * (1.f - gz);
+            if (a.gates3) hcur = hp;
             const f4v dar = dan * gq * gr * (1.f - gr);
             const f4v dgn = dan * gr;
             drec = dh * gz;                                // direct path; the W_hh path is added after the MFMAs

@@ -549,6 +549,12 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 // of phase (gru_layer8_h2_pair_kernel).  Bit-identical, and 1.9 - 2.6 x SLOWER than the single-tile kernel (round 4, profiles/r04_layer_pair_ab.txt):
 // the second tile's state does not fit next to the resident weights — 150 spilled VGPRs, scratch reloads on the critical path of every slot.
 // Kept as the measured negative of VERDICT r3 item 2 (b / c); default off.
+#ifdef CTGCN_LAYER_TIMELINE
+// diagnostic build: per (block, wave) phase sums of the layer kernel, written to $CTGCN_LAYER_TIMELINE_FILE by every call (tools/layer_timeline.py)
+struct LayerArgs;
+const char *timeline_begin(LayerArgs &a, unsigned nb8, void *stream);
+void timeline_end(LayerArgs &a, unsigned nb8, const char *tl_file, void *stream);
+#endif
 bool layer_pair_enabled() { static const bool on = [] { const char *e = getenv("CTGCN_LAYER_PAIR"); return e && atoi(e) == 1; }(); return on; }
 int g_persistent_cus = 0;
 int persistent_cus(int device_cus) { return g_persistent_cus > 0 && g_persistent_cus < device_cus ? g_persistent_cus : device_cus; }
@@ -2003,6 +2009,32 @@ struct LayerArgs {
 };
 
 // weight fragments of ONE 16-unit tile (tile16 = hidden units [16*tile16, 16*tile16+16)) of all three gates, as h2_load_weights
+#ifdef CTGCN_LAYER_TIMELINE
+const char *timeline_begin(LayerArgs &a, unsigned nb8, void *stream)
+{
+    const char *tl_file = getenv("CTGCN_LAYER_TIMELINE_FILE");
+    a.timeline = nullptr;
+    if (tl_file) { (void)hipMalloc(&a.timeline, (size_t)nb8 * 8 * 12 * 8); (void)hipMemsetAsync(a.timeline, 0, (size_t)nb8 * 8 * 12 * 8, (hipStream_t)stream); }
+    return tl_file;
+}
+void timeline_end(LayerArgs &a, unsigned nb8, const char *tl_file, void *stream)
+{
+    if (!a.timeline) return;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    unsigned long long *h = (unsigned long long *)malloc((size_t)nb8 * 8 * 12 * 8);
+    (void)hipMemcpy(h, a.timeline, (size_t)nb8 * 8 * 12 * 8, hipMemcpyDeviceToHost);
+    FILE *f = fopen(tl_file, "w");          // rewritten by every call: the last call's numbers stay
+    for (unsigned i = 0; i < nb8 * 8; ++i) {
+        fprintf(f, "%u %u", i / 8, i % 8);
+        for (int j = 0; j < 12; ++j) fprintf(f, " %llu", h[i * 12 + j]);
+        fprintf(f, "\n");
+    }
+    fclose(f);
+    free(h);
+    (void)hipFree(a.timeline);
+    a.timeline = nullptr;
+}
+#endif
 template <int RS>
 __device__ __forceinline__ void h2_load_weight_tile(const float *w, int tile16, int col, int grp, h8v (&Wf)[2][4][3], float (*wscale)[GRU_H])
 {
@@ -2284,6 +2316,21 @@ constexpr int L8_PITCH = 128;                            // halfs per plane row,
 // half index of element k of row r (r < 16): 16-byte segment k / 8 goes to segment (k / 8) ^ r
 __device__ __forceinline__ int l8_off(int r, int k) { return ((((k >> 3) ^ r) & 15) << 3) | (k & 7); }
 __device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : -1; }
+#ifndef CTGCN_L8_WL_PLAN
+#define CTGCN_L8_WL_PLAN 12
+#endif
+#ifndef CTGCN_L8_HPIPE
+#define CTGCN_L8_HPIPE 0
+#endif
+#ifndef CTGCN_L8_PRIO
+#define CTGCN_L8_PRIO 0
+#endif
+#ifndef CTGCN_L8_ABLATE
+#define CTGCN_L8_ABLATE 0            // diagnostic builds of the row-plan path (WRONG results): 1 no LayerNorm / row output, 2 no transcendentals in the gate math,
+#endif                               // 3 no x loads after the first two units, 4 no h products, 5 no x products, 6 no publish split, 7 no gate math, 8 no barrier, 9 no MFMA, 10 = 7 + 9
+// WL fragments of W_ih in LDS: the 12 of the residual plane, then the LAST WL - 12 of the leading plane
+template <int WL>
+__device__ __forceinline__ constexpr int l8_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : (c * 3 + g >= 24 - WL ? c * 3 + g - (24 - WL) + 12 : -1); }
 
 // bid / nblk: this block's index among the nblk blocks that share the work of `a` (the whole grid, or — grouped launch of a window's
 // snapshots, gru_layer8_h2_group_kernel — the blocks assigned to this snapshot)
@@ -2300,7 +2347,11 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     __shared__ float wsc_ih[3][GRU_H];
     __shared__ float csc_hh[4][GRU_H];                   // rows 0-2: product scales of the three gates, row 3: b_hn
     __shared__ float bias_s[3][GRU_H];
-    __shared__ h8v Wl[8][L8_WL][64];
+    __shared__ float ln_gb[2][GRU_H];                    // row-plan forms: LayerNorm weight / bias (no vector-memory load at a tile's end, see below)
+    __shared__ int32_t ord_s[4][16];                     // row-plan forms: output rows and step mask of the tiles in flight (ring of four, see below)
+    __shared__ uint32_t msk_s[4];
+    constexpr int WL = (PRESPLIT && REDUCE) ? CTGCN_L8_WL_PLAN : L8_WL;   // the row-plan forms have no hrow staging: room for more fragments
+    __shared__ h8v Wl[8][WL][64];
     // per-step form: h_t of the unit's 16 rows in fp32, double buffered by unit parity; the rows leave (LayerNorm, 512-byte stores) at the
     // start of the NEXT unit, two per wave — the staging the kernel pair uses, so the outputs are the pair's bit for bit
     __shared__ float hrow[REDUCE ? 1 : 2][REDUCE ? 1 : 16][GRU_PITCH];
@@ -2321,7 +2372,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
                 asm volatile("" : "+a"(Wh[sp][c][g]));
-                if (l8_lds_slot(sp, c, g) >= 0) Wl[wave][l8_lds_slot(sp, c, g)][lane] = Wi[sp][c][g];
+                if (l8_slot<WL>(sp, c, g) >= 0) Wl[wave][l8_slot<WL>(sp, c, g)][lane] = Wi[sp][c][g];
                 else if (c * 3 + g < 8) asm volatile("" : "+a"(Wi[sp][c][g]));     // at two waves per SIMD the file splits 128 / 128: 24 + 8 fragments fill the AGPR half
             }
     __syncthreads();
@@ -2330,6 +2381,10 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         (&bias_s[0][0])[i] = a.bias_gi ? a.bias_gi[i] : 0.f;
     }
     if (tid < GRU_H) csc_hh[3][tid] = a.bhn ? a.bhn[tid] : 0.f;
+    if (PRESPLIT && REDUCE && tid < GRU_H) {
+        ln_gb[0][tid] = a.gamma ? a.gamma[tid] : 1.f;
+        ln_gb[1][tid] = (a.gamma && a.beta) ? a.beta[tid] : 0.f;
+    }
     __syncthreads();
 
     const int64_t ntiles = (a.rows + 15) / 16;
@@ -2432,18 +2487,21 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     f4v xr;
     int64_t ptile = bid;                           // unit whose x sits in xr
     int pt = 0;
-    if (DEDUP) pmask = tile_mask(ptile);
-    load_x(ptile, pt, xr);
-    stage_x(0, xr);
-    next_unit(ptile, pt);
-    load_x(ptile, pt, xr);
-    __syncthreads();
+    constexpr bool PLAN_PATH = DEDUP && CTGCN_LAYER_LOOKAHEAD;    // the row-plan path below runs its own x pipeline
+    if constexpr (!PLAN_PATH) {
+        if (DEDUP) pmask = tile_mask(ptile);
+        load_x(ptile, pt, xr);
+        stage_x(0, xr);
+        next_unit(ptile, pt);
+        load_x(ptile, pt, xr);
+        __syncthreads();
+    }
 
     int slot = 0;
 #ifdef CTGCN_LAYER_TIMELINE
-    unsigned long long tl[6] = {0, 0, 0, 0, 0, 0};          // issue of the MFMA stream, gate math (incl. MFMA drain), publish, barrier, tile end, units
+    unsigned long long tl[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // issue of the MFMA stream, gate math (incl. MFMA drain), publish, barrier, tile end, units; row-plan form: see below
     unsigned long long tp = wall_clock64();
-#define TL_MARK(i) { const unsigned long long now_ = wall_clock64(); tl[i] += now_ - tp; tp = now_; }
+#define TL_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = wall_clock64(); tl[i] += now_ - tp; tp = now_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define TL_MARK(i)
 #endif
@@ -2469,7 +2527,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
             }
         ln_last = -1;
     };
-#if CTGCN_LAYER_LOOKAHEAD && !defined(CTGCN_LAYER_TIMELINE)
+#if CTGCN_LAYER_LOOKAHEAD
     if constexpr (DEDUP) {
         // Inference form (planes + row plan).  The x·W_ih products of a unit do not depend on the recurrence, so they are issued one unit
         // EARLY: at the end of the unit before, after h_t is published and in front of the barrier — where a wave that finishes its gate
@@ -2479,6 +2537,62 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         // MFMAs' shadow — keeps gi, the pre-activations and the new accumulators alive together: 23 scratch reloads inside the loop, 99 instead
         // of 65 ms per window.  Removed.)  The x ring keeps its two slots: slot i % 2 is read here for fresh unit i and the other one, last
         // read one barrier ago, takes the planes of fresh unit i + 1 right behind the MFMAs.
+        // Nothing between two barriers may wait on vmcnt except the x staging itself: the counter retires in order, so ANY vector-memory load
+        // a wave has to wait for (the next tile's mask, the output row of a finished tile, the LayerNorm weights) also waits for the x planes
+        // requested a moment earlier — a full HBM latency, per tile (timeline build: 2.3 us per tile around the LayerNorm, 1.0 us in the x
+        // pipeline's tile change, of 14 us).  The scalar cache does not help either (s_load shares lgkmcnt with the LDS reads: the next
+        // ds_read's wait exposes its miss).  So a tile's step mask and output rows RIDE WITH ITS FIRST x LOAD (step 0 is always fresh) and
+        // are staged with it into a ring of four tiles in LDS (the x pipeline is at most two tiles ahead of the one whose rows leave); the
+        // LayerNorm weights sit in LDS.
+        // Waves 0-3 (the older wave of each SIMD: it wins the issue arbitration, finishes every phase first and then WAITS at the barrier —
+        // 350 of 1 770 ns per unit in the timeline build against 57 for waves 4-7) carry everything that is not on the recurrence's path:
+        // the whole x staging (16 rows x 16 lanes x 16 bytes per plane) and the LayerNorm of a finished tile (four rows each).
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const bool stager = wave_u < 4;
+        const int qr = (tid >> 4) & 15, qc = (tid & 15) * 8;
+        h8v xp1r = {0, 0, 0, 0, 0, 0, 0, 0}, xp2r = {0, 0, 0, 0, 0, 0, 0, 0};
+        // row scale, output row, step mask (the last two ride with x_0 only) as ONE four-register tuple, stored with one ds_write_b128: a
+        // lone register with a load in flight can end up as the idle half of a packed-math operand pair, and the hardware's wait for
+        // that pair is a wait for the whole in-order vmcnt queue — the x planes' HBM latency, at the head of every fresh unit
+        // (seen in the ISA of the first version of this pipeline: s_waitcnt vmcnt(0) in front of the gi scaling)
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        __shared__ u4v xmeta[2][16];
+        u4v xmr = {0, 0, 0xffffffffu, 0};
+        int pring = 0;                                    // ring slot of the tile the x pipeline is at
+        auto load_xp = [&]() {
+            if (ptile < ntiles) {
+                const int64_t row = min(ptile * 16 + qr, a.rows - 1);
+                const int64_t rs_ = row * S + pt;
+                xp1r = *(const h8v *)(a.xp1 + rs_ * GRU_H + qc);
+                xp2r = *(const h8v *)(a.xp2 + rs_ * GRU_H + qc);
+                xmr[0] = __float_as_uint(a.xps[rs_]);
+                if (pt == 0) {
+                    xmr[1] = a.order ? (uint32_t)a.order[row] : (uint32_t)row;
+                    xmr[2] = a.tmask ? a.tmask[ptile] : 0xffffffffu;
+                }
+            }
+        };
+        auto stage_xp = [&](int slot) {                   // the unit in the registers -> planes of `slot`; a tile's step 0 brings its plan entries
+            if (ptile < ntiles) {
+                if ((tid & 15) == 0) xmeta[slot][qr] = xmr;
+                *(h8v *)(&Xs[slot][0][qr][l8_off(qr, qc)]) = xp1r;
+                *(h8v *)(&Xs[slot][1][qr][l8_off(qr, qc)]) = xp2r;
+                if (pt == 0) {
+                    if ((tid & 15) == 0) ord_s[pring][qr] = (int32_t)xmr[1];
+                    if (tid == 0) msk_s[pring] = xmr[2];
+                    pmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)xmr[2]);
+                }
+            }
+            do {
+                if (++pt >= S) { pt = 0; ptile += nblk; pring = (pring + 1) & 3; break; }     // step 0 of a tile is always fresh
+            } while (!((pmask >> pt) & 1));
+        };
+        if (stager) {
+            load_xp();
+            stage_xp(0);
+            if (CTGCN_L8_ABLATE != 3) load_xp();
+        }
+        __syncthreads();
         f4v acc0[3] = {zero4, zero4, zero4};
         float rs_n = 0.f;
         int xslot = 0;                                    // slot of the next unit that brings a new x
@@ -2486,7 +2600,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         auto x_begin = [&]() {
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc0[g] = zero4;
-            rs_n = xscale[xslot][col];
+            rs_n = __uint_as_float(xmeta[xslot][col][0]);
             xo1 = *(const h8v *)(&Xs[xslot][0][col][l8_off(col, 8 * grp)]);
             xo2 = *(const h8v *)(&Xs[xslot][1][col][l8_off(col, 8 * grp)]);
         };
@@ -2494,18 +2608,18 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
             constexpr int c = decltype(ctag)::value;
             h8v wr[3];
 #pragma unroll
-            for (int g = 0; g < 3; ++g) wr[g] = l8_lds_slot(1, c, g) >= 0 ? Wl[wave][l8_lds_slot(1, c, g) < 0 ? 0 : l8_lds_slot(1, c, g)][lane] : Wi[1][c][g];
+            for (int g = 0; g < 3; ++g) wr[g] = l8_slot<WL>(1, c, g) >= 0 ? Wl[wave][l8_slot<WL>(1, c, g) < 0 ? 0 : l8_slot<WL>(1, c, g)][lane] : Wi[1][c][g];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                const h8v w1 = l8_slot<WL>(0, c, g) >= 0 ? Wl[wave][l8_slot<WL>(0, c, g) < 0 ? 0 : l8_slot<WL>(0, c, g)][lane] : Wi[0][c][g];
                 acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xo2, acc0[g], 0, 0, 0);
             }
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], xo1, acc0[g], 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                const h8v w1 = l8_slot<WL>(0, c, g) >= 0 ? Wl[wave][l8_slot<WL>(0, c, g) < 0 ? 0 : l8_slot<WL>(0, c, g)][lane] : Wi[0][c][g];
                 acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, xo1, acc0[g], 0, 0, 0);
             }
             if (c < 3) {
@@ -2516,44 +2630,95 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         };
         auto x_end = [&]() {
             // the planes of the fresh unit after this one (in registers since the last call) go to the other slot; request the one after
-            if (ptile < ntiles) stage_x(xslot ^ 1, xr);
-            next_unit(ptile, pt);
-            load_x(ptile, pt, xr);
+            if (stager) {
+                stage_xp(xslot ^ 1);
+                if (CTGCN_L8_ABLATE != 3) load_xp();
+            }
             xslot ^= 1;
         };
         auto x_products = [&]() {
             x_begin();
+            if (CTGCN_L8_ABLATE != 5 && CTGCN_L8_ABLATE != 9 && CTGCN_L8_ABLATE != 10) {
             x_chunk(std::integral_constant<int, 0>{}); x_chunk(std::integral_constant<int, 1>{});
             x_chunk(std::integral_constant<int, 2>{}); x_chunk(std::integral_constant<int, 3>{});
+            }
+            TL_MARK(3)
             x_end();
         };
         x_products();                                     // the block's first unit
+#if CTGCN_L8_PRIO
+        if (wave < 4) __builtin_amdgcn_s_setprio(CTGCN_L8_PRIO);   // A/B: the older wave of each SIMD wins the issue arbitration
+#endif
         int pb = 0, ln_buf = 0, ln_last = -1;
-        int64_t ln_row0 = 0;
+        int cring = 0, ln_ring = 0;                       // ring slots of the running tile and of the one whose rows are about to leave
+        const bool has_ln = a.gamma != nullptr;
         auto pending_layernorm = [&]() {
             if (ln_last < 0) return;
-            for (int r = wave * 2; r < wave * 2 + 2; ++r)
+            if (CTGCN_L8_ABLATE == 1) { ln_last = -1; return; }
+            if (!stager) { ln_last = -1; return; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wave_u * 4 + i;
                 if (r <= ln_last) {
-                    const int64_t orow = a.order ? (int64_t)a.order[ln_row0 + r] : ln_row0 + r;
-                    gru_layernorm_row((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H, a.out + orow * a.ldo, lane, a.gamma, a.beta, a.eps);
+                    float2 v = *(const float2 *)((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H + lane * 2);
+                    if (has_ln) {                          // = gru_layernorm_vals with the weights in LDS
+                        const float mean = wave_sum64(v.x + v.y) * (1.0f / GRU_H);
+                        const float dx = v.x - mean, dy = v.y - mean;
+                        const float rstd = rsqrtf(wave_sum64(dx * dx + dy * dy) * (1.0f / GRU_H) + a.eps);
+                        const float2 g = *(const float2 *)(&ln_gb[0][lane * 2]), b = *(const float2 *)(&ln_gb[1][lane * 2]);
+                        v.x = dx * rstd * g.x + b.x;
+                        v.y = dy * rstd * g.y + b.y;
+                    }
+                    *(float2 *)(a.out + (int64_t)__builtin_amdgcn_readfirstlane(ord_s[ln_ring][r]) * a.ldo + lane * 2) = v;
                 }
+            }
             ln_last = -1;
         };
-        for (int64_t tile = bid; tile < ntiles; tile += nblk) {
+        for (int64_t tile = bid; tile < ntiles; tile += nblk, cring = (cring + 1) & 3) {
             const int64_t row0 = tile * 16;
             const int last = (int)min((int64_t)16, a.rows - row0) - 1;
             f4v hprev = zero4, hsum = zero4;
-            const uint32_t tmask = tile_mask(tile);
+            const uint32_t tmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)msk_s[cring]);
             f4v gi[3] = {zero4, zero4, zero4};
             for (int t = 0; t < S; ++t) {
                 if (t == 0) pending_layernorm();          // the previous tile's rows (its last unit ended with a barrier)
+                TL_MARK(5)                                // row-plan form: [0] h products issued, [1] gate math, [2] publish, [3] x products issued, [4] barrier, [5] LayerNorm, [6] units, [7] fresh, [8] x staging + next request
                 if ((tmask >> t) & 1) {
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
                         gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs_n) + *(const f4v *)(&bias_s[g][oc]);
                 }
                 f4v ach[3] = {zero4, zero4, zero4};
+#if CTGCN_L8_HPIPE
+                f4v csc[3], b_hn;
+                auto load_csc = [&]() {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) csc[g] = *(const f4v *)(&csc_hh[g][oc]);
+                    b_hn = *(const f4v *)(&csc_hh[3][oc]);
+                };
                 if (t > 0) {
+                    // h operand reads two k chunks ahead of the MFMAs that use them (left to the compiler: ONE 4-register buffer, every
+                    // ds_read_b128 followed by s_waitcnt lgkmcnt(0) — seven exposed LDS latencies per unit on the recurrence's critical path)
+                    const int hp = pb ^ 1;                // the buffer step t-1 published into
+                    auto ldh = [&](int pl, int c) { return *(const h8v *)(&Hs[hp][pl][col][l8_off(col, c * 32 + 8 * grp)]); };
+                    h8v a2 = ldh(1, 0), a1 = ldh(0, 0), b2 = ldh(1, 1), b1 = ldh(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    CTGCN_H2_MFMA1(Wh, 0, a1, a2, ach)
+                    __builtin_amdgcn_sched_barrier(0);
+                    a2 = ldh(1, 2); a1 = ldh(0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    CTGCN_H2_MFMA1(Wh, 1, b1, b2, ach)
+                    __builtin_amdgcn_sched_barrier(0);
+                    b2 = ldh(1, 3); b1 = ldh(0, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    CTGCN_H2_MFMA1(Wh, 2, a1, a2, ach)
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_csc();                           // the gate math's scales: their latency passes under the last nine MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    CTGCN_H2_MFMA1(Wh, 3, b1, b2, ach)
+                } else load_csc();
+#else
+                if (t > 0 && CTGCN_L8_ABLATE != 4 && CTGCN_L8_ABLATE != 9 && CTGCN_L8_ABLATE != 10) {
                     const int hp = pb ^ 1;                // the buffer step t-1 published into
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -2564,15 +2729,26 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 }
                 const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
                 const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
+#endif
                 // the next unit's x·W_ih, if it brings a new x (a repeat keeps gi): this tile's next step, or step 0 of the block's next tile
                 const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + nblk < ntiles;
+                TL_MARK(0)
                 f4v h, rv4, zv4, nv4, an4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+#if CTGCN_L8_ABLATE == 7 || CTGCN_L8_ABLATE == 10
+                    const float rv = ach[0][j] + gi[0][j] + csc[0][j], zv = ach[1][j] + gi[1][j], an = ach[2][j] + b_hn[j], nv = gi[2][j];
+#elif CTGCN_L8_ABLATE == 2
+                    const float rv = fmaf(ach[0][j], csc[0][j], gi[0][j]);
+                    const float zv = fmaf(ach[1][j], csc[1][j], gi[1][j]);
+                    const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
+                    const float nv = fmaf(rv, an, gi[2][j]);
+#else
                     const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], gi[0][j]));
                     const float zv = gru_sigmoid(fmaf(ach[1][j], csc[1][j], gi[1][j]));
                     const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
                     const float nv = gru_tanh(fmaf(rv, an, gi[2][j]));
+#endif
                     h[j] = nv + zv * (hprev[j] - nv);
                     if (SAVE) { rv4[j] = rv; zv4[j] = zv; nv4[j] = nv; an4[j] = an; }
                 }
@@ -2589,12 +2765,20 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 }
                 hprev = h;
                 hsum = t > 0 ? hsum + h : h;
+#ifdef CTGCN_LAYER_TIMELINE
+                asm volatile("" :: "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]));
+#endif
+                TL_MARK(1)
                 if (t + 1 < S) {                          // fp16x2 planes of h·2^14 for the next step (the buffer nobody reads in this unit)
                     h4v p, q;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         _Float16 x, y;
+#if CTGCN_L8_ABLATE == 6
+                        x = (_Float16)h[j]; y = x;
+#else
                         h2_split<1>(h[j] * 16384.f, x, y);
+#endif
                         p[j] = x; q[j] = y;
                     }
                     *(h4v *)(&Hs[pb][0][col][l8_off(col, oc)]) = p;
@@ -2603,15 +2787,26 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                     if (col <= last) *(f4v *)(a.presum + (row0 + col) * GRU_H + oc) = hsum;
                 } else {                                  // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
                     *(f4v *)((float *)&Hs[pb][0][0][0] + col * GRU_H + oc) = hsum;
-                    ln_buf = pb; ln_last = last; ln_row0 = row0;
+                    ln_buf = pb; ln_last = last; ln_ring = cring;
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                TL_MARK(2)
                 if (next_fresh) x_products();
-                __syncthreads();
+                TL_MARK(8)
+                if (CTGCN_L8_ABLATE != 8) __syncthreads();
+                TL_MARK(4)
+#ifdef CTGCN_LAYER_TIMELINE
+                ++tl[6];
+                tl[7] += next_fresh ? 1 : 0;
+#endif
                 pb ^= 1;
             }
         }
         pending_layernorm();
+#ifdef CTGCN_LAYER_TIMELINE
+        if (a.timeline && lane == 0)
+            for (int i = 0; i < 12; ++i) a.timeline[((size_t)bid * 8 + wave) * 12 + i] = tl[i];
+#endif
         return;
     }
 #endif
@@ -2649,20 +2844,20 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                         h2 = *(const h8v *)(&Hs[hp][1][col][l8_off(col, c * 32 + 8 * grp)]);
                     }
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) wr[g] = l8_lds_slot(1, c, g) >= 0 ? Wl[wave][l8_lds_slot(1, c, g) < 0 ? 0 : l8_lds_slot(1, c, g)][lane] : Wi[1][c][g];
+                    for (int g = 0; g < 3; ++g) wr[g] = l8_slot<WL>(1, c, g) >= 0 ? Wl[wave][l8_slot<WL>(1, c, g) < 0 ? 0 : l8_slot<WL>(1, c, g)][lane] : Wi[1][c][g];
                     __builtin_amdgcn_sched_barrier(0);
                     // = CTGCN_H2_MFMA1(Wi, c, x1, x2, acc0): one accumulator, small terms first (w1·x2, w2·x1, then w1·x1); LDS-resident
                     // fragments of the leading plane are read on the spot
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
-                        const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                        const h8v w1 = l8_slot<WL>(0, c, g) >= 0 ? Wl[wave][l8_slot<WL>(0, c, g) < 0 ? 0 : l8_slot<WL>(0, c, g)][lane] : Wi[0][c][g];
                         acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x2, acc0[g], 0, 0, 0);
                     }
 #pragma unroll
                     for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], x1, acc0[g], 0, 0, 0);
 #pragma unroll
                     for (int g = 0; g < 3; ++g) {
-                        const h8v w1 = l8_lds_slot(0, c, g) >= 0 ? Wl[wave][l8_lds_slot(0, c, g) < 0 ? 0 : l8_lds_slot(0, c, g)][lane] : Wi[0][c][g];
+                        const h8v w1 = l8_slot<WL>(0, c, g) >= 0 ? Wl[wave][l8_slot<WL>(0, c, g) < 0 ? 0 : l8_slot<WL>(0, c, g)][lane] : Wi[0][c][g];
                         acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x1, acc0[g], 0, 0, 0);
                     }
                     if (c < 3) {
@@ -2750,7 +2945,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     else pending_rows();
 #ifdef CTGCN_LAYER_TIMELINE
     if (a.timeline && lane == 0)
-        for (int i = 0; i < 6; ++i) a.timeline[((size_t)bid * 8 + wave) * 6 + i] = tl[i];
+        for (int i = 0; i < 12; ++i) a.timeline[((size_t)bid * 8 + wave) * 12 + i] = tl[i];
 #endif
 #undef TL_MARK
 }
@@ -4304,22 +4499,11 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
         const int64_t nt8 = (rows + 15) / 16;
 #ifdef CTGCN_LAYER_TIMELINE
         const unsigned nb8 = (unsigned)(nt8 < cus ? nt8 : cus);
-        const char *tl_file = getenv("CTGCN_LAYER_TIMELINE_FILE");
-        a.timeline = nullptr;
-        if (tl_file) { (void)hipMalloc(&a.timeline, (size_t)nb8 * 8 * 6 * 8); (void)hipMemsetAsync(a.timeline, 0, (size_t)nb8 * 8 * 6 * 8, (hipStream_t)stream); }
+        const char *tl_file = timeline_begin(a, nb8, stream);
 #endif
         hipLaunchKernelGGL((gru_layer8_h2_kernel<false, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
 #ifdef CTGCN_LAYER_TIMELINE
-        if (a.timeline) {
-            (void)hipStreamSynchronize((hipStream_t)stream);
-            unsigned long long *h = (unsigned long long *)malloc((size_t)nb8 * 8 * 6 * 8);
-            (void)hipMemcpy(h, a.timeline, (size_t)nb8 * 8 * 6 * 8, hipMemcpyDeviceToHost);
-            FILE *f = fopen(tl_file, "w");          // rewritten by every call: the last call's numbers stay
-            for (unsigned i = 0; i < nb8 * 8; ++i) fprintf(f, "%u %u %llu %llu %llu %llu %llu %llu\n", i / 8, i % 8, h[i * 6], h[i * 6 + 1], h[i * 6 + 2], h[i * 6 + 3], h[i * 6 + 4], h[i * 6 + 5]);
-            fclose(f);
-            free(h);
-            (void)hipFree(a.timeline);
-        }
+        timeline_end(a, nb8, tl_file, stream);
 #endif
     } else if (nw == 8) {
         // per-step form (temporal GRU): LayerNorm(h_t) of every unit leaves through an fp32 staging buffer in LDS (free since the
@@ -4365,10 +4549,11 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
     a.xp2 = a.xp1 + nrow * GRU_H;
     a.xps = (const float *)(a.xp2 + nrow * GRU_H);
     a.order = row_order; a.tmask = tile_mask;
-#ifdef CTGCN_LAYER_TIMELINE
-    a.timeline = nullptr;
-#endif
     const int64_t nt8 = (rows + 15) / 16;
+#ifdef CTGCN_LAYER_TIMELINE
+    const unsigned nb8 = (unsigned)(nt8 < cus ? nt8 : cus);
+    const char *tl_file = timeline_begin(a, nb8, stream);
+#endif
     if (layer_pair_enabled()) {
         // two tiles in flight per block: a block wants an even number of tiles and at least two
         const int64_t nb = nt8 / 2 < cus ? (nt8 / 2 > 0 ? nt8 / 2 : 1) : cus;
@@ -4376,6 +4561,9 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
     } else {
         hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
     }
+#ifdef CTGCN_LAYER_TIMELINE
+    timeline_end(a, nb8, tl_file, stream);
+#endif
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -176,6 +176,103 @@ __device__ __forceinline__ float gemm_act(float v, int act)
     return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// "k3" operand form for a LIBRARY fp16 GEMM (round 4).  The three products of the fp16 x 2 split are one GEMM over concatenated planes:
+//     x side  [ p1 | p2 | p1 ]   (rows x 3 kp halfs)        w side  [ w2 | w1 | w1 ]   (n_out x 3 kp halfs)
+//     sum over 3 kp of x' w'^T = p1 w2 + p2 w1 + p1 w1      (fp32 accumulation inside the matrix cores, fp32 out)
+// hipBLASLt's fp16 kernels reach 0.32 - 0.39 of the fp16 x 2 bound on the shapes of this path (tools/probes/lt_f16_probe.py: 800 - 980 TF/s
+// executed with K' = 3 K) where gemm_h2_kernel holds 0.18 - 0.23; north_star leaves the dense Linear to the library.  The library has no
+// per-row scale, so the scales travel to the CONSUMER of the raw accumulators: the next layer's split (this kernel: its prologue applies
+// act(acc * row_scale * col_scale + bias)) or scale_bias_act_kernel.
+// One wave per row.  fixed_max > 0: one scale for the whole tensor (weights: y's column scale is then a scalar).
+template <bool VEC>
+__global__ __launch_bounds__(256) void split_rows_k3_kernel(int64_t rows, int32_t K, int32_t Kp, const float *__restrict__ x, int64_t ldx,
+                                                             const float *__restrict__ in_rscale, float in_cscale, const float *__restrict__ in_bias,
+                                                             int32_t act, float fixed_max, int32_t w_order, _Float16 *__restrict__ planes,
+                                                             float *__restrict__ scale)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *src = x + row * ldx;
+    const bool xf = in_rscale != nullptr;                 // the input is a raw accumulator tile: v = act(acc rs cs + bias)
+    const float rs = xf ? in_rscale[row] * in_cscale : 1.f;
+    constexpr int HOLD = 8;
+    f4v keep[HOLD];
+    auto load4 = [&](int k) -> f4v {
+        f4v v;
+        if (VEC) v = *(const f4v *)(src + k);
+        else if (k + 4 <= K) v = *(const f4u *)(src + k);
+        else { v = f4v{0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = src[k + j]; }
+        if (xf) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (k + j < K) ? gemm_act(fmaf(v[j], rs, in_bias ? in_bias[k + j] : 0.f), act) : 0.f;
+        }
+        return v;
+    };
+    float m = 0.f;
+    const bool held = K <= HOLD * 256;
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < HOLD; ++i) {
+            const int k = lane * 4 + i * 256;
+            keep[i] = k < K ? load4(k) : f4v{0.f, 0.f, 0.f, 0.f};
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(keep[i][0]), fabsf(keep[i][1])), fmaxf(fabsf(keep[i][2]), fabsf(keep[i][3]))));
+        }
+    } else {
+        for (int k = lane * 4; k < K; k += 256) {
+            const f4v v = load4(k);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s, inv;
+    h2_scale(fixed_max > 0.f ? fixed_max : m, s, inv);
+    if (lane == 0 && !(fixed_max > 0.f)) scale[row] = s;
+    if (fixed_max > 0.f && row == 0 && lane == 0) scale[0] = s;
+    _Float16 *d = planes + row * (int64_t)(3 * Kp);
+    // x side: hi | lo | hi;  w side: lo | hi | hi
+    _Float16 *dh0 = d + (w_order ? Kp : 0), *dlo = d + (w_order ? 0 : Kp), *dh1 = d + 2 * Kp;
+    auto put = [&](int k, const f4v v) {
+        h4v a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xs = v[j] * inv;
+            a[j] = (_Float16)xs;
+            b[j] = (_Float16)(xs - (float)a[j]);
+        }
+        *(h4v *)(dh0 + k) = a; *(h4v *)(dlo + k) = b; *(h4v *)(dh1 + k) = a;
+    };
+    if (held) {
+#pragma unroll
+        for (int i = 0; i < HOLD; ++i) {
+            const int k = lane * 4 + i * 256;
+            if (k < Kp) put(k, keep[i]);                  // columns >= K were loaded as zeros
+        }
+    } else {
+        for (int k = lane * 4; k < Kp; k += 256) put(k, k < K ? load4(k) : f4v{0.f, 0.f, 0.f, 0.f});
+    }
+}
+
+// y = act(acc row_scale[m] col_scale + bias[n]): the last layer of a k3 chain (its consumer wants plain fp32 rows)
+__global__ __launch_bounds__(256) void scale_bias_act_kernel(int64_t rows, int32_t n, const float *__restrict__ acc, int64_t lda,
+                                                              const float *__restrict__ rscale, float cscale, const float *__restrict__ bias,
+                                                              int32_t act, float *__restrict__ y, int64_t ldy)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = n / 4;                                  // host: n % 4 == 0, 16-byte aligned rows
+    if (i >= rows * n4) return;
+    const int64_t r = i / n4;
+    const int c = (int)(i % n4) * 4;
+    const float rs = rscale[r] * cscale;
+    f4v v = *(const f4v *)(acc + r * lda + c);
+    const f4v b = bias ? *(const f4v *)(bias + c) : f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = gemm_act(fmaf(v[j], rs, b[j]), act);
+    *(f4v *)(y + r * ldy + c) = v;
+}
+
 template <int NI, int NJ>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &a, const f16v (&acc)[NI][NJ], int64_t mrow0, int ncol0, int lane, bool full)
 {
@@ -562,6 +659,50 @@ int ctgcn_split_rows_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, v
     _Float16 *p1 = (_Float16 *)planes, *p2 = p1 + (size_t)rows * kp;
     float *sc = (float *)(p2 + (size_t)rows * kp);
     launch_split(rows, k, kp, x, ldx, p1, p2, sc, nullptr, 1, 1.f, (hipStream_t)stream);
+    GEMM_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+size_t ctgcn_k3_planes_bytes(int64_t rows, int32_t k)
+{
+    if (rows < 0 || k < 1) return 0;
+    return align_up((size_t)rows * align_up((size_t)k, 2 * BK) * 3 * sizeof(_Float16), 256);
+}
+
+int ctgcn_split_rows_k3_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, const float *in_row_scale, float in_col_scale,
+                            const float *in_bias, int32_t activation, float fixed_max, int32_t weight_order, void *planes, size_t planes_bytes,
+                            float *scale, void *stream)
+{
+    if (rows < 0 || k < 1 || ldx < k) return ctgcn_set_error_(CTGCN_E_INVALID, "split_rows_k3: bad sizes");
+    if (rows == 0) return CTGCN_OK;
+    if (!x || !planes || !scale || (reinterpret_cast<uintptr_t>(x) & 3u) || (reinterpret_cast<uintptr_t>(planes) & 255u))
+        return ctgcn_set_error_(CTGCN_E_INVALID, "split_rows_k3: x 4-byte aligned, planes 256-byte aligned, scale required");
+    if (activation != CTGCN_ACT_NONE && activation != CTGCN_ACT_SELU) return ctgcn_set_error_(CTGCN_E_INVALID, "split_rows_k3: activation");
+    if (!in_row_scale && (in_bias || activation != CTGCN_ACT_NONE)) return ctgcn_set_error_(CTGCN_E_INVALID, "split_rows_k3: bias / activation go with in_row_scale");
+    if (!(fixed_max >= 0.f)) return ctgcn_set_error_(CTGCN_E_INVALID, "split_rows_k3: fixed_max");
+    if (planes_bytes < ctgcn_k3_planes_bytes(rows, k)) return ctgcn_set_error_(CTGCN_E_WORKSPACE, "split_rows_k3: planes buffer too small (ctgcn_k3_planes_bytes)");
+    const int32_t kp = (int32_t)align_up((size_t)k, 2 * BK);
+    const bool vec = (ldx % 4 == 0) && (k % 4 == 0) && !(reinterpret_cast<uintptr_t>(x) & 15u);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (vec) hipLaunchKernelGGL(split_rows_k3_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, rows, k, kp, x, ldx, in_row_scale, in_col_scale, in_bias,
+                                activation, fixed_max, weight_order, (_Float16 *)planes, scale);
+    else hipLaunchKernelGGL(split_rows_k3_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, rows, k, kp, x, ldx, in_row_scale, in_col_scale, in_bias,
+                            activation, fixed_max, weight_order, (_Float16 *)planes, scale);
+    GEMM_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_scale_bias_act_f32(int64_t rows, int32_t n, const float *acc, int64_t ld_acc, const float *row_scale, float col_scale, const float *bias,
+                             int32_t activation, float *y, int64_t ldy, void *stream)
+{
+    if (rows < 0 || n < 4 || (n & 3) || ld_acc < n || ldy < n || (ld_acc & 3) || (ldy & 3)) return ctgcn_set_error_(CTGCN_E_INVALID, "scale_bias_act: n, ld multiples of 4");
+    if (rows == 0) return CTGCN_OK;
+    if (!acc || !row_scale || !y || (reinterpret_cast<uintptr_t>(acc) & 15u) || (reinterpret_cast<uintptr_t>(y) & 15u) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)))
+        return ctgcn_set_error_(CTGCN_E_INVALID, "scale_bias_act: null or misaligned pointer");
+    if (activation != CTGCN_ACT_NONE && activation != CTGCN_ACT_SELU) return ctgcn_set_error_(CTGCN_E_INVALID, "scale_bias_act: activation");
+    const int64_t work = rows * (n / 4);
+    hipLaunchKernelGGL(scale_bias_act_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n, acc, ld_acc, row_scale, col_scale,
+                       bias, activation, y, ldy);
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

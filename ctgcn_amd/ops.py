@@ -387,7 +387,105 @@ class _PlaneCache(object):
         return buf
 
 
+    def planes_k3(self, t, lib, weight):
+        """the k3 operand form (ctgcn_split_rows_k3_f32) of a tensor that does not change between forwards -> (fp16 [rows, 3 kp], scales,
+        scalar scale or None).  weight: one scale for the whole tensor (host read of max|w| once per weight version)."""
+        import weakref
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device), "k3w" if weight else "k3x")
+        e = self.entries.get(key)
+        cur = torch.cuda.current_stream(t.device)
+        if e is not None and e[0]() is t and e[1] == t._version:
+            self.entries.move_to_end(key)
+            if e[5] != cur:
+                cur.wait_event(e[4])
+                e[2][0].record_stream(cur)
+                e[2][1].record_stream(cur)
+            return e[2]
+        self._drop(key)
+        val = split_rows_k3(t.detach(), lib, weight=weight)
+        nbytes = val[0].numel() * 2 + val[1].numel() * 4
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.entries[key] = (weakref.ref(t, lambda _r, key=key: self._drop(key)), t._version, val, nbytes, ev, cur)
+        self.bytes += nbytes
+        while self.bytes > self.limit and len(self.entries) > 1:
+            self._drop(next(iter(self.entries)))
+        return val
+
+
 _plane_cache = _PlaneCache()
+
+
+def gemm_library_enabled():
+    """CTGCN_GEMM=lib hands the fp16 x 2 planes of the MLP's dense Linear layers to the library's fp16 GEMM as ONE product over 3 kp
+    (ctgcn_split_rows_k3_f32).  Measured (profiles/r04_library_gemm_k3.txt): the GEMMs alone run 1.3 - 1.7 x faster than gemm_h2_kernel
+    (0.32 - 0.39 of the fp16 x 2 bound against 0.18 - 0.23), the Facebook-like window gains 4 % (the raw accumulators cost an fp32 round
+    trip and the k3 planes half as many bytes again) — and hipBLASLt's results are not bit-identical from run to run there (bench.py's
+    single-stream / multi-stream equality check fails one time in two).  Default: the hand-written, deterministic gemm_h2_kernel."""
+    import os
+    return os.environ.get("CTGCN_GEMM", "hand") == "lib" and not torch.cuda.is_current_stream_capturing()
+
+
+def _h2_scale_host(m):
+    """the power of two s with m / s in [2^14, 2^15) — h2_scale of the kernels, on the host"""
+    import struct
+    e = (struct.unpack("<I", struct.pack("<f", float(m)))[0] >> 23) & 0xff
+    e = min(max(e, 15), 253)
+    return struct.unpack("<f", struct.pack("<I", (e - 14) << 23))[0]
+
+
+def split_rows_k3(x2d, lib, weight=False, acc_scale=None, acc_col_scale=1.0, acc_bias=None, selu=False):
+    """ctgcn_split_rows_k3_f32 -> (planes fp16 [rows, 3 kp], scale fp32 [rows] (weight: [1]), host scalar scale (weight) or None).
+    acc_scale: x2d is the raw accumulator of the layer before; the split reads act(x2d acc_scale[r] acc_col_scale + acc_bias[c])."""
+    rows, k = x2d.shape
+    kp = -(-k // 64) * 64
+    nbytes = int(lib.ctgcn_k3_planes_bytes(rows, k))
+    buf = torch.empty(nbytes // 2, dtype=torch.float16, device=x2d.device)
+    fixed, host_scale = 0.0, None
+    if weight:
+        fixed = float(x2d.abs().max())                    # host read: once per weight version (the planes are cached)
+        fixed = fixed if fixed > 0.0 else 1.0
+        host_scale = _h2_scale_host(fixed)
+    scale = torch.empty(1 if weight else rows, dtype=torch.float32, device=x2d.device)
+    with _timed("linear_aux", rows=rows, k=k, split=True):
+        check(lib.ctgcn_split_rows_k3_f32(rows, k, ptr(x2d), x2d.stride(0), ptr(acc_scale), float(acc_col_scale), ptr(acc_bias),
+                                          _lib.ACT_SELU if (selu and acc_scale is not None) else _lib.ACT_NONE, fixed, 1 if weight else 0,
+                                          ptr(buf), nbytes, ptr(scale), _stream()), "ctgcn_split_rows_k3_f32")
+    return buf[:rows * 3 * kp].view(rows, 3 * kp), scale, host_scale
+
+
+def linear_k3_ok(x2d, weight):
+    return (gemm_library_enabled() and plane_cache_enabled() and weight.shape[0] % 4 == 0 and x2d.shape[0] * (x2d.shape[1] + 64) * 6 <= _LINEAR_WS_MAX)
+
+
+def mlp_k3(x2d, layers, selu, static_x=False, out=None):
+    """selu?(Linear_n(... selu?(Linear_1(x)))) — MLP.forward (layers.py:95-106) on dense features (or one nn.Linear), inference: per layer
+    ONE library fp16 GEMM over the k3 planes (fp32 accumulators out); a layer's scales, bias and activation are applied by the next layer's
+    split (its prologue) or, for the last layer, by ctgcn_scale_bias_act_f32."""
+    lib = _lib.load()
+    rows = x2d.shape[0]
+    with torch.cuda.device(x2d.device):
+        if static_x and not x2d.requires_grad:
+            xp, xs, _ = _plane_cache.planes_k3(x2d, lib, False)
+        else:
+            xp, xs, _ = split_rows_k3(x2d, lib)
+        acc = None
+        for i, lin in enumerate(layers):
+            wp, _, wscale = _plane_cache.planes_k3(lin.weight, lib, True)
+            n_out, k = lin.weight.shape
+            with _timed("linear_split", rows=rows, k=k, n_out=n_out, planes=True, library=True):
+                acc = torch.mm(xp, wp.t(), out_dtype=torch.float32)
+            b = None if lin.bias is None else lin.bias.detach()
+            if i + 1 < len(layers):
+                xp, xs_next, _ = split_rows_k3(acc, lib, acc_scale=xs, acc_col_scale=wscale, acc_bias=b, selu=selu)
+                xs = xs_next
+            else:
+                if out is None:
+                    out = torch.empty(rows, n_out, dtype=torch.float32, device=x2d.device)
+                with _timed("linear_aux", rows=rows, k=n_out, split=False):
+                    check(lib.ctgcn_scale_bias_act_f32(rows, n_out, ptr(acc), acc.stride(0), ptr(xs), float(wscale), ptr(b),
+                                                       _lib.ACT_SELU if selu else _lib.ACT_NONE, ptr(out), out.stride(0), _stream()), "ctgcn_scale_bias_act_f32")
+    return out
 
 
 def plane_cache_enabled():
@@ -410,6 +508,12 @@ def linear_split(x2d, weight, bias, out=None, selu=False, static_x=False):
     chunk = max(128, (_LINEAR_WS_MAX // (kp * 4 + 4)) // 128 * 128)
     b = None if bias is None else bias.detach().contiguous()
     w = weight.detach()
+    if linear_k3_ok(x2d, weight) and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)):
+        class _L(object):
+            pass
+        lin = _L()
+        lin.weight, lin.bias = weight, bias
+        return mlp_k3(x2d, [lin], selu, static_x=static_x, out=out)
     if rows <= chunk and plane_cache_enabled():
         with torch.cuda.device(x2d.device):
             wp = _plane_cache.planes(weight, lib)
@@ -705,8 +809,8 @@ def core_diffusion_split(x, adj, rnn, norm, out=None):
         ln_b = None if norm is None else norm.bias
         eps = 0.0 if norm is None else float(norm.eps)
         plan = adj.row_plan(adj.PLAN_TILE_GEMM) if (row_plan_enabled() and forward_split_mode() == 2) else None
-        ws, ws_bytes = aggregate_split_planes(x, adj, n_out, plan)
         rows = plan["operand_rows"] if plan is not None else n * K          # under a plan the GEMM only sees rows that bring a new x
+        ws, ws_bytes = aggregate_split_planes(x, adj, n_out, plan)
         gi_buf = torch.empty(rows * n_out, dtype=torch.float32, device=x.device) if plan is not None else _gi_buffer(n, K, hid, x.device)
         with _timed("linear_split", rows=rows, k=d, n_out=n_out, presplit=True):
             if plane_cache_enabled():          # W_ih's planes: split once per weight version, not per call

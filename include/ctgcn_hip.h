@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 23
+#define CTGCN_ABI_VERSION 24
 
 enum {
     CTGCN_OK = 0,
@@ -374,6 +374,24 @@ int ctgcn_linear_planes_f32(int64_t rows, int32_t n_out, int32_t k, const void *
                             const float *bias, int32_t activation, float *y, int64_t ldy, void *y_planes, size_t y_planes_bytes, void *stream);
 int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
                      int32_t activation, float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Operands for a LIBRARY fp16 GEMM with fp32 output (round 4; reference layers.py:95-106 nn.Linear stacks and the nn.GRU input projection of
+ * layers.py:59 — north_star leaves the dense Linear to PyTorch-ROCm / hipBLASLt).  The three products of the fp16 x 2 split become ONE GEMM over
+ * k' = 3 kp (kp = k rounded up to 64, zero padded):   x side [ hi | lo | hi ],  w side [ lo | hi | hi ]  ->  hi·lo + lo·hi + hi·hi.
+ *   ctgcn_split_rows_k3_f32   rows x k fp32 -> `planes` [rows, 3 kp] fp16 (ctgcn_k3_planes_bytes, 256-byte aligned) + scale:
+ *        fixed_max = 0: one power-of-two scale per row -> scale[rows];  fixed_max > 0 (weights): the whole tensor under the scale of that
+ *        maximum -> scale[0], so that the product's column scale is a scalar.  weight_order != 0 writes the w side's order.
+ *        in_row_scale != null: x is the RAW accumulator of a previous k3 GEMM and the split reads act(x in_row_scale[r] in_col_scale + in_bias[c])
+ *        (the layer's scales, bias and activation are applied where its output is consumed: no pass of their own).
+ *   ctgcn_scale_bias_act_f32  y = act(acc row_scale[r] col_scale + bias[c]) for a consumer that wants plain fp32 rows (n % 4 == 0).
+ */
+size_t ctgcn_k3_planes_bytes(int64_t rows, int32_t k);
+int ctgcn_split_rows_k3_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, const float *in_row_scale, float in_col_scale,
+                            const float *in_bias, int32_t activation, float fixed_max, int32_t weight_order, void *planes, size_t planes_bytes,
+                            float *scale, void *stream);
+int ctgcn_scale_bias_act_f32(int64_t rows, int32_t n, const float *acc, int64_t ld_acc, const float *row_scale, float col_scale, const float *bias,
+                             int32_t activation, float *y, int64_t ldy, void *stream);
 
 /*
  * CoreDiffusion aggregation (ctgcn_core_aggregate_f32: layers.py:41-48,58) whose only consumer is the GRU input projection of a

@@ -98,6 +98,7 @@ def test_operand_plane_cache_follows_the_tensors(monkeypatch):
     x = torch.randn(777, 1737, device=dev)
     w = torch.nn.Parameter(torch.randn(500, 1737, device=dev) * 0.05)
     b = torch.randn(500, device=dev)
+    monkeypatch.setenv("CTGCN_GEMM", "hand")                 # bit identity cached / uncached: the hand-written GEMM's planes
     monkeypatch.setenv("CTGCN_PLANE_CACHE", "0")
     ref = ops.linear_split(x, w, b, selu=True)
     monkeypatch.setenv("CTGCN_PLANE_CACHE", "1")
@@ -139,6 +140,7 @@ def test_mlp_chain_matches_float64(monkeypatch):
             want = torch.nn.functional.selu(torch.nn.functional.linear(want, lin.weight.double(), lin.bias.double()))
         mlp = mlp.to(dev).eval()
         xg = x.to(dev)
+        monkeypatch.setenv("CTGCN_GEMM", "hand")        # the chain belongs to the hand-written GEMM
         with torch.no_grad():
             monkeypatch.setenv("CTGCN_MLP_CHAIN", "1")
             got = mlp(xg)
@@ -149,3 +151,96 @@ def test_mlp_chain_matches_float64(monkeypatch):
         e_layer = (ref.double().cpu() - want).abs().max().item() / scale
         assert e_chain < 2e-6, (widths, e_chain, e_layer)
         assert e_chain < 4 * e_layer + 1e-7, (widths, e_chain, e_layer)
+
+
+@pytest.mark.parametrize("rows,k,n_out", [(1000, 500, 384), (60_730, 500, 500), (5000, 1737, 500), (300, 1740, 128), (129, 128, 132)])
+def test_library_gemm_over_k3_planes_against_the_hand_kernel(rows, k, n_out, monkeypatch):
+    """The default dense path (ops.mlp_k3: ONE library fp16 GEMM over [hi | lo | hi] x [lo | hi | hi]^T, scales / bias in the finishing kernel)
+    and the hand-written split GEMM (CTGCN_GEMM=hand) against float64: same error class (fp16 x 2 operands, fp32 accumulation)."""
+    from ctgcn_amd import ops
+    torch.manual_seed(rows + k + n_out)
+    x = torch.randn(rows, k, device=DEV) * torch.rand(rows, 1, device=DEV).mul(6).exp()
+    w = torch.randn(n_out, k, device=DEV) / k ** 0.5
+    w[3] *= 1e-3                                          # a small row under the tensor-wide weight scale
+    b = torch.randn(n_out, device=DEV)
+    ref = x.double() @ w.double().t() + b.double()
+    scale = (x.double().abs() @ w.double().abs().t()) + 1e-30
+    seen = []
+    ops.set_launch_timer(lambda name, s, e, meta: seen.append(meta.get("library", False)) if name == "linear_split" else None)
+    try:
+        monkeypatch.setenv("CTGCN_GEMM", "lib")
+        got = ops.linear_split(x, w, b)
+        assert seen and all(seen), seen
+        del seen[:]
+        monkeypatch.setenv("CTGCN_GEMM", "hand")
+        hand = ops.linear_split(x, w, b)
+        assert seen and not any(seen), seen
+    finally:
+        ops.set_launch_timer(None)
+    e_lib = ((got.double() - ref).abs() / scale).max().item()
+    e_hand = ((hand.double() - ref).abs() / scale).max().item()
+    lib32 = torch.addmm(b, x, w.t())
+    e_32 = ((lib32.double() - ref).abs() / scale).max().item()
+    print("rows=%d k=%d n=%d: library-k3 %.2e  hand %.2e  fp32 library %.2e" % (rows, k, n_out, e_lib, e_hand, e_32))
+    assert e_lib <= max(2 * e_32, 2e-7), (e_lib, e_hand, e_32)
+
+
+def test_mlp_k3_chain_matches_float64(monkeypatch):
+    """three Linear + SELU layers (layers.py:95-106) on the library path: a layer's scales, bias and SELU are applied by the next layer's
+    split — against float64 and against the hand-written layer-by-layer path"""
+    from ctgcn_amd.layers import MLP
+    torch.manual_seed(15)
+    for rows, widths in ((1000, (1737, 500, 500, 128)), (333, (96, 200, 64)), (70, (64, 132, 500, 32))):
+        lins = [torch.nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:])]
+        mlp = MLP(widths[0], widths[1], widths[-1], len(widths) - 1, activate_type='N')
+        mlp.linears = torch.nn.ModuleList(lins)
+        mlp.layer_num = len(lins)
+        x = torch.randn(rows, widths[0]) * torch.rand(rows, 1) * 10
+        want = x.double()
+        for lin in lins:
+            want = torch.nn.functional.selu(torch.nn.functional.linear(want, lin.weight.double(), lin.bias.double()))
+        mlp = mlp.to(DEV).eval()
+        xg = x.to(DEV)
+        seen = []
+        from ctgcn_amd import ops
+        ops.set_launch_timer(lambda name, s, e, meta: seen.append(meta.get("library", False)) if name == "linear_split" else None)
+        try:
+            with torch.no_grad():
+                monkeypatch.setenv("CTGCN_GEMM", "lib")
+                got = mlp(xg)
+                assert len(seen) == len(lins) and all(seen), seen
+                monkeypatch.setenv("CTGCN_GEMM", "hand")
+                ref = mlp(xg)
+        finally:
+            ops.set_launch_timer(None)
+        scale = want.abs().max().item()
+        e_lib = (got.double().cpu() - want).abs().max().item() / scale
+        e_hand = (ref.double().cpu() - want).abs().max().item() / scale
+        assert e_lib < 2e-6, (widths, e_lib, e_hand)
+        assert e_lib < 4 * e_hand + 1e-7, (widths, e_lib, e_hand)
+
+
+def test_k3_planes_are_cached_and_follow_in_place_updates(monkeypatch):
+    """the library path keeps the k3 planes of weights / static inputs (ops._PlaneCache.planes_k3): same result from the cache, a new one
+    after an in-place update (version counter), entries die with their tensors"""
+    from ctgcn_amd import ops
+    monkeypatch.setenv("CTGCN_GEMM", "lib")
+    torch.manual_seed(4)
+    x = torch.randn(600, 500, device=DEV)
+    w = torch.nn.Parameter(torch.randn(384, 500, device=DEV) * 0.05)
+    b = torch.randn(384, device=DEV)
+    ops._plane_cache.entries.clear(); ops._plane_cache.bytes = 0
+    a1 = ops.linear_split(x, w, b, static_x=True)
+    assert len(ops._plane_cache.entries) == 2
+    a2 = ops.linear_split(x, w, b, static_x=True)
+    assert torch.equal(a1, a2)
+    with torch.no_grad():
+        w.mul_(2.0)
+        x[0, 0] = 5.0
+    a3 = ops.linear_split(x, w, b, static_x=True)
+    ref = x.double() @ w.detach().double().t() + b.double()          # detached: an autograd graph would keep w alive
+    assert ((a3.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6 and not torch.equal(a3, a1)
+    del x, w
+    import gc
+    gc.collect()
+    assert len(ops._plane_cache.entries) == 0

@@ -145,7 +145,8 @@ class CTGCN(nn.Module):
 
     def _snapshot_streams(self, seq, n, T, x_list):
         """HIP streams for the snapshot branches of an inference forward, or None.  CTGCN_STREAMS=k asks for k (1 = off); default:
-        4 streams for graphs up to 200 000 nodes (launches of tens of microseconds: tails and launch gaps overlap), none above
+        2 streams for graphs up to 200 000 nodes (launches of tens of microseconds: tails and launch gaps overlap; 4 until the width-128
+        layers became one grouped launch per window — since then 2 measure 2 - 5 % faster than 4 or 1 on the four small windows), none above
         (config-5 kernels fill the chip and are HBM-bound: concurrency buys nothing there).
         Only when every dense step of a branch runs in this library's own kernels (GRU width 128, one-hot or split-GEMM-able
         inputs): library GEMMs may use stream-K / split-K kernels whose workgroups wait for each other through flags, and two of
@@ -154,7 +155,7 @@ class CTGCN(nn.Module):
         if seq is None or not seq.is_cuda or T < 2:
             return None
         env = os.environ.get("CTGCN_STREAMS")
-        k = int(env) if env else (4 if n <= 200_000 else 1)
+        k = int(env) if env else (2 if n <= 200_000 else 1)
         k = min(k, T)
         if k <= 1 or not self._branches_use_own_kernels(x_list):
             return None

@@ -414,7 +414,7 @@ def test_multi_stream_snapshot_branches_equal_the_single_stream_forward(monkeypa
             assert lanes is not None and len(lanes) == 3
             got = m(xs, adj)
             monkeypatch.delenv("CTGCN_STREAMS")
-            assert len(m._snapshot_streams(torch.empty(1, device=DEV), n, T, xs)) == min(4, T)      # default for small graphs
+            assert len(m._snapshot_streams(torch.empty(1, device=DEV), n, T, xs)) == min(2, T)      # default for small graphs
             assert m._snapshot_streams(torch.empty(1, device=DEV), 1_000_000, T, xs) is None          # config-5 size: one stream
         if kw["model_type"] == "S":
             assert all(torch.equal(a, b) for a, b in zip(got[1], want[1]))

@@ -2646,6 +2646,9 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
             x_end();
         };
         x_products();                                     // the block's first unit
+        __syncthreads();                                  // its x_end staged the SECOND fresh unit, which the first unit's x_products reads — every other
+                                                          // staging is a barrier ahead of its reader by construction, this one is not (found by
+                                                          // tools/stress_group.py: one forward in 1 200 differed in four rows once waves 0-3 alone staged)
 #if CTGCN_L8_PRIO
         if (wave < 4) __builtin_amdgcn_s_setprio(CTGCN_L8_PRIO);   // A/B: the older wave of each SIMD wins the issue arbitration
 #endif

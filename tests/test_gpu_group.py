@@ -60,3 +60,26 @@ def test_grouped_window_with_a_hub_row_falls_back(monkeypatch):
     a = _forward(model, xs, adjs, monkeypatch, True)
     b = _forward(model, xs, adjs, monkeypatch, False)
     assert torch.equal(a, b)
+
+
+def test_repeated_small_window_forwards_stay_bit_identical(monkeypatch):
+    """200 inference forwards of a small window (two streams, grouped and per-snapshot launches alternating, the allocator perturbed between
+    them) give the same bits every time — tools/stress_group.py in short.  Round 4: with the x staging on waves 0-3 only, the staging of a
+    block's second fresh unit had no barrier between it and its first reader; one forward in ~1 200 differed in four rows."""
+    from ctgcn_amd import CTGCN
+    monkeypatch.setenv("CTGCN_STREAMS", "2")
+    n, T = 3001, 5
+    adjs = _window(n, T, 6, 6, seed=3)
+    torch.manual_seed(0)
+    model = CTGCN(40, 64, 128, 1, 2, T).to(DEV).eval()
+    xs = [torch.randn(n, 40, device=DEV) for _ in range(T)]
+    ref = None
+    for it in range(200):
+        monkeypatch.setenv("CTGCN_GROUP", "1" if it % 2 == 0 else "0")
+        junk = torch.empty((it * 7919) % 20_000_000 + 1, device=DEV)
+        with torch.no_grad():
+            out = model(xs, adjs)
+        del junk
+        if ref is None:
+            ref = out.clone()
+        assert torch.equal(out, ref), it

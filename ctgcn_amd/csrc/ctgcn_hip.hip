@@ -2347,7 +2347,8 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     __shared__ float wsc_ih[3][GRU_H];
     __shared__ float csc_hh[4][GRU_H];                   // rows 0-2: product scales of the three gates, row 3: b_hn
     __shared__ float bias_s[3][GRU_H];
-    __shared__ float ln_gb[2][GRU_H];                    // row-plan forms: LayerNorm weight / bias (no vector-memory load at a tile's end, see below)
+    __shared__ float ln_gb[2][GRU_H];                    // LayerNorm weight / bias and the temporal layout's step offsets: no vector-memory load
+    __shared__ int64_t soff_s[32];                       // outside the x pipeline (any wait on one is a wait for the x rows in flight, see below)
     __shared__ int32_t ord_s[4][16];                     // row-plan forms: output rows and step mask of the tiles in flight (ring of four, see below)
     __shared__ uint32_t msk_s[4];
     constexpr int WL = (PRESPLIT && REDUCE) ? CTGCN_L8_WL_PLAN : L8_WL;   // the row-plan forms have no hrow staging: room for more fragments
@@ -2381,10 +2382,11 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         (&bias_s[0][0])[i] = a.bias_gi ? a.bias_gi[i] : 0.f;
     }
     if (tid < GRU_H) csc_hh[3][tid] = a.bhn ? a.bhn[tid] : 0.f;
-    if (PRESPLIT && REDUCE && tid < GRU_H) {
+    if (tid < GRU_H) {
         ln_gb[0][tid] = a.gamma ? a.gamma[tid] : 1.f;
         ln_gb[1][tid] = (a.gamma && a.beta) ? a.beta[tid] : 0.f;
     }
+    if (tid < 32) soff_s[tid] = (a.step_off && tid < a.steps) ? a.step_off[tid] : 0;
     __syncthreads();
 
     const int64_t ntiles = (a.rows + 15) / 16;
@@ -2403,7 +2405,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 xq2 = *(const h4v *)(a.xp2 + rs_ * GRU_H + sc);
                 xqs = a.xps[rs_];
             } else {
-                v = *(const f4v *)(a.x + (a.step_off ? row * a.ld_row + a.step_off[t] : (row * S + t) * a.ldx) + sc);
+                v = *(const f4v *)(a.x + (a.step_off ? row * a.ld_row + soff_s[t] : (row * S + t) * a.ldx) + sc);
             }
         }
     };
@@ -2512,10 +2514,23 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     int64_t ln_row0 = 0;
     int em_buf = 0, em_last = -1, em_t = 0;                // per-step form: the unit whose rows are still to be emitted
     int64_t em_row0 = 0;
+    const bool has_ln_ = a.gamma != nullptr;
+    auto ln_row_lds = [&](const float *src, float *dst) {     // = gru_layernorm_row with the weights in LDS (same operations, bit for bit)
+        float2 v = *(const float2 *)(src + lane * 2);
+        if (has_ln_) {
+            const float mean = wave_sum64(v.x + v.y) * (1.0f / GRU_H);
+            const float dx = v.x - mean, dy = v.y - mean;
+            const float rstd = rsqrtf(wave_sum64(dx * dx + dy * dy) * (1.0f / GRU_H) + a.eps);
+            const float2 g = *(const float2 *)(&ln_gb[0][lane * 2]), b = *(const float2 *)(&ln_gb[1][lane * 2]);
+            v.x = dx * rstd * g.x + b.x;
+            v.y = dy * rstd * g.y + b.y;
+        }
+        *(float2 *)(dst + lane * 2) = v;
+    };
     auto pending_rows = [&]() {
         if (em_last < 0) return;
         for (int r = wave * 2; r < wave * 2 + 2; ++r)
-            if (r <= em_last) gru_layernorm_row(hrow[REDUCE ? 0 : em_buf][REDUCE ? 0 : r], a.out + ((em_row0 + r) * S + em_t) * GRU_H, lane, a.gamma, a.beta, a.eps);
+            if (r <= em_last) ln_row_lds(hrow[REDUCE ? 0 : em_buf][REDUCE ? 0 : r], a.out + ((em_row0 + r) * S + em_t) * GRU_H);
         em_last = -1;
     };
     auto pending_layernorm = [&]() {
@@ -2523,7 +2538,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         for (int r = wave * 2; r < wave * 2 + 2; ++r)
             if (r <= ln_last) {
                 const int64_t orow = (DEDUP && a.order) ? (int64_t)a.order[ln_row0 + r] : ln_row0 + r;
-                gru_layernorm_row((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H, a.out + orow * a.ldo, lane, a.gamma, a.beta, a.eps);
+                ln_row_lds((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H, a.out + orow * a.ldo);
             }
         ln_last = -1;
     };

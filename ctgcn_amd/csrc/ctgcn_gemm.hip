@@ -398,7 +398,7 @@ __device__ __forceinline__ void gemm_epilogue_planes(const GemmArgs &a, const f1
 // not the 2.5 of the data sheet.  Measured and NOT faster: a 256 x 128 tile with 64 x 128 wave tiles at one wave per SIMD (1.09 vs
 // 1.08 ms per projection, slower on the short MLP shapes), tile-contiguous global addresses (-6 %), staggered block starts (0).
 // CHAIN: the layer-chain form (per-block A scales and / or planes out); the plain form keeps round 2's code and registers untouched
-template <bool CHAIN>
+template <bool CHAIN, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 {
     constexpr int BM = 128;
@@ -429,18 +429,30 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
     for (int r = 0; r < 2; ++r) {
         const int64_t ra = min(m0 + lr + 64 * r, a.M - 1), rb = min((int64_t)n0 + lr + 64 * r, (int64_t)a.N - 1);
         const int sw = swz(lr + 64 * r, tid & 3);
-        gp[r] = a.a1 + ra * a.Kp + ls;      lp[r] = &As[0][0][lr + 64 * r][sw];
-        gp[2 + r] = a.a2 + ra * a.Kp + ls;  lp[2 + r] = &As[0][1][lr + 64 * r][sw];
-        gp[4 + r] = a.b1 + rb * a.Kp + ls;  lp[4 + r] = &Bs[0][0][lr + 64 * r][sw];
-        gp[6 + r] = a.b2 + rb * a.Kp + ls;  lp[6 + r] = &Bs[0][1][lr + 64 * r][sw];
+        if (DMA) {
+            // direct-to-LDS loads: a wave instruction fills 16 rows x 64 B = 1 KB of LDS linearly (lane l -> byte 16 l = row l / 4, stored segment
+            // l % 4), so the swizzle moves to the GLOBAL side: the lane fetches the segment that belongs at its position (the XOR is its own inverse)
+            gp[r] = a.a1 + ra * a.Kp + sw;      lp[r] = &As[0][0][16 * wave + 64 * r][0];
+            gp[2 + r] = a.a2 + ra * a.Kp + sw;  lp[2 + r] = &As[0][1][16 * wave + 64 * r][0];
+            gp[4 + r] = a.b1 + rb * a.Kp + sw;  lp[4 + r] = &Bs[0][0][16 * wave + 64 * r][0];
+            gp[6 + r] = a.b2 + rb * a.Kp + sw;  lp[6 + r] = &Bs[0][1][16 * wave + 64 * r][0];
+        } else {
+            gp[r] = a.a1 + ra * a.Kp + ls;      lp[r] = &As[0][0][lr + 64 * r][sw];
+            gp[2 + r] = a.a2 + ra * a.Kp + ls;  lp[2 + r] = &As[0][1][lr + 64 * r][sw];
+            gp[4 + r] = a.b1 + rb * a.Kp + ls;  lp[4 + r] = &Bs[0][0][lr + 64 * r][sw];
+            gp[6 + r] = a.b2 + rb * a.Kp + ls;  lp[6 + r] = &Bs[0][1][lr + 64 * r][sw];
+        }
     }
     constexpr int A_STAGE = 2 * BM * BKP, B_STAGE = 2 * BN * BKP;          // halfs per LDS stage
     // Two register sets of 8 x 16 B: tile kt+1 waits in one while tiles kt+2 / kt+3 are in flight.  Loads are never
     // conditional: past the last k step the last tile is requested again and dropped (behind a branch the compiler cannot
     // count the outstanding loads and waits for vmcnt(0) before every LDS store: the distance silently becomes one step).
     h8v gr[2][8];
-    auto gload1 = [&](int kt, int s, int i) { gr[s][i] = *(const h8v *)(gp[i] + (int64_t)min(kt, nk - 1) * BK); };
-    auto lstore1 = [&](int st, int s, int i) { *(h8v *)(lp[i] + st * (i < 4 ? A_STAGE : B_STAGE)) = gr[s][i]; };
+#ifndef CTGCN_GEMM_ABLATE
+#define CTGCN_GEMM_ABLATE 0          // diagnostic builds (WRONG results): 1 no LDS stores in the k loop, 2 no global loads in the k loop, 3 no barrier in the k loop,
+#endif                               // 4 no MFMA, 5 no fragment reads in the k loop
+    auto gload1 = [&](int kt, int s, int i) { if (CTGCN_GEMM_ABLATE == 2 && kt > 2) return; gr[s][i] = *(const h8v *)(gp[i] + (int64_t)min(kt, nk - 1) * BK); };
+    auto lstore1 = [&](int st, int s, int i) { if (CTGCN_GEMM_ABLATE == 1) { asm volatile("" :: "v"(gr[s][i])); return; } *(h8v *)(lp[i] + st * (i < 4 ? A_STAGE : B_STAGE)) = gr[s][i]; };
 
     f16v acc[2][2];
 #pragma unroll
@@ -476,23 +488,56 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 #pragma unroll
         for (int t = 0; t < 12; ++t) {
             const int term = t >> 2, i = (t >> 1) & 1, j = t & 1;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][term == 1 ? 1 : 0], fb[kk][j][term == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
+            if (CTGCN_GEMM_ABLATE != 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][term == 1 ? 1 : 0], fb[kk][j][term == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
+            else asm volatile("" :: "v"(fa[kk][i][term == 1 ? 1 : 0]), "v"(fb[kk][j][term == 0 ? 1 : 0]));
+            __builtin_amdgcn_sched_barrier(0);
             if (t < 8) side(t);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // DMA: tile kt -> LDS stage kt & 1 without passing through registers (global_load_lds_dwordx4; the request counts in vmcnt)
+    auto dma1 = [&](int kt, int i) {
+        const int st = kt & 1;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(gp[i] + (int64_t)min(kt, nk - 1) * BK),
+                                         (void __attribute__((address_space(3))) *)(lp[i] + st * (i < 4 ? A_STAGE : B_STAGE)), 16, 0, 0);
+    };
+    // one k step, DMA form: tile kt is complete in stage kt & 1 (slab-0 fragments in registers), tile kt+1 is landing in the other stage.
+    //   phase A   fragments of slab 1; 12 MFMAs on slab 0; wait for this wave's requests of tile kt+1; barrier (tile kt+1 complete, stage kt&1 read)
+    //   phase B   fragments of slab 0 of tile kt+1; 12 MFMAs on slab 1 with the eight requests of tile kt+2 (into stage kt&1) behind the first eight
+    auto step_dma = [&](int kt) {
+        const int st = kt & 1;
+        // the fragment reads of the NEXT slab go out behind the first MFMA of this one: in front of it the compiler's s_waitcnt lgkmcnt(0)
+        // for this slab's fragments (read a phase ago, long complete) would also wait for them — an LDS latency per phase
+        slab(0, [&](int t) { if (t == 0) fread(st, 1); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        slab(1, [&](int t) { if (t == 0) fread(st ^ 1, 0); dma1(kt + 2, t); });
+    };
     // one k step: tile kt is in LDS stage kt & 1 and its slab-0 fragments are in registers; register set s holds tile kt+1
     auto step = [&](int kt, int s) {
         const int st = kt & 1;
-        fread(st, 1);
+        if (CTGCN_GEMM_ABLATE != 5 || kt == 0) fread(st, 1);
         __builtin_amdgcn_sched_barrier(0);
         slab(0, [&](int t) { lstore1(st ^ 1, s, t); });   // stage st^1 was last read before the barrier of step kt-1
-        __syncthreads();
-        fread(st ^ 1, 0);
+        if (CTGCN_GEMM_ABLATE != 3) __syncthreads();
+        if (CTGCN_GEMM_ABLATE != 5 || kt == 0) fread(st ^ 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         slab(1, [&](int t) { gload1(kt + 3, s, t); });
     };
 
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma1(0, i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma1(1, i);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 is in (requests retire in order)
+        __syncthreads();
+        fread(0, 0);
+        for (int kt = 0; kt < nk; ++kt) step_dma(kt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dropped requests past the last tile must not land in the epilogue's tile
+        gemm_epilogue<2, 2>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, m0 + BM <= a.M && n0 + BN <= a.N);
+        return;
+    }
     // prologue: tiles 0 and 1 are requested together (one exposed memory latency, not two), tile 2 as soon as set 0 is in LDS
 #pragma unroll
     for (int i = 0; i < 8; ++i) gload1(0, 0, i);
@@ -553,6 +598,12 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 }
 
 size_t align_up(size_t x, size_t al) { return (x + al - 1) / al * al; }
+
+// CTGCN_GEMM_DMA=1: operand staging with global_load_lds_dwordx4 (no registers, no ds_write_b128) instead of registers + ds_write_b128.
+// Measured equal (round 4, profiles/r04_gemm_ablation_dma.txt: 1.085 vs 1.096 ms on the Enron projection, windows unchanged): the k loop is not
+// bound by the LDS stores' issue but by the operand bytes themselves (HBM for A, 0.35 ms of the 0.75) adding to the MFMA time instead of hiding
+// under it.  Kept as a switch (read per call: tests toggle it); default off.
+bool gemm_dma_enabled() { const char *e = getenv("CTGCN_GEMM_DMA"); return e && atoi(e) == 1; }
 
 }  // namespace
 
@@ -624,7 +675,8 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
         (void)hipMemsetAsync(g.timeline, 0, (size_t)blocks * 64, st);
     }
 #endif
-    hipLaunchKernelGGL(gemm_h2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    if (gemm_dma_enabled()) hipLaunchKernelGGL((gemm_h2_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_h2_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
 #ifdef CTGCN_GEMM_TIMELINE
     if (g.timeline) {
         (void)hipStreamSynchronize(st);
@@ -747,8 +799,9 @@ int ctgcn_linear_planes_f32(int64_t rows, int32_t n_out, int32_t k, const void *
 #ifdef CTGCN_GEMM_TIMELINE
     g.timeline = nullptr;
 #endif
-    if (x_scale_blocks > 1 || y_planes) hipLaunchKernelGGL(gemm_h2_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(gemm_h2_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    if (x_scale_blocks > 1 || y_planes) hipLaunchKernelGGL((gemm_h2_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else if (gemm_dma_enabled()) hipLaunchKernelGGL((gemm_h2_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((gemm_h2_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

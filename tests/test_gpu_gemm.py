@@ -244,3 +244,19 @@ def test_k3_planes_are_cached_and_follow_in_place_updates(monkeypatch):
     import gc
     gc.collect()
     assert len(ops._plane_cache.entries) == 0
+
+
+def test_direct_to_lds_operand_staging_is_bit_identical(monkeypatch):
+    """CTGCN_GEMM_DMA=1 (global_load_lds_dwordx4 instead of registers + ds_write_b128): the same tiles, the same MFMA order — the same bits"""
+    from ctgcn_amd import ops
+    monkeypatch.setenv("CTGCN_GEMM", "hand")
+    torch.manual_seed(11)
+    for rows, k, n_out in ((5000, 500, 384), (777, 1737, 500), (129, 96, 130)):
+        x = torch.randn(rows, k, device=DEV) * torch.rand(rows, 1, device=DEV).mul(4).exp()
+        w = torch.randn(n_out, k, device=DEV) / k ** 0.5
+        b = torch.randn(n_out, device=DEV)
+        monkeypatch.setenv("CTGCN_GEMM_DMA", "0")
+        ref = ops.linear_split(x, w, b, selu=True)
+        monkeypatch.setenv("CTGCN_GEMM_DMA", "1")
+        got = ops.linear_split(x, w, b, selu=True)
+        assert torch.equal(got, ref), (rows, k, n_out)

@@ -597,7 +597,126 @@ __global__ __launch_bounds__(256, 2) void gemm_h2_kernel(const GemmArgs a)
 #endif
 }
 
+// gemm_h2_wide_kernel (round 4 experiment, CTGCN_GEMM_WIDE=1): 256 x 128 block tile, EIGHT waves (4 x 2 of 64 x 64), k steps of 32, THREE LDS
+// stages filled by global_load_lds_dwordx4 — a request is in flight for two whole k steps (gemm_h2_kernel: one to one and a half), 96 KB per CU
+// instead of 64.  Why: in gemm_h2_kernel the operand bytes and the MFMAs ADD (profiles/r04_gemm_ablation_dma.txt); Little's law on the A planes
+// (17.6 KB/us per CU at 4.5 TB/s x ~3 us of loaded latency) asks for ~53 KB in flight per CU, which two blocks of one step each only just hold.
+// Same MFMA order per accumulator as gemm_h2_kernel: bit-identical results.  One block per CU (144 KB of LDS).
+__global__ __launch_bounds__(512, 2) void gemm_h2_wide_kernel(const GemmArgs a)
+{
+    constexpr int BM = 256, NST = 3;
+    constexpr int ROWS = BM + BN;                         // plane rows of one stage: A rows 0..255, then B rows
+    __shared__ _Float16 Ls[NST][2][ROWS][BKP];            // [stage][plane][row][k]: 3 x 2 x 384 x 64 B = 144 KB
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t b = blockIdx.x;
+    const int xcd = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int nt = (int)(q % a.ntiles);
+    const int64_t mp = (q / a.ntiles) * 8 + xcd;
+    if (mp >= a.mtiles) return;
+    const int64_t m0 = mp * BM;
+    const int n0 = nt * BN;
+    const int nk = a.Kp / BK;
+    // staging: a wave instruction fills 16 rows x 64 B of one plane (lane l -> row l / 4, stored segment l % 4; the swizzle sits in the global
+    // address).  24 row groups x 2 planes = 48 instructions per stage, 6 per wave: groups wave, wave + 8, wave + 16 of both planes
+    const _Float16 *gp[6];
+    int lo[6];                                            // LDS offset (halfs) inside a stage
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int grp = wave + 8 * (i >> 1), plane = i & 1;
+        const int row = grp * 16 + (lane >> 2);           // 0..383
+        const int sw = swz(row, lane & 3);
+        if (row < BM) gp[i] = (plane ? a.a2 : a.a1) + min(m0 + row, a.M - 1) * a.Kp + sw;
+        else gp[i] = (plane ? a.b2 : a.b1) + min((int64_t)n0 + row - BM, (int64_t)a.N - 1) * a.Kp + sw;
+        lo[i] = (plane * ROWS + grp * 16) * BKP;
+    }
+    constexpr int STAGE = 2 * ROWS * BKP;
+    _Float16 *const l0 = &Ls[0][0][0][0];
+    auto dma1 = [&](int kt, int i) {
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(gp[i] + (int64_t)min(kt, nk - 1) * BK),
+                                         (void __attribute__((address_space(3))) *)(l0 + (kt % NST) * STAGE + lo[i]), 16, 0, 0);
+    };
+    f16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    const int fr = lane & 31;
+    int fo_a[2][2], fo_b[2][2];                           // [slab][tile] -> offset (halfs) of plane 0 inside a stage
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ra = wm * 64 + t * 32 + fr, rb = BM + wn * 64 + t * 32 + fr;
+            fo_a[kk][t] = ra * BKP + swz(ra, kk * 2 + (lane >> 5));
+            fo_b[kk][t] = rb * BKP + swz(rb, kk * 2 + (lane >> 5));
+        }
+    h8v fa[2][2][2], fb[2][2][2];
+    auto fread = [&](int st, int kk) {
+        const _Float16 *sb = l0 + st * STAGE;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                fa[kk][t][p] = *(const h8v *)(sb + fo_a[kk][t] + p * (ROWS * BKP));
+                fb[kk][t][p] = *(const h8v *)(sb + fo_b[kk][t] + p * (ROWS * BKP));
+            }
+    };
+    auto slab = [&](int kk, auto side) {
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            const int term = t >> 2, i = (t >> 1) & 1, j = t & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[kk][i][term == 1 ? 1 : 0], fb[kk][j][term == 0 ? 1 : 0], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            side(t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma1(0, i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma1(1, i);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dma1(2, i);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // tile 0 is in (requests retire in order)
+    __syncthreads();
+    fread(0, 0);
+    int st = 0;                                           // kt % 3
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st1 = st == NST - 1 ? 0 : st + 1;
+        // phase A: slab 0 of tile kt; the fragments of slab 1 go out behind the first MFMA; then tile kt+1 must be complete (this wave's six
+        // requests of tile kt+2 may still be in flight) and everybody must have read stage st's slab 1 before it is refilled
+        slab(0, [&](int t) { if (t == 0) fread(st, 1); });
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __syncthreads();
+        // phase B: slab 1 of tile kt, fragments of slab 0 of tile kt+1, and the requests of tile kt+3 into the stage tile kt leaves
+        slab(1, [&](int t) { if (t == 0) fread(st1, 0); if (t >= 1 && t < 7) dma1(kt + 3, t - 1); });
+        st = st1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gemm_epilogue<2, 2>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, m0 + BM <= a.M && n0 + BN <= a.N);
+}
+
 size_t align_up(size_t x, size_t al) { return (x + al - 1) / al * al; }
+
+// CTGCN_GEMM_WIDE=1: gemm_h2_wide_kernel for the plain GEMMs (read per call)
+bool gemm_wide_enabled() { const char *e = getenv("CTGCN_GEMM_WIDE"); return e && atoi(e) == 1; }
+bool gemm_dma_enabled();
+static void launch_gemm_plain(GemmArgs &g, hipStream_t st)
+{
+    if (gemm_wide_enabled()) {
+        g.mtiles = (g.M + 255) / 256;
+        const int64_t blocks = (g.mtiles + 7) / 8 * 8 * g.ntiles;
+        hipLaunchKernelGGL(gemm_h2_wide_kernel, dim3((unsigned)blocks), dim3(512), 0, st, g);
+        return;
+    }
+    const int64_t blocks = (g.mtiles + 7) / 8 * 8 * g.ntiles;
+    if (gemm_dma_enabled()) hipLaunchKernelGGL((gemm_h2_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_h2_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+}
 
 // CTGCN_GEMM_DMA=1: operand staging with global_load_lds_dwordx4 (no registers, no ds_write_b128) instead of registers + ds_write_b128.
 // Measured equal (round 4, profiles/r04_gemm_ablation_dma.txt: 1.085 vs 1.096 ms on the Enron projection, windows unchanged): the k loop is not
@@ -675,8 +794,7 @@ static int linear_impl(int64_t rows, int32_t n_out, int32_t k, const float *x, i
         (void)hipMemsetAsync(g.timeline, 0, (size_t)blocks * 64, st);
     }
 #endif
-    if (gemm_dma_enabled()) hipLaunchKernelGGL((gemm_h2_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_h2_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, g);
+    launch_gemm_plain(g, st);
 #ifdef CTGCN_GEMM_TIMELINE
     if (g.timeline) {
         (void)hipStreamSynchronize(st);
@@ -800,8 +918,7 @@ int ctgcn_linear_planes_f32(int64_t rows, int32_t n_out, int32_t k, const void *
     g.timeline = nullptr;
 #endif
     if (x_scale_blocks > 1 || y_planes) hipLaunchKernelGGL((gemm_h2_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
-    else if (gemm_dma_enabled()) hipLaunchKernelGGL((gemm_h2_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL((gemm_h2_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    else launch_gemm_plain(g, (hipStream_t)stream);
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

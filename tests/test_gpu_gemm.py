@@ -260,3 +260,8 @@ def test_direct_to_lds_operand_staging_is_bit_identical(monkeypatch):
         monkeypatch.setenv("CTGCN_GEMM_DMA", "1")
         got = ops.linear_split(x, w, b, selu=True)
         assert torch.equal(got, ref), (rows, k, n_out)
+        monkeypatch.setenv("CTGCN_GEMM_DMA", "0")
+        monkeypatch.setenv("CTGCN_GEMM_WIDE", "1")            # 256 x 128 tiles, eight waves, three LDS stages
+        got = ops.linear_split(x, w, b, selu=True)
+        monkeypatch.setenv("CTGCN_GEMM_WIDE", "0")
+        assert torch.equal(got, ref), ("wide", rows, k, n_out)

@@ -2351,7 +2351,9 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     __shared__ int64_t soff_s[32];                       // outside the x pipeline (any wait on one is a wait for the x rows in flight, see below)
     __shared__ int32_t ord_s[4][16];                     // row-plan forms: output rows and step mask of the tiles in flight (ring of four, see below)
     __shared__ uint32_t msk_s[4];
-    constexpr int WL = (PRESPLIT && REDUCE) ? CTGCN_L8_WL_PLAN : L8_WL;   // the row-plan forms have no hrow staging: room for more fragments
+    // the row-plan forms have no hrow staging: room for more fragments.  The recompute pass (SAVE) takes two more: with 12 the x prefetch
+    // registers were spilled right behind their loads (s_waitcnt + scratch_store: the prefetch distance became zero)
+    constexpr int WL = (PRESPLIT && REDUCE) ? (SAVE ? 15 : CTGCN_L8_WL_PLAN) : L8_WL;
     __shared__ h8v Wl[8][WL][64];
     // per-step form: h_t of the unit's 16 rows in fp32, double buffered by unit parity; the rows leave (LayerNorm, 512-byte stores) at the
     // start of the NEXT unit, two per wave — the staging the kernel pair uses, so the outputs are the pair's bit for bit
@@ -2525,17 +2527,18 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
             v.x = dx * rstd * g.x + b.x;
             v.y = dy * rstd * g.y + b.y;
         }
-        *(float2 *)(dst + lane * 2) = v;
+        *(float2 *)(dst + (uint32_t)(lane * 2)) = v;
     };
+    const int wave_g = __builtin_amdgcn_readfirstlane(wave);      // uniform row numbers: output addresses = scalar base + one 32-bit lane offset
     auto pending_rows = [&]() {
         if (em_last < 0) return;
-        for (int r = wave * 2; r < wave * 2 + 2; ++r)
+        for (int r = wave_g * 2; r < wave_g * 2 + 2; ++r)
             if (r <= em_last) ln_row_lds(hrow[REDUCE ? 0 : em_buf][REDUCE ? 0 : r], a.out + ((em_row0 + r) * S + em_t) * GRU_H);
         em_last = -1;
     };
     auto pending_layernorm = [&]() {
         if (ln_last < 0) return;
-        for (int r = wave * 2; r < wave * 2 + 2; ++r)
+        for (int r = wave_g * 2; r < wave_g * 2 + 2; ++r)
             if (r <= ln_last) {
                 const int64_t orow = (DEDUP && a.order) ? (int64_t)a.order[ln_row0 + r] : ln_row0 + r;
                 ln_row_lds((const float *)&Hs[ln_buf][0][0][0] + r * GRU_H, a.out + orow * a.ldo);
@@ -2771,15 +2774,19 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                     if (SAVE) { rv4[j] = rv; zv4[j] = zv; nv4[j] = nv; an4[j] = an; }
                 }
                 if (SAVE && col <= last) {                // training's recompute pass: gates and raw h of this step, position order
-                    const int64_t e = (row0 + col) * S + t;
+                    // uniform 64-bit base (tile, step) + ONE 32-bit lane offset per stream: with per-lane 64-bit addresses the recompute pass
+                    // spilled its loop-invariant address pairs and reloaded them behind the x requests (scratch is vector memory: in-order vmcnt)
+                    const int ng = a.gates3 ? 3 : 4;
+                    float *gb = a.gates + ((int64_t)row0 * S + t) * (ng * GRU_H);
+                    float *hb = a.hseq + ((int64_t)row0 * S + t) * GRU_H;
+                    const uint32_t go = (uint32_t)(col * S) * (uint32_t)(ng * GRU_H) + (uint32_t)oc;
+                    const uint32_t ho = (uint32_t)(col * S) * (uint32_t)GRU_H + (uint32_t)oc;
                     if (a.gates3) {
-                        float *gp = a.gates + e * (3 * GRU_H) + oc;
-                        *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = an4;
+                        *(f4v *)(gb + go) = rv4; *(f4v *)(gb + go + GRU_H) = zv4; *(f4v *)(gb + go + 2 * GRU_H) = an4;
                     } else {
-                        float *gp = a.gates + e * (4 * GRU_H) + oc;
-                        *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
+                        *(f4v *)(gb + go) = rv4; *(f4v *)(gb + go + GRU_H) = zv4; *(f4v *)(gb + go + 2 * GRU_H) = nv4; *(f4v *)(gb + go + 3 * GRU_H) = an4;
                     }
-                    *(f4v *)(a.hseq + e * GRU_H + oc) = h;
+                    *(f4v *)(hb + ho) = h;
                 }
                 hprev = h;
                 hsum = t > 0 ? hsum + h : h;
@@ -2802,7 +2809,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                     *(h4v *)(&Hs[pb][0][col][l8_off(col, oc)]) = p;
                     *(h4v *)(&Hs[pb][1][col][l8_off(col, oc)]) = q;
                 } else if (SAVE) {                        // recompute pass: the pre-LayerNorm sum leaves as it is (its backward needs it)
-                    if (col <= last) *(f4v *)(a.presum + (row0 + col) * GRU_H + oc) = hsum;
+                    if (col <= last) *(f4v *)((a.presum + (int64_t)row0 * GRU_H) + (uint32_t)(col * GRU_H + oc)) = hsum;
                 } else {                                  // last step: that buffer takes the summed rows (fp32) for the LayerNorm instead
                     *(f4v *)((float *)&Hs[pb][0][0][0] + col * GRU_H + oc) = hsum;
                     ln_buf = pb; ln_last = last; ln_ring = cring;
@@ -2921,8 +2928,9 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 if (SAVE) { rv4[j] = rv; zv4[j] = zv; nv4[j] = nv; an4[j] = an; }
             }
             if (SAVE && col <= last) {                    // the gates of this step for the backward recurrence (training: recompute pass)
-                float *gp = a.gates + ((row0 + col) * S + t) * (4 * GRU_H) + oc;
-                *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
+                float *gb = a.gates + ((int64_t)row0 * S + t) * (4 * GRU_H);       // scalar base + one 32-bit lane offset (see the row-plan path)
+                const uint32_t go = (uint32_t)(col * S) * (uint32_t)(4 * GRU_H) + (uint32_t)oc;
+                *(f4v *)(gb + go) = rv4; *(f4v *)(gb + go + GRU_H) = zv4; *(f4v *)(gb + go + 2 * GRU_H) = nv4; *(f4v *)(gb + go + 3 * GRU_H) = an4;
             }
             hprev = h;
             if (REDUCE) hsum = t > 0 ? hsum + h : h;

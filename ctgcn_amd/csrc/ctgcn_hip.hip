@@ -1773,17 +1773,21 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
         const int64_t row0 = tile * GRU_BM;
         const int last = (int)min((int64_t)GRU_BM, a.rows - row0) - 1;
         // address of the lane's float4 of gate 0 for (step t, row tile rt); gates are gi_gs floats apart
-        const float *gi_tile = a.gi_blocked ? a.gi + tile * (int64_t)gstride * GRU_BM + wave * 1024 + col * 16 + 4 * grp
-                                            : a.gi + row0 * gstride + oc;
+        // = (scalar base of the tile) + one 32-bit lane offset: per-lane 64-bit pointers were spilled and reloaded inside the step loop, behind
+        // the gi requests in flight (scratch is vector memory: the reload's wait is a wait for all of them)
         const int gi_gs = a.gi_blocked ? 8 * 1024 : GRU_H;
         // compact gi under a row plan (REDUCE form only): see GruArgs
         const bool planned = REDUCE && !SAVE && a.tmask != nullptr;
-        const uint32_t tm = planned ? a.tmask[tile] : 0u;
+        const uint32_t tm = planned ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tmask[tile]) : 0u;
         const int nfresh = __popc(tm);
-        const float *gi_plan = planned ? a.gi + (int64_t)a.tbase[tile] * (3 * GRU_H) + oc : nullptr;
+        const float *gi_base = planned ? a.gi + (int64_t)__builtin_amdgcn_readfirstlane(a.tbase[tile]) * (3 * GRU_H)
+                                       : (a.gi_blocked ? a.gi + tile * (int64_t)gstride * GRU_BM : a.gi + row0 * gstride);
+        const uint32_t gi_lane = a.gi_blocked ? (uint32_t)(wave * 1024 + col * 16 + 4 * grp) : (uint32_t)oc;
         auto gaddr = [&](int t, int rt) {
-            if (planned) return gi_plan + ((int64_t)min(rt * 16 + col, last) * nfresh + (__popc(tm & ((2u << t) - 1u)) - 1)) * (3 * GRU_H);
-            return a.gi_blocked ? gi_tile + t * (3 * 8 * 1024) + rt * 256 : gi_tile + t * 3 * GRU_H + min(rt * 16 + col, last) * gstride;
+            uint32_t off;
+            if (planned) off = (uint32_t)(min(rt * 16 + col, last) * nfresh + (__popc(tm & ((2u << t) - 1u)) - 1)) * (uint32_t)(3 * GRU_H);
+            else off = a.gi_blocked ? (uint32_t)(t * (3 * 8 * 1024) + rt * 256) : (uint32_t)(t * 3 * GRU_H) + (uint32_t)min(rt * 16 + col, last) * (uint32_t)gstride;
+            return gi_base + (gi_lane + off);
         };
         f4v hreg[GRU_RT];
 

@@ -248,7 +248,8 @@ def main():
         gen = torch.Generator(device=dev)
         for t in mine:
             gen.manual_seed(DEFAULT_SEED + t)
-            x_list[t] = torch.randn(n, input_dim, generator=gen, device=dev).mul_(1e-4).add_(degrees[t].unsqueeze(1))
+            # built once, fed to every forward (reference train.py:72-76): declared static, as ctgcn_amd.helper.DataLoader does for its outputs
+            x_list[t] = ops.mark_static(torch.randn(n, input_dim, generator=gen, device=dev).mul_(1e-4).add_(degrees[t].unsqueeze(1)))
     torch.manual_seed(0)
     with torch.device(dev):
         model = CTGCN(input_dim, hid, emb, W["trans"], layers, T, rnn_type="GRU", model_type=W["model"], trans_activate_type=W["act"])

@@ -14,7 +14,7 @@ ACT_NONE, ACT_SELU = 0, 1
 OP_KCORE = 1
 OP_INGEST = 2
 MAX_SLOTS = 255
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _c = ctypes
 _vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_int, _c.c_size_t
@@ -62,11 +62,9 @@ SIGNATURES = {
     "ctgcn_linear_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "ctgcn_split_planes_bytes": (_sz, [_i64, _i32]),
     "ctgcn_split_rows_f32": (_int, [_i64, _i32, _vp, _i64, _vp, _sz, _vp]),
-    "ctgcn_k3_planes_bytes": (_sz, [_i64, _i32]),
-    "ctgcn_split_rows_k3_f32": (_int, [_i64, _i32, _vp, _i64, _vp, _c.c_float, _vp, _i32, _c.c_float, _i32, _vp, _sz, _vp, _vp]),
-    "ctgcn_scale_bias_act_f32": (_int, [_i64, _i32, _vp, _i64, _vp, _c.c_float, _vp, _i32, _vp, _i64, _vp]),
-    "ctgcn_chain_planes_bytes": (_sz, [_i64, _i32]),
-    "ctgcn_linear_planes_f32": (_int, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _sz, _vp]),
+    "ctgcn_pack_weight_bytes": (_sz, [_i32, _i32]),
+    "ctgcn_pack_weight_f32": (_int, [_i32, _i32, _vp, _i64, _vp, _sz, _vp]),
+    "ctgcn_linear_packed_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _i64, _vp]),
     "ctgcn_linear_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _sz, _vp]),
     "ctgcn_core_aggregate_split_workspace_bytes": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "ctgcn_core_aggregate_split_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _u32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i32, _vp, _sz, _vp, _sz, _vp]),

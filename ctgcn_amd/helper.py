@@ -12,6 +12,7 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 
+from . import ops
 from .core_adj import CoreAdj
 from .utils import get_sp_adj_mat, read_edge_rows
 
@@ -174,7 +175,8 @@ class DataLoader(object):
         width = max_degree + 1
         for adj, deg in zip(adjs, degrees):
             if init_type == 'gaussian':
-                x_list.append(self._gaussian_degree_features(deg, std, width))
+                # dense features built once and fed to every forward (train.py:72-76): the first Linear may keep their operand planes
+                x_list.append(ops.mark_static(self._gaussian_degree_features(deg, std, width)))
                 input_dim = width
             elif init_type == 'adj':
                 x_list.append(_coo_tensor(adj, self.device))
@@ -222,7 +224,7 @@ class DataLoader(object):
         for arr in arrays:
             full = np.zeros((arr.shape[0], width), dtype=np.float32)
             full[:, : arr.shape[1]] = arr
-            x_list.append(torch.from_numpy(full).to(self.device))
+            x_list.append(ops.mark_static(torch.from_numpy(full).to(self.device)))
         return x_list, width
 
 

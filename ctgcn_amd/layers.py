@@ -163,16 +163,9 @@ class MLP(nn.Module):
 
     def forward(self, x):
         stack = [self.linear] if self.layer_num == 1 else list(self.linears)
-        inference = torch.is_tensor(x) and not x.is_sparse and x.is_cuda and x.dim() == 2 and not (
-            torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
-        if inference and len(stack) > 1 and all(ops.linear_split_ok(x if i == 0 else torch.empty(1, l.weight.shape[1], device=x.device), l.weight)
-                                                and ops.linear_k3_ok(x, l.weight) for i, l in enumerate(stack)):
-            # inference: one library fp16 GEMM per layer over the fp16 x 2 planes, scales / bias / SELU applied by the next layer's split
-            return ops.mlp_k3(x, stack, selu=self.activate_type == 'N', static_x=True)
-        if inference and len(stack) > 1 and ops.mlp_chain_ok(x, stack):
-            return ops.mlp_chain_split(x, stack, selu=self.activate_type == 'N', static_x=True)     # inference: layer to layer in operand form
         for i, layer in enumerate(stack):
-            # the first layer's operand is the module's input — node features the callers build once and pass to every forward
-            # (train.py:72-76, embedding.py:318): its operand planes are kept between calls (ops._PlaneCache, validated by the version counter)
-            x = self._apply_linear(layer, x, selu=self.activate_type == 'N', static_x=(i == 0))
+            # the first layer's operand is the module's input: when the caller has declared it static (ops.mark_static — node features
+            # built once and passed to every forward, train.py:72-76, embedding.py:318; ctgcn_amd.helper.DataLoader does) its operand
+            # planes are kept between calls (ops._PlaneCache, validated by the version counter)
+            x = self._apply_linear(layer, x, selu=self.activate_type == 'N', static_x=(i == 0 and ops.is_static(x)))
         return x

@@ -348,10 +348,14 @@ def linear_split_ok(x2d, weight):
 
 
 class _PlaneCache(object):
-    """Operand planes (ctgcn_split_rows_f32) of tensors that do not change between forwards: the weights of an inference run and the node
-    features the reference builds once and feeds to every batch (train.py:72-76 -> embedding.py:318).  Keyed by storage address + shape +
-    strides, validated by identity (weak reference) and by the tensor's version counter (an in-place update — optimizer.step() — re-splits).
-    Entries die with their tensor; at most `limit` bytes are kept (least recently used first out)."""
+    """Operand planes (ctgcn_split_rows_f32 / ctgcn_pack_weight_f32) of tensors that do not change between forwards: the weights of an
+    inference run and node features the caller has marked static (mark_static: the reference builds them once and feeds them to every
+    batch, train.py:72-76 -> embedding.py:318).  Keyed by storage address + shape + strides + kind, validated by identity (weak
+    reference) and by the tensor's version counter: an in-place update — optimizer.step(), load_state_dict(), p.copy_() — re-splits.
+    What the version counter does NOT see: writes through `.data` / raw pointers (p.data.mul_(2), dist.broadcast(p.data)).  After such
+    an edit call ops.invalidate_plane_cache() (snapshot_parallel.shard_cgcn does).  Tensors created under torch.inference_mode() have no
+    version counter: they are split on every call and never cached.  Entries die with their tensor; at most `limit` bytes are kept
+    (least recently used first out)."""
 
     def __init__(self, limit=48 << 30):
         import collections
@@ -362,22 +366,26 @@ class _PlaneCache(object):
         if e is not None:
             self.bytes -= e[3]
 
-    def planes(self, t, lib):
+    def clear(self):
+        self.entries.clear()
+        self.bytes = 0
+
+    def get(self, t, kind, make):
+        """make() -> (buffer, nbytes): the operand form `kind` of tensor t, built on the current stream"""
         import weakref
-        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device))
+        if t.is_inference():                     # no version counter to validate against (t._version raises): never cached
+            return make()[0]
+        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device), kind)
         e = self.entries.get(key)
         cur = torch.cuda.current_stream(t.device)
         if e is not None and e[0]() is t and e[1] == t._version:
             self.entries.move_to_end(key)
-            if e[5] != cur:                      # split on another stream: order behind it, keep the buffer alive for this stream too
+            if e[5] != cur:                      # built on another stream: order behind it, keep the buffer alive for this stream too
                 cur.wait_event(e[4])
                 e[2].record_stream(cur)
             return e[2]
         self._drop(key)
-        rows, k = t.shape
-        nbytes = int(lib.ctgcn_split_planes_bytes(rows, k))
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
-        check(lib.ctgcn_split_rows_f32(rows, k, ptr(t), t.stride(0), ptr(buf), nbytes, _stream()), "ctgcn_split_rows_f32")
+        buf, nbytes = make()
         ev = torch.cuda.Event()
         ev.record(cur)
         self.entries[key] = (weakref.ref(t, lambda _r, key=key: self._drop(key)), t._version, buf, nbytes, ev, cur)
@@ -386,106 +394,47 @@ class _PlaneCache(object):
             self._drop(next(iter(self.entries)))
         return buf
 
+    def planes(self, t, lib):
+        """row-major fp16 planes + row scales of t [rows, k] (the A operand form of the split GEMM)"""
+        def make():
+            rows, k = t.shape
+            nbytes = int(lib.ctgcn_split_planes_bytes(rows, k))
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+            check(lib.ctgcn_split_rows_f32(rows, k, ptr(t), t.stride(0), ptr(buf), nbytes, _stream()), "ctgcn_split_rows_f32")
+            return buf, nbytes
+        return self.get(t, "planes", make)
 
-    def planes_k3(self, t, lib, weight):
-        """the k3 operand form (ctgcn_split_rows_k3_f32) of a tensor that does not change between forwards -> (fp16 [rows, 3 kp], scales,
-        scalar scale or None).  weight: one scale for the whole tensor (host read of max|w| once per weight version)."""
-        import weakref
-        key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device), "k3w" if weight else "k3x")
-        e = self.entries.get(key)
-        cur = torch.cuda.current_stream(t.device)
-        if e is not None and e[0]() is t and e[1] == t._version:
-            self.entries.move_to_end(key)
-            if e[5] != cur:
-                cur.wait_event(e[4])
-                e[2][0].record_stream(cur)
-                e[2][1].record_stream(cur)
-            return e[2]
-        self._drop(key)
-        val = split_rows_k3(t.detach(), lib, weight=weight)
-        nbytes = val[0].numel() * 2 + val[1].numel() * 4
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        self.entries[key] = (weakref.ref(t, lambda _r, key=key: self._drop(key)), t._version, val, nbytes, ev, cur)
-        self.bytes += nbytes
-        while self.bytes > self.limit and len(self.entries) > 1:
-            self._drop(next(iter(self.entries)))
-        return val
+    def packed(self, t, lib):
+        """packed W operand of the weight t [n_out, k] (ctgcn_pack_weight_f32: the split in matrix-core fragment order + column scales)"""
+        def make():
+            n_out, k = t.shape
+            nbytes = int(lib.ctgcn_pack_weight_bytes(n_out, k))
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+            check(lib.ctgcn_pack_weight_f32(n_out, k, ptr(t), t.stride(0), ptr(buf), nbytes, _stream()), "ctgcn_pack_weight_f32")
+            return buf, nbytes
+        return self.get(t, "packed", make)
 
 
 _plane_cache = _PlaneCache()
 
 
-def gemm_library_enabled():
-    """CTGCN_GEMM=lib hands the fp16 x 2 planes of the MLP's dense Linear layers to the library's fp16 GEMM as ONE product over 3 kp
-    (ctgcn_split_rows_k3_f32).  Measured (profiles/r04_library_gemm_k3.txt): the GEMMs alone run 1.3 - 1.7 x faster than gemm_h2_kernel
-    (0.32 - 0.39 of the fp16 x 2 bound against 0.18 - 0.23), the Facebook-like window gains 4 % (the raw accumulators cost an fp32 round
-    trip and the k3 planes half as many bytes again) — and hipBLASLt's results are not bit-identical from run to run there (bench.py's
-    single-stream / multi-stream equality check fails one time in two).  Default: the hand-written, deterministic gemm_h2_kernel."""
-    import os
-    return os.environ.get("CTGCN_GEMM", "hand") == "lib" and not torch.cuda.is_current_stream_capturing()
+def invalidate_plane_cache():
+    """Forget every cached operand plane.  Needed after weights or static features were edited behind the version counter's back
+    (writes through `.data`, raw pointers, collectives on `.data`)."""
+    _plane_cache.clear()
 
 
-def _h2_scale_host(m):
-    """the power of two s with m / s in [2^14, 2^15) — h2_scale of the kernels, on the host"""
-    import struct
-    e = (struct.unpack("<I", struct.pack("<f", float(m)))[0] >> 23) & 0xff
-    e = min(max(e, 15), 253)
-    return struct.unpack("<f", struct.pack("<I", (e - 14) << 23))[0]
+def mark_static(x):
+    """Declare that the feature tensor x is fed to every forward unchanged (what the reference's loader output is: built once in
+    train.py:72-76, passed to every batch, embedding.py:318): the first dense Linear keeps x's operand planes between forwards instead of
+    splitting x on every call.  ctgcn_amd.helper.DataLoader marks what it returns; in-place edits through the autograd-visible API
+    re-split (version counter), edits through `.data` need invalidate_plane_cache().  Returns x."""
+    x._ctgcn_static = True
+    return x
 
 
-def split_rows_k3(x2d, lib, weight=False, acc_scale=None, acc_col_scale=1.0, acc_bias=None, selu=False):
-    """ctgcn_split_rows_k3_f32 -> (planes fp16 [rows, 3 kp], scale fp32 [rows] (weight: [1]), host scalar scale (weight) or None).
-    acc_scale: x2d is the raw accumulator of the layer before; the split reads act(x2d acc_scale[r] acc_col_scale + acc_bias[c])."""
-    rows, k = x2d.shape
-    kp = -(-k // 64) * 64
-    nbytes = int(lib.ctgcn_k3_planes_bytes(rows, k))
-    buf = torch.empty(nbytes // 2, dtype=torch.float16, device=x2d.device)
-    fixed, host_scale = 0.0, None
-    if weight:
-        fixed = float(x2d.abs().max())                    # host read: once per weight version (the planes are cached)
-        fixed = fixed if fixed > 0.0 else 1.0
-        host_scale = _h2_scale_host(fixed)
-    scale = torch.empty(1 if weight else rows, dtype=torch.float32, device=x2d.device)
-    with _timed("linear_aux", rows=rows, k=k, split=True):
-        check(lib.ctgcn_split_rows_k3_f32(rows, k, ptr(x2d), x2d.stride(0), ptr(acc_scale), float(acc_col_scale), ptr(acc_bias),
-                                          _lib.ACT_SELU if (selu and acc_scale is not None) else _lib.ACT_NONE, fixed, 1 if weight else 0,
-                                          ptr(buf), nbytes, ptr(scale), _stream()), "ctgcn_split_rows_k3_f32")
-    return buf[:rows * 3 * kp].view(rows, 3 * kp), scale, host_scale
-
-
-def linear_k3_ok(x2d, weight):
-    return (gemm_library_enabled() and plane_cache_enabled() and weight.shape[0] % 4 == 0 and x2d.shape[0] * (x2d.shape[1] + 64) * 6 <= _LINEAR_WS_MAX)
-
-
-def mlp_k3(x2d, layers, selu, static_x=False, out=None):
-    """selu?(Linear_n(... selu?(Linear_1(x)))) — MLP.forward (layers.py:95-106) on dense features (or one nn.Linear), inference: per layer
-    ONE library fp16 GEMM over the k3 planes (fp32 accumulators out); a layer's scales, bias and activation are applied by the next layer's
-    split (its prologue) or, for the last layer, by ctgcn_scale_bias_act_f32."""
-    lib = _lib.load()
-    rows = x2d.shape[0]
-    with torch.cuda.device(x2d.device):
-        if static_x and not x2d.requires_grad:
-            xp, xs, _ = _plane_cache.planes_k3(x2d, lib, False)
-        else:
-            xp, xs, _ = split_rows_k3(x2d, lib)
-        acc = None
-        for i, lin in enumerate(layers):
-            wp, _, wscale = _plane_cache.planes_k3(lin.weight, lib, True)
-            n_out, k = lin.weight.shape
-            with _timed("linear_split", rows=rows, k=k, n_out=n_out, planes=True, library=True):
-                acc = torch.mm(xp, wp.t(), out_dtype=torch.float32)
-            b = None if lin.bias is None else lin.bias.detach()
-            if i + 1 < len(layers):
-                xp, xs_next, _ = split_rows_k3(acc, lib, acc_scale=xs, acc_col_scale=wscale, acc_bias=b, selu=selu)
-                xs = xs_next
-            else:
-                if out is None:
-                    out = torch.empty(rows, n_out, dtype=torch.float32, device=x2d.device)
-                with _timed("linear_aux", rows=rows, k=n_out, split=False):
-                    check(lib.ctgcn_scale_bias_act_f32(rows, n_out, ptr(acc), acc.stride(0), ptr(xs), float(wscale), ptr(b),
-                                                       _lib.ACT_SELU if selu else _lib.ACT_NONE, ptr(out), out.stride(0), _stream()), "ctgcn_scale_bias_act_f32")
-    return out
+def is_static(x):
+    return bool(getattr(x, "_ctgcn_static", False))
 
 
 def plane_cache_enabled():
@@ -495,10 +444,10 @@ def plane_cache_enabled():
 
 
 def linear_split(x2d, weight, bias, out=None, selu=False, static_x=False):
-    """out[rows, n_out] = x2d @ weight^T + bias in fp32-accurate fp16x2 split arithmetic on the matrix cores (ctgcn_linear_f32);
+    """out[rows, n_out] = x2d @ weight^T + bias in fp32-accurate fp16x2 split arithmetic on the matrix cores (gemm_h2_panel_kernel);
     selu: F.selu applied in the GEMM's epilogue (one pass over the output less).
-    The weight's operand planes are split once per weight version (_PlaneCache); static_x: x2d is a tensor the caller feeds to every
-    forward unchanged (the model's input features): its planes are kept too."""
+    The weight's packed operand is built once per weight version (_PlaneCache); static_x: x2d is a tensor the caller feeds to every
+    forward unchanged (mark_static): its planes are kept too."""
     lib = _lib.load()
     rows, k = x2d.shape
     n_out = weight.shape[0]
@@ -508,24 +457,19 @@ def linear_split(x2d, weight, bias, out=None, selu=False, static_x=False):
     chunk = max(128, (_LINEAR_WS_MAX // (kp * 4 + 4)) // 128 * 128)
     b = None if bias is None else bias.detach().contiguous()
     w = weight.detach()
-    if linear_k3_ok(x2d, weight) and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0)):
-        class _L(object):
-            pass
-        lin = _L()
-        lin.weight, lin.bias = weight, bias
-        return mlp_k3(x2d, [lin], selu, static_x=static_x, out=out)
+    act = _lib.ACT_SELU if selu else _lib.ACT_NONE
     if rows <= chunk and plane_cache_enabled():
         with torch.cuda.device(x2d.device):
-            wp = _plane_cache.planes(weight, lib)
+            wp = _plane_cache.packed(weight, lib)
             if static_x and not x2d.requires_grad:
                 xp = _plane_cache.planes(x2d, lib)
             else:
                 nbytes = int(lib.ctgcn_split_planes_bytes(rows, k))
                 xp = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
-                check(lib.ctgcn_split_rows_f32(rows, k, ptr(x2d), x2d.stride(0), ptr(xp), nbytes, _stream()), "ctgcn_split_rows_f32")
+                with _timed("linear_aux", rows=rows, k=k, split=True):
+                    check(lib.ctgcn_split_rows_f32(rows, k, ptr(x2d), x2d.stride(0), ptr(xp), nbytes, _stream()), "ctgcn_split_rows_f32")
             with _timed("linear_split", rows=rows, k=k, n_out=n_out, planes=True):
-                check(lib.ctgcn_linear_planes_f32(rows, n_out, k, ptr(xp), 1, ptr(wp), ptr(b), _lib.ACT_SELU if selu else _lib.ACT_NONE, ptr(out),
-                                                  out.stride(0), None, 0, _stream()), "ctgcn_linear_planes_f32")
+                check(lib.ctgcn_linear_packed_f32(rows, n_out, k, ptr(xp), ptr(wp), ptr(b), act, ptr(out), out.stride(0), _stream()), "ctgcn_linear_packed_f32")
         return out
     with torch.cuda.device(x2d.device):
         ws_bytes = int(lib.ctgcn_linear_workspace_bytes(min(rows, chunk), n_out, k))
@@ -534,67 +478,8 @@ def linear_split(x2d, weight, bias, out=None, selu=False, static_x=False):
             n = min(chunk, rows - lo)
             xs, ys = x2d[lo:lo + n], out[lo:lo + n]
             with _timed("linear_split", rows=n, k=k, n_out=n_out):
-                check(lib.ctgcn_linear_f32(n, n_out, k, ptr(xs), xs.stride(0), ptr(w), w.stride(0), ptr(b), _lib.ACT_SELU if selu else _lib.ACT_NONE,
+                check(lib.ctgcn_linear_f32(n, n_out, k, ptr(xs), xs.stride(0), ptr(w), w.stride(0), ptr(b), act,
                                            ptr(ys), ys.stride(0), ptr(ws), ws_bytes, _stream()), "ctgcn_linear_f32")
-    return out
-
-
-def mlp_chain_ok(x2d, layers):
-    """A stack of nn.Linear layers (layers.py:95-106) as one chain of split GEMMs whose epilogues write the next layer's operand planes."""
-    # default OFF: measured on the Facebook-like window (profiles/r04_mlp_chain_ab.txt) the chain is SLOWER than layer-by-layer with cached
-    # planes (30.5 vs 26.7 ms): the 500-wide layers are 16 k steps long, and the planes epilogue (tile through LDS in two halves) + the
-    # accumulator rescales cost more than the two split passes they remove.  CTGCN_MLP_CHAIN=1 runs it (tests/test_gpu_gemm.py does).
-    if len(layers) < 2 or not plane_cache_enabled() or os_environ_get("CTGCN_MLP_CHAIN", "0") != "1":
-        return False
-    if x2d.dim() != 2 or x2d.shape[0] * (-(-x2d.shape[1] // 64) * 64 * 4 + 4) > _LINEAR_WS_MAX:
-        return False
-    width = x2d.shape[1]
-    probe = x2d
-    for lin in layers:
-        if lin.weight.shape[1] != width or not linear_split_ok(probe, lin.weight) or lin.weight.shape[0] < 32:
-            return False
-        width = lin.weight.shape[0]
-        probe = torch.empty(1, width, dtype=torch.float32, device=x2d.device)
-    return True
-
-
-def os_environ_get(k, d):
-    import os
-    return os.environ.get(k, d)
-
-
-def mlp_chain_split(x2d, layers, selu, static_x=False):
-    """selu?(Linear_n(... selu?(Linear_1(x)))) — MLP.forward (layers.py:95-106) on dense features, inference: every layer is
-    ctgcn_linear_planes_f32; all but the last write fp16 operand planes + per-(row, 128-column) scales for the next one instead of fp32
-    activations (no split pass, no fp32 round trip between the layers).  The last layer's output is fp32."""
-    lib = _lib.load()
-    rows, k = x2d.shape
-    act = _lib.ACT_SELU if selu else _lib.ACT_NONE
-    with torch.cuda.device(x2d.device):
-        if static_x and not x2d.requires_grad:
-            xp = _plane_cache.planes(x2d, lib)
-        else:
-            nbytes = int(lib.ctgcn_split_planes_bytes(rows, k))
-            xp = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
-            check(lib.ctgcn_split_rows_f32(rows, k, ptr(x2d), x2d.stride(0), ptr(xp), nbytes, _stream()), "ctgcn_split_rows_f32")
-        blocks = 1
-        out = None
-        for i, lin in enumerate(layers):
-            n_out = lin.weight.shape[0]
-            wp = _plane_cache.planes(lin.weight, lib)
-            b = None if lin.bias is None else lin.bias.detach().contiguous()
-            last = i == len(layers) - 1
-            with _timed("linear_split", rows=rows, k=k, n_out=n_out, planes=True, chain=True):
-                if last:
-                    out = torch.empty(rows, n_out, dtype=torch.float32, device=x2d.device)
-                    check(lib.ctgcn_linear_planes_f32(rows, n_out, k, ptr(xp), blocks, ptr(wp), ptr(b), act, ptr(out), n_out, None, 0, _stream()),
-                          "ctgcn_linear_planes_f32")
-                else:
-                    ybytes = int(lib.ctgcn_chain_planes_bytes(rows, n_out))
-                    yp = torch.empty(ybytes, dtype=torch.uint8, device=x2d.device)
-                    check(lib.ctgcn_linear_planes_f32(rows, n_out, k, ptr(xp), blocks, ptr(wp), ptr(b), act, None, 0, ptr(yp), ybytes, _stream()),
-                          "ctgcn_linear_planes_f32")
-                    xp, k, blocks = yp, n_out, -(-n_out // 128)
     return out
 
 
@@ -813,10 +698,10 @@ def core_diffusion_split(x, adj, rnn, norm, out=None):
         ws, ws_bytes = aggregate_split_planes(x, adj, n_out, plan)
         gi_buf = torch.empty(rows * n_out, dtype=torch.float32, device=x.device) if plan is not None else _gi_buffer(n, K, hid, x.device)
         with _timed("linear_split", rows=rows, k=d, n_out=n_out, presplit=True):
-            if plane_cache_enabled():          # W_ih's planes: split once per weight version, not per call
-                wp = _plane_cache.planes(rnn.weight_ih_l0, lib)
-                check(lib.ctgcn_linear_planes_f32(rows, n_out, d, ptr(ws), 1, ptr(wp), ptr(bias), _lib.ACT_NONE, ptr(gi_buf), n_out, None, 0, _stream()),
-                      "ctgcn_linear_planes_f32")
+            if plane_cache_enabled():          # W_ih's packed operand: built once per weight version, not per call
+                wp = _plane_cache.packed(rnn.weight_ih_l0, lib)
+                check(lib.ctgcn_linear_packed_f32(rows, n_out, d, ptr(ws), ptr(wp), ptr(bias), _lib.ACT_NONE, ptr(gi_buf), n_out, _stream()),
+                      "ctgcn_linear_packed_f32")
             else:
                 check(lib.ctgcn_linear_presplit_f32(rows, n_out, d, ptr(w_ih), w_ih.stride(0), ptr(bias), ptr(gi_buf), n_out, ptr(ws), ws_bytes,
                                                     _stream()), "ctgcn_linear_presplit_f32")

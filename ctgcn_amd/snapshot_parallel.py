@@ -367,8 +367,12 @@ def shard_cgcn(model, num_snapshots, costs=None, assignment=None, group=None):
     if assignment is None:
         assignment = plan_assignment([1.0] * num_snapshots if costs is None else costs, world)
     model.process_group, model.shard_assignment = group, [list(a) for a in assignment]
-    for p in model.parameters():                       # replicas must start identical
-        dist.broadcast(p.data, src=dist.get_global_rank(group, 0) if group is not dist.group.WORLD else 0, group=group)
+    src = dist.get_global_rank(group, 0) if group is not dist.group.WORLD else 0
+    with torch.no_grad():                              # replicas must start identical; the parameter itself (not .data): an in-place
+        for p in model.parameters():                   # write the version counter sees, so cached operand planes of a weight re-split
+            dist.broadcast(p, src=src, group=group)
+    from . import ops
+    ops.invalidate_plane_cache()
     return model.shard_assignment
 
 

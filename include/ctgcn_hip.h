@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 24
+#define CTGCN_ABI_VERSION 25
 
 enum {
     CTGCN_OK = 0,
@@ -348,50 +348,35 @@ int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hid
 /*
  * Dense  y[rows, n_out] = x[rows, k]·w[n_out, k]^T + bias  (bias [n_out] may be NULL) in fp32-accurate fp16x2 split arithmetic on the
  * matrix cores (CTGCN_SPLIT_F16X2: operand rows scaled by a power of two and written as two fp16 terms, three
- * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation) - the GRU input projection for d_in != 128 (layers.py:59 with
+ * v_mfma_f32_16x16x32_f16 per product, fp32 accumulation) - the GRU input projection for d_in != 128 (layers.py:59 with
  * input_size = hid_dim = 500) and nn.Linear on dense inputs (layers.py:95-106), which otherwise run as fp32 library GEMMs.
  * ldx / ldw / ldy: row strides in floats.  Any k >= 1 (rows that are only 4-byte aligned, e.g. k = 1737, are read with the same 16-byte
- * loads).  activation: CTGCN_ACT_NONE, or CTGCN_ACT_SELU applied to y in the epilogue (the F.selu after each Linear of an 'N' MLP).
- * workspace: ctgcn_linear_workspace_bytes(rows, n_out, k) bytes, 256-byte aligned (the fp16 planes + row scales of x and w).
+ * loads), any n_out (more than 512 columns: one launch per 512).  activation: CTGCN_ACT_NONE, or CTGCN_ACT_SELU applied to y in the
+ * epilogue (the F.selu after each Linear of an 'N' MLP).
+ * workspace: ctgcn_linear_workspace_bytes(rows, n_out, k) bytes, 256-byte aligned: ctgcn_split_planes_bytes(rows, k) bytes of x's operand
+ * planes followed by ctgcn_pack_weight_bytes(n_out, k) bytes of w's packed operand.
  */
 size_t ctgcn_linear_workspace_bytes(int64_t rows, int32_t n_out, int32_t k);
 /*
- * The same product with the operands' planes kept by the caller (round 4): an operand that does not change between calls — the weights of an
- * inference run, the node features x_list the reference builds once and feeds to every batch (train.py:72-76) — is split ONCE:
- *   ctgcn_split_rows_f32      rows x k fp32 (row stride ldx) -> `planes`: plane 1 | plane 2 | row scales, ctgcn_split_planes_bytes(rows, k)
- *                             bytes, 256-byte aligned (the layout of ctgcn_linear_f32's workspace halves)
- *   ctgcn_linear_planes_f32   y = x·w^T + bias (+ activation) from the planes of x [rows, k] and w [n_out, k]
+ * The same product with the operands kept by the caller: an operand that does not change between calls — the weights of an inference run,
+ * node features the reference builds once and feeds to every batch (train.py:72-76) — is prepared ONCE:
+ *   ctgcn_split_rows_f32      x side: rows x k fp32 (row stride ldx) -> `planes`: plane 1 [rows, kp] | plane 2 | row scales, kp = k rounded up
+ *                             to 64 (zero padded), ctgcn_split_planes_bytes(rows, k) bytes, 256-byte aligned
+ *   ctgcn_pack_weight_f32     w side (round 5): n_out x k fp32 (row stride ldw) -> `packed`: the same split stored in matrix-core fragment order
+ *                             ([column tile of 16][k slab of 32][plane][lane][8 halfs], column tiles padded to a multiple of 8 per chunk of 512
+ *                             columns) | column scales; ctgcn_pack_weight_bytes(n_out, k) bytes, 256-byte aligned
+ *   ctgcn_linear_packed_f32   y = x·w^T + bias (+ activation) from x's planes and w's packed operand (gemm_h2_panel_kernel: persistent blocks,
+ *                             each 128-row panel of x read once over the full width)
  * Same split, same kernel as ctgcn_linear_f32: bit-identical results.
- * Chained layers (layers.py:95-106: Linear -> SELU -> Linear ...): with y_planes instead of y the epilogue writes the NEXT layer's operand —
- * two fp16 planes [rows, kp(n_out)] and one power-of-two scale per (row, 128-column tile), ctgcn_chain_planes_bytes(rows, n_out) bytes — and the
- * next call takes them with x_scale_blocks = ceil(kp / 128) (1: one scale per row, ctgcn_split_rows_f32's layout): its accumulators are rescaled
- * exactly where the k block changes.  The fp32 activations between the layers and their split passes do not exist.
  */
 size_t ctgcn_split_planes_bytes(int64_t rows, int32_t k);
-size_t ctgcn_chain_planes_bytes(int64_t rows, int32_t n_out);
+size_t ctgcn_pack_weight_bytes(int32_t n_out, int32_t k);
 int ctgcn_split_rows_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, void *planes, size_t planes_bytes, void *stream);
-int ctgcn_linear_planes_f32(int64_t rows, int32_t n_out, int32_t k, const void *x_planes, int32_t x_scale_blocks, const void *w_planes,
-                            const float *bias, int32_t activation, float *y, int64_t ldy, void *y_planes, size_t y_planes_bytes, void *stream);
+int ctgcn_pack_weight_f32(int32_t n_out, int32_t k, const float *w, int64_t ldw, void *packed, size_t packed_bytes, void *stream);
+int ctgcn_linear_packed_f32(int64_t rows, int32_t n_out, int32_t k, const void *x_planes, const void *w_packed, const float *bias,
+                            int32_t activation, float *y, int64_t ldy, void *stream);
 int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
                      int32_t activation, float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
-
-/*
- * Operands for a LIBRARY fp16 GEMM with fp32 output (round 4; reference layers.py:95-106 nn.Linear stacks and the nn.GRU input projection of
- * layers.py:59 — north_star leaves the dense Linear to PyTorch-ROCm / hipBLASLt).  The three products of the fp16 x 2 split become ONE GEMM over
- * k' = 3 kp (kp = k rounded up to 64, zero padded):   x side [ hi | lo | hi ],  w side [ lo | hi | hi ]  ->  hi·lo + lo·hi + hi·hi.
- *   ctgcn_split_rows_k3_f32   rows x k fp32 -> `planes` [rows, 3 kp] fp16 (ctgcn_k3_planes_bytes, 256-byte aligned) + scale:
- *        fixed_max = 0: one power-of-two scale per row -> scale[rows];  fixed_max > 0 (weights): the whole tensor under the scale of that
- *        maximum -> scale[0], so that the product's column scale is a scalar.  weight_order != 0 writes the w side's order.
- *        in_row_scale != null: x is the RAW accumulator of a previous k3 GEMM and the split reads act(x in_row_scale[r] in_col_scale + in_bias[c])
- *        (the layer's scales, bias and activation are applied where its output is consumed: no pass of their own).
- *   ctgcn_scale_bias_act_f32  y = act(acc row_scale[r] col_scale + bias[c]) for a consumer that wants plain fp32 rows (n % 4 == 0).
- */
-size_t ctgcn_k3_planes_bytes(int64_t rows, int32_t k);
-int ctgcn_split_rows_k3_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, const float *in_row_scale, float in_col_scale,
-                            const float *in_bias, int32_t activation, float fixed_max, int32_t weight_order, void *planes, size_t planes_bytes,
-                            float *scale, void *stream);
-int ctgcn_scale_bias_act_f32(int64_t rows, int32_t n, const float *acc, int64_t ld_acc, const float *row_scale, float col_scale, const float *bias,
-                             int32_t activation, float *y, int64_t ldy, void *stream);
 
 /*
  * CoreDiffusion aggregation (ctgcn_core_aggregate_f32: layers.py:41-48,58) whose only consumer is the GRU input projection of a

@@ -21,6 +21,9 @@ def coo_like_reference(csr):
     return torch.sparse_coo_tensor(idx, torch.from_numpy(coo.data).float(), torch.Size(coo.shape))
 
 
+_tap = None      # tests: a list that receives, per aggregate_loop call, {"pre": [K detached pre-ReLU tensors]} (cdn_rows adds "rows")
+
+
 def aggregate_loop(adj_list, x):
     """layers.py:41-48: the K-step cumulative torch.sparse.mm loop + ReLU. Returns list of K [N,d]."""
     acc, out = None, []
@@ -28,6 +31,8 @@ def aggregate_loop(adj_list, x):
         y = torch.sparse.mm(a, x)
         acc = y if acc is None else acc + y
         out.append(acc)
+    if _tap is not None:
+        _tap.append({"pre": [v.detach() for v in out]})
     return [F.relu(v) for v in out]
 
 
@@ -157,3 +162,72 @@ def ctgcn(sd, x_list, adj_list, rnn_type="GRU", model_type="C", activate="L"):
     w, b = sd["norm.weight"], sd["norm.bias"]
     out = F.layer_norm(out, (w.shape[0],), w, b).transpose(0, 1)
     return out if model_type == "C" else (out, trans)
+
+
+# ----------------------------------------------------------------------------------- rows of the outputs
+# The reference path evaluated for a SUBSET of the nodes — for parity checks at sizes where the whole float64 forward + autograd
+# would take minutes (1 M nodes).  Nothing new is computed: rows R of torch.sparse.mm(A, x) are torch.sparse.mm(A[R, :], x), and
+# the GRU / LayerNorm behind it (layers.py:59-62) act on every row by itself, so rows R of a CoreDiffusion layer's output are
+# core_diffusion() called with the row-sliced matrices.  A stack of layers (models.py:39-42) needs the layer before it on the
+# columns those sliced matrices touch — worked out back to front, scattered into an otherwise-zero [N, d] operand front to back.
+# Autograd runs through all of it, so the gradient of a loss that only reads rows R (the reference's batch loss reads the batch's
+# nodes, their walk partners and the negatives: embedding.py:346-352, metrics.py:38-60) is the same as through the full forward.  Pinned against ctgcn() / ctgcn_with_grad() on whole
+# small graphs by tests/test_oracle_golden.py::test_row_subset_path_equals_the_full_path.
+# ReLU kinks: a pre-activation within rounding of zero has a derivative that depends on the arithmetic (0 or 1); `_tap` hands the tests the
+# float64 pre-activations so that they can keep such entries out of the loss (ambiguous_rows below) instead of widening tolerances.
+def ambiguous_rows(pre_list, rel=1e-5):
+    """bool [rows]: some pre-ReLU value of the row (any core, any feature) lies within rel x the row's largest |value| of zero"""
+    stack = torch.stack(pre_list, 1).abs()                              # [rows, K, d]
+    big = stack.reshape(stack.shape[0], -1).max(1).values.clamp_min(1.0)
+    return (stack.reshape(stack.shape[0], -1).min(1).values <= rel * big)
+
+
+def _rows_of(mats, rows, dtype):
+    """[A[rows, :] for A in mats] as the reference's COO tensors (utils.py:89-95); mats: scipy matrices"""
+    import scipy.sparse as sp
+    return [coo_like_reference(sp.csr_matrix(m)[rows]).to(dtype) for m in mats]
+
+
+def _columns_of(mats, rows):
+    """sorted union of `rows` (the + I of the first matrix, helper.py:71-72) and every column the rows touch in any matrix"""
+    import scipy.sparse as sp
+    cols = [np.asarray(rows, dtype=np.int64)]
+    for m in mats:
+        cols.append(sp.csr_matrix(m)[rows].indices.astype(np.int64))
+    return np.unique(np.concatenate(cols))
+
+
+def cdn_rows(sd, prefix, x, mats, rows, rnn_type="GRU"):
+    """rows `rows` of cdn(sd, prefix, x, adj_list) (models.py:39-42); x: the full [N, d] input, mats: scipy k-core list"""
+    n_layers = 0
+    while (prefix + "diffusion_list.%d.norm.weight" % n_layers) in sd:
+        n_layers += 1
+    need = [np.asarray(rows, dtype=np.int64)]
+    for _ in range(n_layers - 1):
+        need.insert(0, _columns_of(mats, need[0]))
+    for l in range(n_layers):
+        y = core_diffusion(sd, prefix + "diffusion_list.%d." % l, x, _rows_of(mats, need[l], x.dtype), rnn_type)
+        if _tap is not None:
+            _tap[-1]["rows"] = need[l]
+        if l + 1 < n_layers:
+            x = torch.zeros(mats[0].shape[0], y.shape[1], dtype=y.dtype).index_put((torch.from_numpy(need[l]),), y)
+    return y
+
+
+def ctgcn_rows(sd, x_list, mats_list, rows, rnn_type="GRU", model_type="C", activate="L", with_grad=False):
+    """ctgcn(...)[:, rows] (models.py:240-253) -> [T, len(rows), d]; mats_list: per snapshot the scipy k-core list"""
+    global _rnn
+    saved = _rnn
+    if with_grad:
+        _rnn = _rnn_grad
+    try:
+        hx = []
+        for t in range(len(x_list)):
+            tr = mlp(sd, "mlp_list.%d." % t, x_list[t], activate)
+            hx.append(cdn_rows(sd, "duffision_list.%d." % t, tr, mats_list[t], rows, rnn_type))
+        seq = torch.stack(hx).transpose(0, 1)
+        out = _rnn(sd, "rnn.", rnn_type, seq)
+        w, b = sd["norm.weight"], sd["norm.bias"]
+        return F.layer_norm(out, (w.shape[0],), w, b).transpose(0, 1)
+    finally:
+        _rnn = saved

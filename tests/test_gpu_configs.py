@@ -169,7 +169,7 @@ def config5():
         a = sp.coo_matrix((np.ones(2 * len(uu)), (np.concatenate([uu, vv]), np.concatenate([vv, uu]))), shape=(n, n)).tocsr()
         a.sort_indices()
         graphs.append(a)
-    adj, ref_adj = [], []
+    adj, ref_adj, mats = [], [], []
     for g in graphs:
         core = O.core_numbers(g)
         a, core_dev, _ = core_adj_from_scipy(g, K, DEV)
@@ -178,6 +178,7 @@ def config5():
         ref = O.core_adj_list([O.kcore_matrices(g, capped)], 0, 1, 1, max_core=K)[0]      # levels above max_core are never told apart (helper.py:63)
         assert a.nnz_per_slot == [m.nnz for m in ref] and len(a) == len(ref)
         adj.append(a)
+        mats.append(ref)
         ref_adj.append([TP.coo_like_reference(m) for m in ref])
     idx = torch.arange(n).repeat(2, 1)
     xs = [torch.sparse_coo_tensor(idx, torch.ones(n), (n, n)) for _ in graphs]
@@ -186,7 +187,7 @@ def config5():
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(DEV)
     want, want64, t32, t64 = _oracle_fp32_and_fp64(sd, xs, ref_adj)
-    return dict(model=model, adj=adj, xs=[x.to(DEV) for x in xs], want=want.numpy(), want64=want64.numpy(),
+    return dict(model=model, adj=adj, xs=[x.to(DEV) for x in xs], want=want.numpy(), want64=want64.numpy(), mats=mats, graphs=graphs, sd=sd,
                 times=dict(oracle_fp32_s=t32, oracle_fp64_s=t64), K=[len(a) for a in adj], nnz=[a.nnz for a in adj])
 
 
@@ -222,3 +223,205 @@ def test_config5_full_size_matches_cpu_oracle(config5, path):
     got = got.cpu().numpy()
     assert got.shape == c["want"].shape == (2, C5["n"], 128) and np.isfinite(got).all()
     _compare("config5_full_" + path, got, c["want"], c["want64"], extra)
+
+
+# ------------------------------------------------------------------ training at full size
+def _sample_rows(graph, n_random, n_hubs, n_isolated, seed):
+    """sorted node sample: random rows + the highest-degree rows (hub-row kernels, long gathers) + rows without any entry
+    (core number 0: under the row plan every step of such a row repeats x — first tag f = K)"""
+    deg = np.diff(graph.indptr)
+    rng = np.random.default_rng(seed)
+    picks = [rng.choice(graph.shape[0], n_random, replace=False), np.argsort(-deg, kind="stable")[:n_hubs]]
+    iso = np.flatnonzero(deg == 0)
+    if n_isolated and len(iso):
+        picks.append(rng.choice(iso, min(n_isolated, len(iso)), replace=False))
+    return np.unique(np.concatenate(picks)), deg
+
+
+def _rel_max(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+def test_config5_training_layer_gradients_at_full_size(config5):
+    """(a) ONE CoreDiffusion(128, 128) on snapshot 15 of the config-5 window — 1 M rows, K = 8, 17 M entries, row plan on, the backward in
+    four row chunks at the shipped _GI_MAX_ELEMS — forward + backward through ops._CoreDiffusionFused against float64 autograd of the
+    reference's path (layers.py:38-63 via oracle/torch_path.py).  The loss reads 131 072 random rows + the 256 highest-degree rows + 4 096
+    rows without entries (the reference's batch loss reads a node subset too, embedding.py:346-352); the float64 side evaluates exactly
+    those rows (TP.core_diffusion on row-sliced matrices, pinned by tests/test_oracle_golden.py::test_row_subset_path_equals_the_full_path).
+    Rows with a pre-ReLU value within 1e-5 (relative) of zero are kept out of the loss (their G is zero): there the derivative of ReLU is
+    decided by the last bit of the sum — found with this very test: one such entry moved 47 neighbours' dX by 2.7e-2 with every dH
+    correct to 5e-6 (tools/diag_c5_layer2.py).  Compared IN FULL: all seven parameter gradients, and dX on all 1 M rows (rows the loss
+    does not reach must come out exactly zero, so garbage from any row of any chunk would show).  Tolerances: gradients 1e-4 of each
+    tensor's largest entry (tests/test_gpu_train_fused.py); forward rows: this module's rule against the fp32 CPU path on the same rows
+    (x is unit normal here: hub rows sum ~1 900 of them, |H| up to 1e3 — the fp32 CPU path itself is 1.1e-4 from float64 there)."""
+    from ctgcn_amd import ops
+    from ctgcn_amd.layers import CoreDiffusion
+    from oracle import torch_path as TP
+    n = C5["n"]
+    adj, mats, graph = config5["adj"][1], config5["mats"][1], config5["graphs"][1]
+    rows, deg = _sample_rows(graph, 131072, 256, 4096, seed=11)
+    assert deg[rows].max() == deg.max() and (deg[rows] == 0).sum() >= 1000
+    torch.manual_seed(5)
+    layer = CoreDiffusion(128, 128)
+    with torch.no_grad():
+        layer.norm.weight.uniform_(0.5, 1.5)
+        layer.norm.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(n, 128)
+    Gs = torch.randn(len(rows), 128)
+    # float64 truth on the sampled rows (and the fp32 CPU path's forward on the same rows)
+    t0 = time.time()
+    sd = {"l." + k: v.detach().double().clone().requires_grad_(True) for k, v in layer.state_dict().items() if not k.startswith("linear.")}
+    xd = x.detach().clone().double().requires_grad_(True)
+    saved, TP._tap = TP._rnn, []
+    TP._rnn = TP._rnn_grad
+    try:
+        want_out = TP.core_diffusion(sd, "l.", xd, TP._rows_of(mats, rows, torch.float64))
+        kink = TP.ambiguous_rows(TP._tap[0]["pre"])
+    finally:
+        TP._rnn, TP._tap = saved, None
+    Gs[kink] = 0.0
+    (want_out * Gs.double()).sum().backward()
+    with torch.no_grad():
+        want32 = TP.core_diffusion({"l." + k: v.detach() for k, v in layer.state_dict().items()}, "l.", x, TP._rows_of(mats, rows, torch.float32))
+    t_truth = time.time() - t0
+    # the HIP path on all rows
+    layer = layer.to(DEV)
+    xg = x.detach().clone().to(DEV).requires_grad_(True)
+    assert ops.core_diffusion_fused_ok(layer.rnn, layer.norm, xg, adj) and adj.row_plan() is not None
+    assert len(ops._row_chunks(ops._lib.load(), n, adj.K, 128)) >= 2                  # the backward really runs in row chunks here
+    sel = torch.from_numpy(rows).to(DEV)
+    G = torch.zeros(n, 128, device=DEV)
+    G[sel] = Gs.to(DEV)
+    out = layer(xg, adj)
+    (out * G).sum().backward()
+    assert torch.isfinite(out).all()
+    obs = _compare("config5_training_layer_forward_rows", out.detach()[sel].cpu().numpy(), want32.numpy(), want_out.detach().numpy(),
+                   dict(rows=int(len(rows)), kink_rows=int(kink.sum())))
+    rel = {"x": _rel_max(xg.grad.cpu(), xd.grad)}
+    for k, p in layer.named_parameters():
+        if k.startswith("linear."):
+            assert p.grad is None
+            continue
+        assert torch.isfinite(p.grad).all(), k
+        rel[k] = _rel_max(p.grad.cpu(), sd["l." + k].grad)
+    untouched = (xd.grad.abs().sum(1) == 0)
+    stray = float(xg.grad.cpu()[untouched].abs().max()) if bool(untouched.any()) else 0.0
+    print("config5 layer gradients on %d rows (%d kept out of the loss: pre-ReLU value at a kink): gradient errors / largest entry %s; rows outside the "
+          "loss's reach: %d, largest |dX| there %.1e; float64 + fp32 sides %.1f s" % (len(rows), int(kink.sum()), {k: "%.1e" % v for k, v in rel.items()},
+                                                                                 int(untouched.sum()), stray, t_truth))
+    _record("config5_training_layer", forward_max_err_vs_fp64=obs["max_err_hip_vs_fp64"], forward_max_err_cpu_fp32_vs_fp64=obs["max_err_cpu_fp32_vs_fp64"],
+            rows=int(len(rows)), kink_rows=int(kink.sum()), truth_s=t_truth, stray_dx=stray, **{"rel_" + k: v for k, v in rel.items()})
+    assert int(kink.sum()) < 0.05 * len(rows)
+    assert stray == 0.0
+    assert len(rel) == 8 and max(rel.values()) < 1e-4, rel
+
+
+def test_config5_training_window_gradients_at_full_size(config5):
+    """(b) the 2-snapshot CTGCN-C of the fixture (1 M nodes, snapshots 3 and 15, two CoreDiffusion layers each) in training mode with
+    .backward() through the temporal GRU's backward kernels: loss = <out[:, rows], G>, rows = 8 192 random + the 16 highest-degree nodes
+    of snapshot 15.  float64 side: TP.ctgcn_rows(with_grad) — models.py:240-253 on those rows, layer 1 evaluated on the columns layer 2
+    touches (~170 000 rows on snapshot 15).  Sample rows whose value depends on a ReLU at a kink (their own layer-2 pre-activations, or
+    layer-1 pre-activations of a node they aggregate: within 1e-5 of zero) get G = 0 — see test (a).  Every parameter gradient is compared
+    in full — the one-hot MLP's weight gradient [128, 1 M] is the first layer's dX, transposed."""
+    from oracle import torch_path as TP
+    import scipy.sparse as sp
+    c = config5
+    model, n = c["model"], C5["n"]
+    rows, _ = _sample_rows(c["graphs"][1], 8192, 16, 0, seed=12)
+    torch.manual_seed(6)
+    G = torch.randn(2, len(rows), 128)
+    t0 = time.time()
+    sd64 = {k: v.double().clone().requires_grad_(True) for k, v in c["sd"].items()}
+    idx = torch.arange(n).repeat(2, 1)
+    xs64 = [torch.sparse_coo_tensor(idx, torch.ones(n, dtype=torch.float64), (n, n)) for _ in range(2)]
+    TP._tap = []
+    try:
+        want = TP.ctgcn_rows(sd64, xs64, c["mats"], rows, with_grad=True)
+        taps = TP._tap
+    finally:
+        TP._tap = None
+    assert len(taps) == 4                                  # (snapshot 0: layer 1, layer 2), (snapshot 1: layer 1, layer 2)
+    drop = torch.zeros(len(rows), dtype=torch.bool)
+    for t in range(2):
+        l1, l2 = taps[2 * t], taps[2 * t + 1]
+        assert np.array_equal(l2["rows"], rows)
+        drop |= TP.ambiguous_rows(l2["pre"])
+        bad1 = np.zeros(n)
+        bad1[l1["rows"][TP.ambiguous_rows(l1["pre"]).numpy()]] = 1.0
+        reach = sp.csr_matrix(c["mats"][t][-1])[rows]      # the largest matrix of the list (+ the row itself: the + I of the first)
+        drop |= torch.from_numpy((reach @ bad1 + bad1[rows]) > 0)
+    G[:, drop] = 0.0
+    (want * G.double()).sum().backward()
+    t_truth = time.time() - t0
+    model.train()
+    try:
+        model.zero_grad(set_to_none=True)
+        out = model(c["xs"], c["adj"])
+        assert out.requires_grad and out.shape == (2, n, 128)
+        sel = torch.from_numpy(rows).to(DEV)
+        (out[:, sel] * G.to(DEV)).sum().backward()
+        got = out.detach()[:, sel].cpu()
+        grads = {k: (None if p.grad is None else p.grad.detach().cpu()) for k, p in model.named_parameters()}
+    finally:
+        model.zero_grad(set_to_none=True)
+        model.eval()
+    d = (got.double() - want.detach()).abs()
+    tol = 1e-4 * want.detach().abs() + 1e-5
+    frac_out, err_out = float((d > tol).double().mean()), float(d.max())
+    rel = {}
+    for k, g in grads.items():
+        if ".diffusion_list." in k and ".linear." in k:          # CoreDiffusion.linear is unused (layers.py:24)
+            assert g is None or float(g.abs().max()) == 0.0
+            continue
+        assert g is not None and torch.isfinite(g).all(), k
+        rel[k] = _rel_max(g, sd64[k].grad)
+    worst = max(rel, key=rel.get)
+    print("config5 window gradients: forward max |err| %.2e, fraction outside rtol 1e-4 / atol 1e-5 %.1e on %d x 2 rows (%d kept out of the loss: "
+          "ReLU kinks); %d parameter gradients, worst %s %.1e; float64 side %.1f s" % (err_out, frac_out, len(rows), int(drop.sum()), len(rel), worst,
+                                                                                      rel[worst], t_truth))
+    _record("config5_training_window", forward_max_err=err_out, forward_frac_outside=frac_out, rows=int(len(rows)), kink_rows=int(drop.sum()),
+            truth_s=t_truth, worst_gradient=worst, **{"rel_" + k: v for k, v in rel.items()})
+    assert int(drop.sum()) < 0.5 * len(rows)
+    assert err_out < 2e-4 and frac_out < 1e-4
+    assert len(rel) == 2 * (2 + 2 * 6) + 6 and rel[worst] < 1e-4, rel
+
+
+def test_full_depth_window_matches_cpu_oracle_on_sampled_rows():
+    """(c) a T = 16 window at 200 000 nodes (config 5's generator and depth: cumulative snapshots, max_core 8, CTGCN-C 128 / 128, two
+    CoreDiffusion layers per snapshot) through the inference path — 16 grouped-or-single snapshot branches and the per-step temporal GRU
+    kernel at depth 16 — against the CPU oracle on 2 048 random rows + the 8 highest-degree nodes, in float32 (the reference's arithmetic)
+    and float64, under the module's rule (HIP no further from float64 than 1.5 x / 1.25 x the fp32 CPU path)."""
+    import ctgcn_amd
+    from ctgcn_amd.helper import core_adj_from_scipy
+    from ctgcn_amd.synth import window_graph
+    from oracle import oracle as O, torch_path as TP
+    n, T, K = 200_000, 16, 8
+    graphs = window_graph(n, 1_600_000, T, cumulative=True)
+    adj, mats = [], []
+    for g in graphs:
+        capped = np.minimum(O.core_numbers(g), K)
+        a, core_dev, _ = core_adj_from_scipy(g, K, DEV)
+        assert np.array_equal(core_dev.cpu().numpy(), capped)
+        ref = O.core_adj_list([O.kcore_matrices(g, capped)], 0, 1, 1, max_core=K)[0]
+        assert a.nnz_per_slot == [m.nnz for m in ref]
+        adj.append(a)
+        mats.append(ref)
+    rows, _ = _sample_rows(graphs[-1], 2048, 8, 0, seed=13)
+    idx = torch.arange(n).repeat(2, 1)
+    xs = [torch.sparse_coo_tensor(idx, torch.ones(n), (n, n)) for _ in range(T)]
+    torch.manual_seed(0)
+    model = ctgcn_amd.CTGCN(n, 128, 128, 1, 2, T).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(DEV)
+    with torch.no_grad():
+        got = model([x.to(DEV) for x in xs], adj)
+    assert got.shape == (T, n, 128) and torch.isfinite(got).all()
+    got = got[:, torch.from_numpy(rows).to(DEV)].cpu().numpy()
+    t0 = time.time()
+    with torch.no_grad():
+        want = TP.ctgcn_rows(sd, xs, mats, rows).numpy()
+        t32 = time.time() - t0
+        xs64 = [torch.sparse_coo_tensor(idx, torch.ones(n, dtype=torch.float64), (n, n)) for _ in range(T)]
+        want64 = TP.ctgcn_rows({k: v.double() for k, v in sd.items()}, xs64, mats, rows).numpy()
+    _compare("window_T16_n200k_sampled_rows", got, want, want64, dict(oracle_fp32_s=t32, oracle_fp64_s=time.time() - t0 - t32, rows=int(len(rows)),
+                                                                     K=[len(a) for a in adj]))

@@ -89,20 +89,19 @@ def test_rows_that_are_only_4_byte_aligned_and_selu_epilogue(rows, k, n_out):
 
 
 def test_operand_plane_cache_follows_the_tensors(monkeypatch):
-    """ops._PlaneCache: planes of the weights / static inputs are split once, an in-place update re-splits them, results equal the
-    uncached call bit for bit"""
-    import torch
+    """ops._PlaneCache: the packed operand of a weight and the planes of a static input are built once, an in-place update re-builds them,
+    results equal the uncached call bit for bit; writes through .data need ops.invalidate_plane_cache() (documented limit of the version
+    counter); tensors made under torch.inference_mode() are never cached"""
+    import gc
     from ctgcn_amd import ops
-    dev = "cuda:0"
     torch.manual_seed(3)
-    x = torch.randn(777, 1737, device=dev)
-    w = torch.nn.Parameter(torch.randn(500, 1737, device=dev) * 0.05)
-    b = torch.randn(500, device=dev)
-    monkeypatch.setenv("CTGCN_GEMM", "hand")                 # bit identity cached / uncached: the hand-written GEMM's planes
+    x = torch.randn(777, 1737, device=DEV)
+    w = torch.nn.Parameter(torch.randn(500, 1737, device=DEV) * 0.05)
+    b = torch.randn(500, device=DEV)
     monkeypatch.setenv("CTGCN_PLANE_CACHE", "0")
     ref = ops.linear_split(x, w, b, selu=True)
     monkeypatch.setenv("CTGCN_PLANE_CACHE", "1")
-    ops._plane_cache.entries.clear(); ops._plane_cache.bytes = 0
+    ops.invalidate_plane_cache()
     a1 = ops.linear_split(x, w, b, selu=True, static_x=True)
     assert len(ops._plane_cache.entries) == 2
     a2 = ops.linear_split(x, w, b, selu=True, static_x=True)
@@ -115,153 +114,79 @@ def test_operand_plane_cache_follows_the_tensors(monkeypatch):
     monkeypatch.setenv("CTGCN_PLANE_CACHE", "1")
     a3 = ops.linear_split(x, w, b, selu=True, static_x=True)
     assert torch.equal(a3, ref2) and not torch.equal(a3, ref)
+    w.data.mul_(0.5)                     # behind the version counter's back: stale until invalidated
+    assert torch.equal(ops.linear_split(x, w, b, selu=True, static_x=True), ref2)
+    ops.invalidate_plane_cache()
+    assert len(ops._plane_cache.entries) == 0
+    a4 = ops.linear_split(x, w, b, selu=True, static_x=True)
+    monkeypatch.setenv("CTGCN_PLANE_CACHE", "0")
+    assert torch.equal(a4, ops.linear_split(x, w, b, selu=True))
+    monkeypatch.setenv("CTGCN_PLANE_CACHE", "1")
     del x, w
-    import gc
     gc.collect()
     assert len(ops._plane_cache.entries) == 0        # entries die with their tensors
+    with torch.inference_mode():                     # no version counter: split per call, nothing cached, no exception
+        xi = torch.randn(300, 96, device=DEV)
+        wi = torch.randn(64, 96, device=DEV)
+        y1 = ops.linear_split(xi, wi, None, static_x=True)
+        y2 = ops.linear_split(xi, wi, None, static_x=True)
+    assert len(ops._plane_cache.entries) == 0 and torch.equal(y1, y2)
+    assert ((y1.double() - xi.double() @ wi.double().t()).abs().max() / (xi.double().abs() @ wi.double().abs().t()).max()).item() < 1e-6
 
 
-def test_mlp_chain_matches_float64(monkeypatch):
-    """ops.mlp_chain_split: three Linear + SELU layers with operand planes handed from epilogue to main loop (per-(row, 128-column) scales,
-    accumulators rescaled at the k-block boundaries) against float64, and against the layer-by-layer path"""
-    import torch
-    from ctgcn_amd.layers import MLP
-    dev = "cuda:0"
-    torch.manual_seed(5)
-    for rows, widths in ((1000, (1737, 500, 500, 128)), (333, (96, 200, 64)), (70, (64, 130, 500, 32))):
-        mlp = MLP(widths[0], widths[1], widths[-1], len(widths) - 1, activate_type='N')
-        # give the hidden widths of the test (MLP builds in -> hid ... hid -> out)
-        lins = [torch.nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:])]
-        mlp.linears = torch.nn.ModuleList(lins)
-        mlp.layer_num = len(lins)
-        x = torch.randn(rows, widths[0]) * torch.rand(rows, 1) * 10
-        want = x.double()
-        for lin in lins:
-            want = torch.nn.functional.selu(torch.nn.functional.linear(want, lin.weight.double(), lin.bias.double()))
-        mlp = mlp.to(dev).eval()
-        xg = x.to(dev)
-        monkeypatch.setenv("CTGCN_GEMM", "hand")        # the chain belongs to the hand-written GEMM
-        with torch.no_grad():
-            monkeypatch.setenv("CTGCN_MLP_CHAIN", "1")
-            got = mlp(xg)
-            monkeypatch.setenv("CTGCN_MLP_CHAIN", "0")
-            ref = mlp(xg)
-        scale = want.abs().max().item()
-        e_chain = (got.double().cpu() - want).abs().max().item() / scale
-        e_layer = (ref.double().cpu() - want).abs().max().item() / scale
-        assert e_chain < 2e-6, (widths, e_chain, e_layer)
-        assert e_chain < 4 * e_layer + 1e-7, (widths, e_chain, e_layer)
+def test_model_runs_under_inference_mode():
+    """a CTGCN-S built and run inside torch.inference_mode() (dense features through the MLP's split GEMMs, W_ih through the projection)"""
+    import ctgcn_amd
+    from ctgcn_amd.helper import core_adj_from_scipy
+    from ctgcn_amd.synth import dynamic_graph
+    graphs = dynamic_graph(1500, avg_deg=8, snapshots=2, seed=3)
+    adj = [core_adj_from_scipy(g, 4, DEV)[0] for g in graphs]
+    torch.manual_seed(1)
+    xs = [torch.randn(1500, 200) for _ in graphs]
+    model = ctgcn_amd.CTGCN(200, 96, 128, 2, 1, 2, model_type="S", trans_activate_type="N").to(DEV).eval()
+    with torch.no_grad():
+        want, _ = model([x.to(DEV) for x in xs], adj)
+    with torch.inference_mode():
+        got, _ = model([x.to(DEV) for x in xs], adj)
+    assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("rows,k,n_out", [(1000, 500, 384), (60_730, 500, 500), (5000, 1737, 500), (300, 1740, 128), (129, 128, 132)])
-def test_library_gemm_over_k3_planes_against_the_hand_kernel(rows, k, n_out, monkeypatch):
-    """The default dense path (ops.mlp_k3: ONE library fp16 GEMM over [hi | lo | hi] x [lo | hi | hi]^T, scales / bias in the finishing kernel)
-    and the hand-written split GEMM (CTGCN_GEMM=hand) against float64: same error class (fp16 x 2 operands, fp32 accumulation)."""
+def test_static_features_are_opt_in():
+    """only a tensor marked with ops.mark_static (what helper.DataLoader returns) gets its planes cached by the MLP"""
     from ctgcn_amd import ops
-    torch.manual_seed(rows + k + n_out)
-    x = torch.randn(rows, k, device=DEV) * torch.rand(rows, 1, device=DEV).mul(6).exp()
+    from ctgcn_amd.layers import MLP
+    torch.manual_seed(2)
+    mlp = MLP(300, 64, 32, 2, activate_type='N').to(DEV).eval()
+    x = torch.randn(500, 300, device=DEV)
+    ops.invalidate_plane_cache()
+    with torch.no_grad():
+        y0 = mlp(x)
+        assert all(e[0]() is not x for e in ops._plane_cache.entries.values())
+        x.data.add_(1.0)                       # an unmarked input may be edited any way the caller likes
+        y1 = mlp(x)
+        assert not torch.equal(y0, y1)
+        ops.mark_static(x)
+        y2 = mlp(x)
+        assert torch.equal(y1, y2) and any(e[0]() is x for e in ops._plane_cache.entries.values())
+
+
+@pytest.mark.parametrize("rows,k,n_out", [(128, 64, 16), (129, 64, 500), (255, 100, 384), (256, 1737, 512), (3000, 500, 513), (700, 96, 1100), (40_000, 500, 384)])
+def test_panel_kernel_edges(rows, k, n_out):
+    """gemm_h2_panel_kernel at its seams: one k stage (k <= 64: the scales of a panel are staged in the same stage its epilogue runs),
+    partial last panels, every column-tile count per wave (N = 16 ... 512), more than 512 columns (one launch per chunk), more panels
+    than CUs (persistent blocks walk several panels: the cross-panel prefetch), SELU on / off, output written into a wider buffer."""
+    from ctgcn_amd import ops
+    torch.manual_seed(rows + n_out)
+    x = torch.randn(rows, k, device=DEV) * torch.rand(rows, 1, device=DEV).mul(4).exp()
     w = torch.randn(n_out, k, device=DEV) / k ** 0.5
-    w[3] *= 1e-3                                          # a small row under the tensor-wide weight scale
     b = torch.randn(n_out, device=DEV)
     ref = x.double() @ w.double().t() + b.double()
     scale = (x.double().abs() @ w.double().abs().t()) + 1e-30
-    seen = []
-    ops.set_launch_timer(lambda name, s, e, meta: seen.append(meta.get("library", False)) if name == "linear_split" else None)
-    try:
-        monkeypatch.setenv("CTGCN_GEMM", "lib")
-        got = ops.linear_split(x, w, b)
-        assert seen and all(seen), seen
-        del seen[:]
-        monkeypatch.setenv("CTGCN_GEMM", "hand")
-        hand = ops.linear_split(x, w, b)
-        assert seen and not any(seen), seen
-    finally:
-        ops.set_launch_timer(None)
-    e_lib = ((got.double() - ref).abs() / scale).max().item()
-    e_hand = ((hand.double() - ref).abs() / scale).max().item()
-    lib32 = torch.addmm(b, x, w.t())
-    e_32 = ((lib32.double() - ref).abs() / scale).max().item()
-    print("rows=%d k=%d n=%d: library-k3 %.2e  hand %.2e  fp32 library %.2e" % (rows, k, n_out, e_lib, e_hand, e_32))
-    assert e_lib <= max(2 * e_32, 2e-7), (e_lib, e_hand, e_32)
-
-
-def test_mlp_k3_chain_matches_float64(monkeypatch):
-    """three Linear + SELU layers (layers.py:95-106) on the library path: a layer's scales, bias and SELU are applied by the next layer's
-    split — against float64 and against the hand-written layer-by-layer path"""
-    from ctgcn_amd.layers import MLP
-    torch.manual_seed(15)
-    for rows, widths in ((1000, (1737, 500, 500, 128)), (333, (96, 200, 64)), (70, (64, 132, 500, 32))):
-        lins = [torch.nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:])]
-        mlp = MLP(widths[0], widths[1], widths[-1], len(widths) - 1, activate_type='N')
-        mlp.linears = torch.nn.ModuleList(lins)
-        mlp.layer_num = len(lins)
-        x = torch.randn(rows, widths[0]) * torch.rand(rows, 1) * 10
-        want = x.double()
-        for lin in lins:
-            want = torch.nn.functional.selu(torch.nn.functional.linear(want, lin.weight.double(), lin.bias.double()))
-        mlp = mlp.to(DEV).eval()
-        xg = x.to(DEV)
-        seen = []
-        from ctgcn_amd import ops
-        ops.set_launch_timer(lambda name, s, e, meta: seen.append(meta.get("library", False)) if name == "linear_split" else None)
-        try:
-            with torch.no_grad():
-                monkeypatch.setenv("CTGCN_GEMM", "lib")
-                got = mlp(xg)
-                assert len(seen) == len(lins) and all(seen), seen
-                monkeypatch.setenv("CTGCN_GEMM", "hand")
-                ref = mlp(xg)
-        finally:
-            ops.set_launch_timer(None)
-        scale = want.abs().max().item()
-        e_lib = (got.double().cpu() - want).abs().max().item() / scale
-        e_hand = (ref.double().cpu() - want).abs().max().item() / scale
-        assert e_lib < 2e-6, (widths, e_lib, e_hand)
-        assert e_lib < 4 * e_hand + 1e-7, (widths, e_lib, e_hand)
-
-
-def test_k3_planes_are_cached_and_follow_in_place_updates(monkeypatch):
-    """the library path keeps the k3 planes of weights / static inputs (ops._PlaneCache.planes_k3): same result from the cache, a new one
-    after an in-place update (version counter), entries die with their tensors"""
-    from ctgcn_amd import ops
-    monkeypatch.setenv("CTGCN_GEMM", "lib")
-    torch.manual_seed(4)
-    x = torch.randn(600, 500, device=DEV)
-    w = torch.nn.Parameter(torch.randn(384, 500, device=DEV) * 0.05)
-    b = torch.randn(384, device=DEV)
-    ops._plane_cache.entries.clear(); ops._plane_cache.bytes = 0
-    a1 = ops.linear_split(x, w, b, static_x=True)
-    assert len(ops._plane_cache.entries) == 2
-    a2 = ops.linear_split(x, w, b, static_x=True)
-    assert torch.equal(a1, a2)
-    with torch.no_grad():
-        w.mul_(2.0)
-        x[0, 0] = 5.0
-    a3 = ops.linear_split(x, w, b, static_x=True)
-    ref = x.double() @ w.detach().double().t() + b.double()          # detached: an autograd graph would keep w alive
-    assert ((a3.double() - ref).abs().max() / ref.abs().max()).item() < 1e-6 and not torch.equal(a3, a1)
-    del x, w
-    import gc
-    gc.collect()
-    assert len(ops._plane_cache.entries) == 0
-
-
-def test_direct_to_lds_operand_staging_is_bit_identical(monkeypatch):
-    """CTGCN_GEMM_DMA=1 (global_load_lds_dwordx4 instead of registers + ds_write_b128): the same tiles, the same MFMA order — the same bits"""
-    from ctgcn_amd import ops
-    monkeypatch.setenv("CTGCN_GEMM", "hand")
-    torch.manual_seed(11)
-    for rows, k, n_out in ((5000, 500, 384), (777, 1737, 500), (129, 96, 130)):
-        x = torch.randn(rows, k, device=DEV) * torch.rand(rows, 1, device=DEV).mul(4).exp()
-        w = torch.randn(n_out, k, device=DEV) / k ** 0.5
-        b = torch.randn(n_out, device=DEV)
-        monkeypatch.setenv("CTGCN_GEMM_DMA", "0")
-        ref = ops.linear_split(x, w, b, selu=True)
-        monkeypatch.setenv("CTGCN_GEMM_DMA", "1")
-        got = ops.linear_split(x, w, b, selu=True)
-        assert torch.equal(got, ref), (rows, k, n_out)
-        monkeypatch.setenv("CTGCN_GEMM_DMA", "0")
-        monkeypatch.setenv("CTGCN_GEMM_WIDE", "1")            # 256 x 128 tiles, eight waves, three LDS stages
-        got = ops.linear_split(x, w, b, selu=True)
-        monkeypatch.setenv("CTGCN_GEMM_WIDE", "0")
-        assert torch.equal(got, ref), ("wide", rows, k, n_out)
+    buf = torch.full((rows, n_out + 5), 7.0, device=DEV)             # ldy % 4 != 0 for some shapes: the scalar store path
+    got = ops.linear_split(x, w, b, out=buf[:, :n_out])
+    assert bool((buf[:, n_out:] == 7.0).all())
+    assert ((got.double() - ref).abs() / scale).max().item() <= 4e-7
+    act = ops.linear_split(x, w, b, selu=True)
+    assert torch.allclose(act, torch.nn.functional.selu(got), rtol=2e-6, atol=1e-7)
+    again = ops.linear_split(x, w, b, out=torch.empty(rows, n_out, device=DEV))
+    assert torch.equal(again, got)                                    # aligned (16-byte stores) and unaligned outputs: the same values

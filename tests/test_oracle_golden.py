@@ -267,3 +267,41 @@ def test_neg_sampling_loss_oracle_matches_reference():
     loss.backward()
     for t in range(T):
         np.testing.assert_allclose(embs[t].grad.numpy(), g["loss_grad%d" % t], rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------ the row-subset form of the oracle (full-size GPU parity tests)
+def test_row_subset_path_equals_the_full_path():
+    """TP.ctgcn_rows / TP.cdn_rows (the reference path evaluated for some rows only: sliced matrices, nothing else) against TP.ctgcn /
+    TP.ctgcn_with_grad — themselves pinned to the reference's outputs above — on whole graphs: outputs of the rows, and every gradient of
+    a loss that reads those rows only, in float64 (agreement to rounding) and float32."""
+    from ctgcn_amd.synth import dynamic_graph
+    n, T = 400, 3
+    graphs = dynamic_graph(n, avg_deg=6, snapshots=T, seed=5)
+    mats = O.core_adj_list([O.kcore_matrices(g) for g in graphs], 0, T, T, max_core=4)
+    assert min(len(m) for m in mats) >= 2
+    adj = [[TP.coo_like_reference(m) for m in l] for l in mats]
+    torch.manual_seed(3)
+    import ctgcn_amd
+    model = ctgcn_amd.CTGCN(n, 24, 16, 1, 3, T)             # three CoreDiffusion layers: two levels of column sets
+    idx = torch.arange(n).repeat(2, 1)
+    rows = np.sort(np.random.default_rng(1).choice(n, 37, replace=False))
+    G = torch.randn(T, len(rows), 16, dtype=torch.float64)
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        xs = [torch.sparse_coo_tensor(idx, torch.ones(n, dtype=dtype), (n, n)) for _ in range(T)]
+        sd_a = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        sd_b = {k: v.detach().to(dtype).clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        full = TP.ctgcn_with_grad(sd_a, xs, [[a.to(dtype) for a in l] for l in adj])
+        part = TP.ctgcn_rows(sd_b, xs, mats, rows, with_grad=True)
+        assert part.shape == (T, len(rows), 16)
+        assert (full[:, rows] - part).abs().max().item() <= tol
+        (full[:, rows] * G.to(dtype)).sum().backward()
+        (part * G.to(dtype)).sum().backward()
+        for k in sd_a:
+            if sd_a[k].grad is None:
+                assert sd_b[k].grad is None or sd_b[k].grad.abs().max().item() == 0.0, k
+                continue
+            scale = sd_a[k].grad.abs().max().item()
+            assert (sd_a[k].grad - sd_b[k].grad).abs().max().item() <= tol * max(scale, 1.0) * 10, k
+        with torch.no_grad():                               # the inference form (nn.GRU) of the same rows
+            part_inf = TP.ctgcn_rows({k: v.detach() for k, v in sd_b.items()}, xs, mats, rows)
+        assert (part_inf - part.detach()).abs().max().item() <= max(tol, 1e-6) * 10

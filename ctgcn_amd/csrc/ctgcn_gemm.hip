@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     // compiler cannot tell which slot a request fills — i.e. for the requests issued a moment earlier (seen in the ISA: prefetch distance 0).
     // Completion is this kernel's business: `s_waitcnt vmcnt` + s_barrier below.  M0 = LDS base of the 1 KB the instruction fills.
     const uint32_t ldst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) _Float16 *)&As[0][(wave >> 2) * PLANE + rg0 * PSK];
-    auto dma = [&](int64_t pn, int ksn, int slot) {
+    auto dma = [&](int64_t pn, int ksn, int slot) __attribute__((always_inline)) {
         if (CTGCN_GEMM_ABLATE == 2 && (pn != (int64_t)blockIdx.x || ksn > 1)) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -289,15 +289,17 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         }
     };
 
-    // W fragments: column tile (wave NT + j), slab s, plane p -> 512 halfs at ((j KS + s) 2 + p) 512 from the wave's base
-    const _Float16 *const bbase = a.bp + (size_t)wave * NT * KS * 1024 + lane * 8;
+    // W fragments: column tile (wave NT + j), slab s, plane p -> 512 halfs at ((j KS + s) 2 + p) 512 from the wave's base.  Scalar base +
+    // one 32-bit lane offset: the address costs no vector registers (eight 64-bit addresses would be 16 of them)
+    const _Float16 *const bwave = a.bp + (size_t)wave * NT * KS * 1024;
+    const uint32_t blane = lane * 16;                     // bytes
     h8v fb[2][NT][2];
-    auto loadB = [&](int buf, int s) {
+    auto loadB = [&](int buf, int s) __attribute__((always_inline)) {
         if (CTGCN_GEMM_ABLATE == 1 && s > 1) return;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) fb[buf][j][p] = *(const h8v *)(bbase + ((size_t)(j * KS + s) * 2 + p) * 512);
+            for (int p = 0; p < 2; ++p) fb[buf][j][p] = *(const h8v *)((const char *)(bwave + ((size_t)(j * KS + s) * 2 + p) * 512) + blane);
     };
 
     // X fragments: row tile r, slab sl: lane l reads row r 16 + (l & 15), k = sl 32 + 8 (l >> 4) .. + 7  (segment sl 4 + (l >> 4))
@@ -312,32 +314,35 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[r][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
-    // all MFMAs of one k slab: row tiles in pairs, the next pair's fragments requested before this pair's 6 NT products
-    auto slab = [&](int slot, int sl, int buf) {
+    // all MFMAs of one k slab: row tiles in groups of RG (2; 1 at NT = 4, where 128 accumulators + 64 W fragment registers leave no room for
+    // four X fragments more), the next group's fragments requested before this group's 3 RG NT products.  An accumulator is written by every
+    // RG NT-th MFMA: >= 3 issue slots apart
+    constexpr int RG = NT >= 4 ? 1 : 2, NG = 8 / RG;
+    auto slab = [&](int slot, int sl, int buf) __attribute__((always_inline)) {
         const _Float16 *sbase = &As[slot][aoff[sl]];
-        h8v xa[2][2][2];                                  // [parity][row tile of the pair][plane]
+        h8v xa[2][RG][2];                                 // [parity][row tile of the group][plane]
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
+        for (int rr = 0; rr < RG; ++rr)
 #pragma unroll
             for (int p = 0; p < 2; ++p) xa[0][rr][p] = *(const h8v *)(sbase + p * PLANE + rr * 16 * PSK);
 #pragma unroll
-        for (int rp = 0; rp < 4; ++rp) {
+        for (int rp = 0; rp < NG; ++rp) {
             const int cur = rp & 1;
-            if (rp < 3) {
+            if (rp + 1 < NG) {
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
+                for (int rr = 0; rr < RG; ++rr)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) xa[cur ^ 1][rr][p] = *(const h8v *)(sbase + p * PLANE + ((rp + 1) * 2 + rr) * 16 * PSK);
+                    for (int p = 0; p < 2; ++p) xa[cur ^ 1][rr][p] = *(const h8v *)(sbase + p * PLANE + ((rp + 1) * RG + rr) * 16 * PSK);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
+                for (int rr = 0; rr < RG; ++rr)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         if (CTGCN_GEMM_ABLATE != 4)
-                            acc[rp * 2 + rr][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[buf][j][term == 0 ? 1 : 0], xa[cur][rr][term == 1 ? 1 : 0], acc[rp * 2 + rr][j], 0, 0, 0);
+                            acc[rp * RG + rr][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[buf][j][term == 0 ? 1 : 0], xa[cur][rr][term == 1 ? 1 : 0], acc[rp * RG + rr][j], 0, 0, 0);
                         else asm volatile("" :: "v"(fb[buf][j][term == 0 ? 1 : 0]), "v"(xa[cur][rr][term == 1 ? 1 : 0]));
                     }
             __builtin_amdgcn_sched_barrier(0);
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     // y = act(acc sa[m] sb[n] + bias[n]): lane l holds columns 4 (l >> 4) .. + 3 of row (l & 15) of every 16 x 16 tile.  A panel that lies
     // inside the matrix (rows) whose wave's columns all exist takes the straight-line path — 8 NT 16-byte stores back to back; with a test
     // around every store the compiler branches around each one and waits for vmcnt(0) in front of it (stores count in vmcnt on gfx9).
-    auto epilogue_as = [&](int64_t pn, int par, auto selu, auto whole) {
+    auto epilogue_as = [&](int64_t pn, int par, auto selu, auto whole) __attribute__((always_inline)) {
         const int64_t m0 = pn * PBM;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         }
     };
     const bool cols_whole = a.vec && (wave * NT + NT) * 16 <= a.N;
-    auto epilogue = [&](int64_t pn, int par) {
+    auto epilogue = [&](int64_t pn, int par) __attribute__((always_inline)) {
         const bool whole = cols_whole && (pn + 1) * PBM <= a.M;
         if (a.act == 1) {
             if (whole) epilogue_as(pn, par, std::true_type{}, std::true_type{});
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     float sa_r = 0.f;
     bool sa_pending = false;
     int sa_par = 0;
-    auto advance = [&](int64_t &pn, int &ks) { if (++ks == nks) { ks = 0; pn += stride; } };
+    auto advance = [&](int64_t &pn, int &ks) __attribute__((always_inline)) { if (++ks == nks) { ks = 0; pn += stride; } };
     dma(pan_2, ks_2, 0);
     advance(pan_2, ks_2);
     dma(pan_2, ks_2, 1);

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=int, default=-1, help="index of the single shape to run")
+    ap.add_argument("--no-lib", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     for rows, k, n, what in (SHAPES if a.only < 0 else SHAPES[a.only:a.only + 1]):
@@ -39,10 +40,19 @@ def main():
             return s.elapsed_time(e) / a.iters
 
         t_split = timeit(lambda: ops.linear_split(x, w, b, out=out))
-        t_lib = timeit(lambda: torch.addmm(b, x, w.t(), out=out))
+        # the GEMM kernel alone: both operands prepared once (what the models' cached weights / aggregation-written planes give it)
+        from ctgcn_amd import _lib
+        from ctgcn_amd._lib import check, ptr
+        lib = _lib.load()
+        xp, wp = ops._plane_cache.planes(x, lib), ops._plane_cache.packed(w, lib)
+        st = ops._stream()
+        t_gemm = timeit(lambda: check(lib.ctgcn_linear_packed_f32(rows, n, k, ptr(xp), ptr(wp), ptr(b), 0, ptr(out), n, st), "gemm"))
+        t_lib = timeit(lambda: torch.addmm(b, x, w.t(), out=out)) if not a.no_lib else float("nan")
         fl = 2.0 * rows * k * n
-        print("%-52s rows=%d k=%d n=%d: split %.3f ms (%.0f TF/s fp32-equivalent) | fp32 library %.3f ms (%.0f TF/s)"
-              % (what, rows, k, n, t_split, fl / t_split / 1e9, t_lib, fl / t_lib / 1e9))
+        kp = -(-k // 64) * 64
+        hbm = rows * kp * 4.0 + rows * n * 4.0
+        print("%-52s rows=%d k=%d n=%d: GEMM alone %.3f ms (%.0f TF/s fp32-eq = %.3f of 833; operand + output bytes at %.2f TB/s) | with the split of x %.3f ms | fp32 library %.3f ms (%.0f TF/s)"
+              % (what, rows, k, n, t_gemm, fl / t_gemm / 1e9, fl / t_gemm / 1e9 / 833.0, hbm / t_gemm / 1e9, t_split, t_lib, fl / t_lib / 1e9))
 
 
 if __name__ == "__main__":

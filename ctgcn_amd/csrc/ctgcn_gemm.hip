@@ -220,10 +220,13 @@ struct PanelArgs {
     float *y;                                // first column of this chunk
     int64_t ldy;
     int64_t mtiles;
+#ifdef CTGCN_GEMM_TIMELINE
+    unsigned long long *timeline;            // diagnostic build: [block][wave 0 / 7][stage < 48][6] s_memtime stamps, see tools/gemm_timeline.py
+#endif
 };
 
 #ifndef CTGCN_GEMM_ABLATE
-#define CTGCN_GEMM_ABLATE 0          // diagnostic builds (WRONG results): 1 no W-fragment loads in the loop, 2 no X staging in the loop, 4 no MFMA, 5 no epilogue stores
+#define CTGCN_GEMM_ABLATE 0          // diagnostic builds (WRONG results), a bit mask: 1 no W-fragment loads in the loop, 2 no X staging in the loop, 4 no MFMA, 8 no epilogue stores
 #endif
 #ifndef CTGCN_GEMM_NT_LOADS
 #define CTGCN_GEMM_NT_LOADS 1        // X planes are streamed once: non-temporal direct-to-LDS loads keep them from evicting W from the XCD's L2
@@ -232,18 +235,28 @@ struct PanelArgs {
 // gemm_h2_panel_kernel<NT>: Y[M, N] = X W^T for N <= 128 NT.  Persistent blocks of 8 waves (two per SIMD), one block per CU.
 //   * A block works on PANELS of 128 rows of X over the full width: X's planes are read from HBM exactly once (round 4's 128 x 128 tiles
 //     re-read them N / 128 times through L2, in 64-byte pieces).  k advances in STAGES of 64: per row and plane one whole 128-byte line,
-//     fetched by global_load_lds_dwordx4 into a three-slot LDS ring (32 KB per stage, requested two stages ahead; XOR swizzle applied on the global side so that the
+//     fetched by global_load_lds_dwordx4 into a three-slot LDS ring (32 KB per stage; XOR swizzle applied on the global side so that the
 //     fragment reads are conflict-free), no registers, no ds_write.
 //   * Wave w owns output columns [16 NT w, 16 NT (w + 1)): its W fragments come from the packed layout (above) with one coalesced 1 KB load
 //     per (column tile, k slab, plane) STRAIGHT INTO REGISTERS — W is never in LDS, nobody shares it, no barrier guards it.  Every wave reads
 //     all 128 X rows of the stage from LDS (8 x 32 KB of ds_read_b128 per stage: 22 % of the LDS read rate at NT = 3).
 //   * Products: v_mfma_f32_16x16x32_f16 with W as the first operand, so a lane ends up with FOUR CONSECUTIVE COLUMNS of one output row
 //     (16-byte stores); per (row tile, column tile, k slab) three MFMAs into one accumulator, small terms first (x1 w2, x2 w1, x1 w1).
-//   * One wait + one barrier per stage: `s_waitcnt vmcnt(0)` at the top of a stage retires, youngest first, the W fragments of the stage's
-//     first slab (requested half a stage ago), the X lines of this stage (requested a stage ago) — memory operations retire in order, so
-//     one counter serves both streams.  Epilogue stores of a finished panel are issued at the start of the NEXT panel's first stage, behind
-//     that stage's operand requests: they drain under a whole stage of MFMAs, and the next panel's operands were already in flight.
-//   * Registers (NT = 3): 96 accumulators + 48 W fragments (two slabs) + 32 X fragments (two row-tile pairs) = 176 + addresses.
+//   * The X requests are INLINE-ASM instructions: behind the compiler's own LDS-DMA intrinsic every ds_read of the ring waits for vmcnt(0) —
+//     the compiler cannot tell which slot a request fills — i.e. for requests issued a moment earlier (seen in the ISA).  Their completion is
+//     this kernel's business: `s_waitcnt vmcnt(0)` + s_barrier at the top of a stage.  The W fragments are plain loads the compiler tracks.
+//   * Requests TRAIL the MFMA groups one or two at a time (a per-stage timeline, tools/gemm_timeline.py: ten requests per wave in one burst
+//     behind the barrier kept the CU's address unit busy for ~2 000 cycles during which no wave reached its MFMAs):
+//         slab 0:  W fragments of slab 1
+//         slab 1:  W fragments of the next stage's slab 0, then the X lines of stage + 2 and the panel's row scales
+//     Memory operations retire in order and the compiler does not see the X requests, so both waits of a stage (top, in front of slab 1) are
+//     vmcnt(0): the X lines are in LDS 1.5 stages before their use, the W fragments were requested one slab ahead.
+//   * A finished panel's rows leave group by group inside the first slab of the NEXT panel (each group right in front of the first products
+//     into the same accumulators): the next panel's operands are already in flight.  The stores (16 rows x 64 bytes per instruction) still
+//     cost ~1.4 stage times per panel: the remaining known inefficiency (14 % at k = 512).
+//   * Registers (NT = 3): 96 accumulators + 48 W fragments (two slabs) + 32 X fragments (two row-tile groups) = 176 + addresses; 251 allocated.
+//   * Measured (tools/gemm_bench.py, GEMM alone): 435 180 x 500 x 384 0.55 ms (round 4's 128 x 128 tiles: 0.77), 60 730 x 1 737 x 500 0.27 (0.35),
+//     60 730 x 500 x 500 0.10 (0.15); SQ counters: matrix pipe busy 44 % of the SIMD cycles at the 1.85 GHz the chip holds here, waves parked 40 %.
 template <int NT>
 __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a)
 {
@@ -251,7 +264,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     __shared__ __attribute__((aligned(1024))) _Float16 As[3][2 * PLANE];      // [slot][plane][row][64 k], 16-byte segment g of row r at g ^ (r & 7)
     __shared__ __attribute__((aligned(16))) float s_sb[NT * 128];
     __shared__ __attribute__((aligned(16))) float s_bias[NT * 128];
-    __shared__ float s_sa[2][PBM];
+    __shared__ __attribute__((aligned(256))) float s_sa[4][PBM];               // row scales of panel count & 3 (four: one k stage per panel leaves no barrier between
+                                                                              // a late wave's epilogue reads and an early wave's request for the panel after next)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;        // wave: in an SGPR
     const int nks = a.Kp / PSK, KS = a.Kp / 32;
     const int64_t stride = gridDim.x;
@@ -266,40 +280,43 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
 
     // X staging: a wave instruction fills 8 rows x 128 B of one plane linearly (lane l -> row l >> 3, stored segment l & 7), so the lane fetches
     // the segment that belongs there: (l & 7) ^ (row & 7).  32 instructions per stage, four per wave: waves 0-3 plane 1, waves 4-7 plane 2.
+    // M0 = LDS address of the 1 KB the instruction fills.
     const _Float16 *aplane = (wave < 4) ? a.a1 : a.a2;
     const int rg0 = (wave & 3) * 32;                      // first of this wave's 32 rows
     const int lrow = lane >> 3;
     const int gseg = ((lane & 7) ^ lrow) * 8;
-    // As an INLINE-ASM instruction: behind the compiler's own LDS-DMA intrinsic every ds_read of the staging buffer waits for vmcnt(0) — the
-    // compiler cannot tell which slot a request fills — i.e. for the requests issued a moment earlier (seen in the ISA: prefetch distance 0).
-    // Completion is this kernel's business: `s_waitcnt vmcnt` + s_barrier below.  M0 = LDS base of the 1 KB the instruction fills.
     const uint32_t ldst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) _Float16 *)&As[0][(wave >> 2) * PLANE + rg0 * PSK];
-    auto dma = [&](int64_t pn, int ksn, int slot) __attribute__((always_inline)) {
-        if (CTGCN_GEMM_ABLATE == 2 && (pn != (int64_t)blockIdx.x || ksn > 1)) return;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t row = min(pn * PBM + rg0 + i * 8 + lrow, a.M - 1);
-            const _Float16 *src = aplane + row * a.Kp + ksn * PSK + gseg;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(ldst + (uint32_t)(slot * 2 * PLANE + i * 8 * PSK) * 2u);
+    auto dma1 = [&](int64_t pn, int ksn, int slot, int i) __attribute__((always_inline)) {
+        if ((CTGCN_GEMM_ABLATE & 2) && (pn != (int64_t)blockIdx.x || ksn > 1)) { asm volatile("s_nop 0"); return; }
+        const int64_t row = min(pn * PBM + rg0 + i * 8 + lrow, a.M - 1);
+        const _Float16 *src = aplane + row * a.Kp + ksn * PSK + gseg;
+        const uint32_t dst = ldst + (uint32_t)(slot * 2 * PLANE + i * 8 * PSK) * 2u;
 #if CTGCN_GEMM_NT_LOADS
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(dst) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" :: "v"(src), "s"(dst) : "memory");
 #else
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");
 #endif
-        }
+    };
+    // the panel's row scales, 4 bytes per lane, straight into s_sa[par]: waves w and w + 2, w + 4, w + 6 fetch the same 64 values (every wave
+    // issues the same number of requests: the waits below count them).  Re-requested in every stage of the panel (256 bytes).
+    const uint32_t sdst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)&s_sa[0][(wave & 1) * 64];
+    auto dma_sa = [&](int64_t pn, int par) __attribute__((always_inline)) {
+        const float *src = a.sa + min(pn * PBM + (wave & 1) * 64 + lane, a.M - 1);
+        const uint32_t dst = sdst + (uint32_t)par * PBM * 4u;
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(src), "s"(dst) : "memory");
     };
 
     // W fragments: column tile (wave NT + j), slab s, plane p -> 512 halfs at ((j KS + s) 2 + p) 512 from the wave's base.  Scalar base +
-    // one 32-bit lane offset: the address costs no vector registers (eight 64-bit addresses would be 16 of them)
+    // one 32-bit lane offset: the address costs no vector registers.  Plain loads the compiler tracks: it waits for them (vmcnt) in front of
+    // their first MFMA.  (Inline-asm loads with hand-counted waits were built, measured 2-5 % faster — and gave wrong panels in one run of
+    // ten at N <= 128, also with every wait at vmcnt(0): removed, profiles/r05_gemm_panel_kernel.txt.)
     const _Float16 *const bwave = a.bp + (size_t)wave * NT * KS * 1024;
     const uint32_t blane = lane * 16;                     // bytes
     h8v fb[2][NT][2];
-    auto loadB = [&](int buf, int s) __attribute__((always_inline)) {
-        if (CTGCN_GEMM_ABLATE == 1 && s > 1) return;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) fb[buf][j][p] = *(const h8v *)((const char *)(bwave + ((size_t)(j * KS + s) * 2 + p) * 512) + blane);
+    auto loadB1 = [&](int buf, int s, int q) __attribute__((always_inline)) {         // request q = 2 j + p of slab s
+        if ((CTGCN_GEMM_ABLATE & 1) && s > 1) return;
+        const int j = q >> 1, p = q & 1;
+        fb[buf][j][p] = *(const h8v *)((const char *)(bwave + ((size_t)(j * KS + s) * 2 + p) * 512) + blane);
     };
 
     // X fragments: row tile r, slab sl: lane l reads row r 16 + (l & 15), k = sl 32 + 8 (l >> 4) .. + 7  (segment sl 4 + (l >> 4))
@@ -315,10 +332,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         for (int j = 0; j < NT; ++j) acc[r][j] = f4v{0.f, 0.f, 0.f, 0.f};
 
     // all MFMAs of one k slab: row tiles in groups of RG (2; 1 at NT = 4, where 128 accumulators + 64 W fragment registers leave no room for
-    // four X fragments more), the next group's fragments requested before this group's 3 RG NT products.  An accumulator is written by every
-    // RG NT-th MFMA: >= 3 issue slots apart
+    // four X fragments more), the next group's fragments requested before this group's 3 RG NT products, side(g) — the memory requests that
+    // trail group g — behind them.  An accumulator is written by every RG NT-th MFMA: >= 3 issue slots apart
     constexpr int RG = NT >= 4 ? 1 : 2, NG = 8 / RG;
-    auto slab = [&](int slot, int sl, int buf) __attribute__((always_inline)) {
+    auto slab = [&](int slot, int sl, int buf, auto pre, auto side) __attribute__((always_inline)) {
         const _Float16 *sbase = &As[slot][aoff[sl]];
         h8v xa[2][RG][2];                                 // [parity][row tile of the group][plane]
 #pragma unroll
@@ -335,16 +352,20 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
                     for (int p = 0; p < 2; ++p) xa[cur ^ 1][rr][p] = *(const h8v *)(sbase + p * PLANE + ((rp + 1) * RG + rr) * 16 * PSK);
             }
             __builtin_amdgcn_sched_barrier(0);
+            pre(rp);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int rr = 0; rr < RG; ++rr)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        if (CTGCN_GEMM_ABLATE != 4)
+                        if (!(CTGCN_GEMM_ABLATE & 4))
                             acc[rp * RG + rr][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[buf][j][term == 0 ? 1 : 0], xa[cur][rr][term == 1 ? 1 : 0], acc[rp * RG + rr][j], 0, 0, 0);
                         else asm volatile("" :: "v"(fb[buf][j][term == 0 ? 1 : 0]), "v"(xa[cur][rr][term == 1 ? 1 : 0]));
                     }
+            __builtin_amdgcn_sched_barrier(0);
+            side(rp);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -352,10 +373,10 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     // y = act(acc sa[m] sb[n] + bias[n]): lane l holds columns 4 (l >> 4) .. + 3 of row (l & 15) of every 16 x 16 tile.  A panel that lies
     // inside the matrix (rows) whose wave's columns all exist takes the straight-line path — 8 NT 16-byte stores back to back; with a test
     // around every store the compiler branches around each one and waits for vmcnt(0) in front of it (stores count in vmcnt on gfx9).
-    auto epilogue_as = [&](int64_t pn, int par, auto selu, auto whole) __attribute__((always_inline)) {
+    auto epilogue_as = [&](int64_t pn, int par, int r0, int r1, auto selu, auto whole) __attribute__((always_inline)) {
         const int64_t m0 = pn * PBM;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = r0; r < r1; ++r) {
             const int64_t m = m0 + r * 16 + arow;
             const float s = s_sa[par][r * 16 + arow];
 #pragma unroll
@@ -372,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
                     } else o[v] = t;
                 }
                 acc[r][j] = f4v{0.f, 0.f, 0.f, 0.f};
-                if (CTGCN_GEMM_ABLATE == 5) { asm volatile("" :: "v"(o)); continue; }
+                if (CTGCN_GEMM_ABLATE & 8) { asm volatile("" :: "v"(o)); continue; }
                 float *dst = a.y + m * a.ldy + n;
                 if (decltype(whole)::value) *(f4v *)dst = o;
                 else if (m < a.M) {
@@ -386,65 +407,91 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         }
     };
     const bool cols_whole = a.vec && (wave * NT + NT) * 16 <= a.N;
-    auto epilogue = [&](int64_t pn, int par) __attribute__((always_inline)) {
+    auto epilogue = [&](int64_t pn, int par, int r0, int r1) __attribute__((always_inline)) {
         const bool whole = cols_whole && (pn + 1) * PBM <= a.M;
         if (a.act == 1) {
-            if (whole) epilogue_as(pn, par, std::true_type{}, std::true_type{});
-            else epilogue_as(pn, par, std::true_type{}, std::false_type{});
+            if (whole) epilogue_as(pn, par, r0, r1, std::true_type{}, std::true_type{});
+            else epilogue_as(pn, par, r0, r1, std::true_type{}, std::false_type{});
         } else {
-            if (whole) epilogue_as(pn, par, std::false_type{}, std::true_type{});
-            else epilogue_as(pn, par, std::false_type{}, std::false_type{});
+            if (whole) epilogue_as(pn, par, r0, r1, std::false_type{}, std::true_type{});
+            else epilogue_as(pn, par, r0, r1, std::false_type{}, std::false_type{});
         }
     };
 
     int64_t pan_c = blockIdx.x, pan_2 = blockIdx.x;       // the stage being multiplied: (panel, k stage); the stage requested two ahead
-    int ks_c = 0, ks_2 = 0, par = 0, slot = 0;
-    float sa_r = 0.f;
-    bool sa_pending = false;
-    int sa_par = 0;
+    int ks_c = 0, ks_2 = 0, par = 0, slot = 0;             // par: (panels finished so far) & 3
     auto advance = [&](int64_t &pn, int &ks) __attribute__((always_inline)) { if (++ks == nks) { ks = 0; pn += stride; } };
-    dma(pan_2, ks_2, 0);
+    // prologue: W fragments of stage 0 / slab 0, X lines of stages 0 and 1, the first panel's scales — the request pattern of a stage's slab 1
+#pragma unroll
+    for (int q = 0; q < 2 * NT; ++q) loadB1(0, 0, q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma1(pan_2, ks_2, 0, i);
     advance(pan_2, ks_2);
-    dma(pan_2, ks_2, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (also: the LDS stores of s_sb / s_bias above are the compiler's to order: __syncthreads below)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma1(pan_2, ks_2, 1, i);
     advance(pan_2, ks_2);
-    loadB(0, 0);
+    dma_sa(pan_c, 0);
+    // requests that trail the row-tile groups of a slab: QB per group from a list of 2 NT (slab 0) / 2 NT + 5 (slab 1) requests, early groups first
+    constexpr int Q0 = (2 * NT + NG - 1) / NG, Q1 = (2 * NT + 5 + NG - 1) / NG;
     for (int64_t it = 0; it < total; ++it) {
         int64_t pan_n = pan_c;
         int ks_n = ks_c;
         advance(pan_n, ks_n);
-        // everything requested so far has landed: this wave's share of this stage's X lines (and the next one's), the W fragments of slab 0, the scales
+#ifdef CTGCN_GEMM_TIMELINE
+        unsigned long long *tl = (a.timeline && it < 48 && (wave == 0 || wave == 7) && lane == 0) ? a.timeline + (((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 48 + it) * 6 : nullptr;
+        if (tl) tl[0] = clock64();
+#endif
+        // everything requested so far has landed: the W fragments of this stage's slab 0, this wave's share of the X lines of stages it .. it + 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (sa_pending) {
-            if (tid < PBM) s_sa[sa_par][tid] = sa_r;
-            sa_pending = false;
-        }
+#ifdef CTGCN_GEMM_TIMELINE
+        if (tl) tl[1] = clock64();
+#endif
         __syncthreads();                                  // the stage is complete for every wave; the slot of stage it - 1 has been read by every wave
-        // everything conditional comes BEFORE this stage's operand requests: behind a branch the compiler cannot count the outstanding
-        // loads and waits for vmcnt(0) at the next use of a W fragment — i.e. for the requests issued a moment ago (measured in the ISA)
-        if (ks_c == 0) {
-            if (tid < PBM) sa_r = a.sa[min(pan_c * PBM + tid, a.M - 1)];
-            sa_pending = true;
-            sa_par = par;
-            if (it > 0) epilogue(pan_c - stride, par ^ 1);
-        }
         __builtin_amdgcn_sched_barrier(0);
-        loadB(1, ks_c * 2 + 1);
-        dma(pan_2, ks_2, slot == 0 ? 2 : slot - 1);       // stage it + 2 into the slot of stage it - 1; never conditional (past the end: a valid address, a dead slot)
+#ifdef CTGCN_GEMM_TIMELINE
+        if (tl) tl[2] = clock64();
+#endif
+        auto side0 = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = g * Q0; q < (g + 1) * Q0 && q < 2 * NT; ++q) loadB1(1, ks_c * 2 + 1, q);
+        };
+        // a panel is finished: its rows leave group by group, each right in front of the first products of the NEXT panel into the same
+        // accumulators — the stores of rows 32 .. 127 are issued among the MFMAs of rows 0 .. 95 (one block of 8 NT stores in front of
+        // the stage cost 1.5 stage times per panel: the address unit takes a 16-row x 64-byte store in no less than a 1 KB load).
+        // ONE copy of slab 0 with a uniform branch per group (two copies — with and without the stores — spilled 68 registers at NT = 3)
+        const bool leave = ks_c == 0 && it > 0;
+        const int64_t pprev = pan_c - stride;
+        const int sprev = (par + 3) & 3;
+        slab(slot, 0, 0, [&](int g) __attribute__((always_inline)) { if (leave) epilogue(pprev, sprev, g * RG, g * RG + RG); }, side0);
+#ifdef CTGCN_GEMM_TIMELINE
+        if (tl) tl[3] = clock64();
+#endif
+        // (here the compiler waits for slab 1's W fragments: vmcnt(0) — it does not see the X requests, all older)
+#ifdef CTGCN_GEMM_TIMELINE
+        if (tl) tl[4] = clock64();
+#endif
+        const int nslot = slot == 0 ? 2 : slot - 1;       // stage it + 2 goes into the slot of stage it - 1
+        slab(slot, 1, 1, [&](int) __attribute__((always_inline)) {}, [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = g * Q1; q < (g + 1) * Q1 && q < 2 * NT + 5; ++q) {
+                if (q < 2 * NT) loadB1(0, ks_n * 2, q);   // the next stage's first slab (past the end: a valid, unused address)
+                else if (q < 2 * NT + 4) dma1(pan_2, ks_2, nslot, q - 2 * NT);       // never conditional (past the end: a valid address, a dead slot)
+                else dma_sa(pan_n, ks_n == 0 ? (par + 1) & 3 : par);                        // the scales of the NEXT stage's panel
+            }
+        });
+#ifdef CTGCN_GEMM_TIMELINE
+        if (tl) tl[5] = clock64();
+#endif
         advance(pan_2, ks_2);
-        __builtin_amdgcn_sched_barrier(0);
-        slab(slot, 0, 0);
-        loadB(0, ks_n * 2);                               // the next stage's first slab (past the end: a valid, unused address)
-        __builtin_amdgcn_sched_barrier(0);
-        slab(slot, 1, 1);                                 // (the compiler's wait for these fragments also retires the X requests above: in order)
-        if (ks_n == 0) par ^= 1;
+        if (ks_n == 0) par = (par + 1) & 3;
         pan_c = pan_n;
         ks_c = ks_n;
         slot = slot == 2 ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (sa_pending && tid < PBM) s_sa[sa_par][tid] = sa_r;
     __syncthreads();
-    epilogue(pan_c - stride, par ^ 1);
+    epilogue(pan_c - stride, (par + 3) & 3, 0, 8);
 }
 
 int device_cus()
@@ -551,6 +598,15 @@ int ctgcn_linear_packed_f32(int64_t rows, int32_t n_out, int32_t k, const void *
     const _Float16 *frags = (const _Float16 *)w_packed;
     const float *sb = (const float *)(frags + g.frag_halfs);
     const int64_t blocks = a.mtiles < device_cus() ? a.mtiles : device_cus();
+#ifdef CTGCN_GEMM_TIMELINE
+    static const char *tl_file = getenv("CTGCN_GEMM_TIMELINE_FILE");
+    static int tl_calls = 0;
+    const size_t tl_words = (size_t)blocks * 2 * 48 * 6;
+    if (tl_file && ++tl_calls == 3) {            // the third call: clocks and caches are warm
+        (void)hipMalloc(&a.timeline, tl_words * 8);
+        (void)hipMemsetAsync(a.timeline, 0, tl_words * 8, (hipStream_t)stream);
+    }
+#endif
     size_t frag_off = 0;
     int32_t pad_off = 0;
     for (int c = 0; c < g.chunks; ++c) {
@@ -569,6 +625,19 @@ int ctgcn_linear_packed_f32(int64_t rows, int32_t n_out, int32_t k, const void *
         frag_off += (size_t)nt * 128 * g.kp * 2;
         pad_off += nt * 128;
     }
+#ifdef CTGCN_GEMM_TIMELINE
+    if (a.timeline) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        unsigned long long *h = (unsigned long long *)malloc(tl_words * 8);
+        (void)hipMemcpy(h, a.timeline, tl_words * 8, hipMemcpyDeviceToHost);
+        FILE *f = fopen(tl_file, "w");
+        for (size_t i = 0; i < tl_words / 6; ++i)
+            if (h[i * 6]) fprintf(f, "%zu %zu %zu %llu %llu %llu %llu %llu %llu\n", i / 96, (i / 48) % 2, i % 48, h[i * 6], h[i * 6 + 1], h[i * 6 + 2], h[i * 6 + 3], h[i * 6 + 4], h[i * 6 + 5]);
+        fclose(f);
+        free(h);
+        (void)hipFree(a.timeline);
+    }
+#endif
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

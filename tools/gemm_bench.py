@@ -19,9 +19,13 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=int, default=-1, help="index of the single shape to run")
     ap.add_argument("--no-lib", action="store_true")
+    ap.add_argument("--shape", action="append", default=[], help="rows,k,n (repeatable): run these instead of the model shapes")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    for rows, k, n, what in (SHAPES if a.only < 0 else SHAPES[a.only:a.only + 1]):
+    shapes = SHAPES if a.only < 0 else SHAPES[a.only:a.only + 1]
+    if a.shape:
+        shapes = [tuple(int(v) for v in sh.split(",")) + ("custom",) for sh in a.shape]
+    for rows, k, n, what in shapes:
         x = torch.randn(rows, k, device=dev)
         w = torch.randn(n, k, device=dev) / k ** 0.5
         b = torch.randn(n, device=dev)

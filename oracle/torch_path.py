@@ -37,12 +37,14 @@ def aggregate_loop(adj_list, x):
 
 
 def _rnn(sd, prefix, rnn_type, seq):
-    """nn.GRU / nn.LSTM(num_layers=1, batch_first=True) evaluated from raw weights (layers.py:27-30)."""
+    """nn.GRU / nn.LSTM(num_layers=1, batch_first=True) evaluated from raw weights (layers.py:27-30).  On a GPU the rows go through the
+    module in chunks: MIOpen rejects problems whose gate buffers pass 2^31 elements (1 M nodes x 8 cores x 3 x 128 already does); rows are
+    independent sequences, so this is the same result."""
     w_ih, w_hh = sd[prefix + "weight_ih_l0"], sd[prefix + "weight_hh_l0"]
     b_ih, b_hh = sd.get(prefix + "bias_ih_l0"), sd.get(prefix + "bias_hh_l0")
     hid = w_hh.shape[1]
     mod = (torch.nn.LSTM if rnn_type == "LSTM" else torch.nn.GRU)(w_ih.shape[1], hid, 1, bias=b_ih is not None,
-                                                                 batch_first=True).to(w_ih.dtype)   # float64 runs = exact truth
+                                                                 batch_first=True).to(device=w_ih.device, dtype=w_ih.dtype)   # float64 runs = exact truth
     with torch.no_grad():
         mod.weight_ih_l0.copy_(w_ih)
         mod.weight_hh_l0.copy_(w_hh)
@@ -51,7 +53,10 @@ def _rnn(sd, prefix, rnn_type, seq):
             mod.bias_hh_l0.copy_(b_hh)
     for p in mod.parameters():
         p.requires_grad_(False)
-    return mod(seq)[0]
+    chunk = (1 << 29) // max(1, seq.shape[1] * 4 * hid)
+    if not seq.is_cuda or seq.shape[0] <= chunk:
+        return mod(seq)[0]
+    return torch.cat([mod(seq[lo:lo + chunk])[0] for lo in range(0, seq.shape[0], chunk)], 0)
 
 
 def _rnn_grad(sd, prefix, rnn_type, seq):

@@ -311,7 +311,7 @@ def test_config5_training_layer_gradients_at_full_size(config5):
                                                                                  int(untouched.sum()), stray, t_truth))
     _record("config5_training_layer", forward_max_err_vs_fp64=obs["max_err_hip_vs_fp64"], forward_max_err_cpu_fp32_vs_fp64=obs["max_err_cpu_fp32_vs_fp64"],
             rows=int(len(rows)), kink_rows=int(kink.sum()), truth_s=t_truth, stray_dx=stray, **{"rel_" + k: v for k, v in rel.items()})
-    assert int(kink.sum()) < 0.05 * len(rows)
+    assert int(kink.sum()) < 0.10 * len(rows)
     assert stray == 0.0
     assert len(rel) == 8 and max(rel.values()) < 1e-4, rel
 

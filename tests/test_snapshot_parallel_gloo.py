@@ -32,7 +32,8 @@ def test_plan_assignment_balances_cumulative_snapshots():
 @pytest.mark.parametrize("exchange,T,n,world", [("all_to_all", 5, 301, 2), ("all_gather", 4, 300, 2),
                                                  ("all_to_all", 5, 203, 4),      # uneven: one rank owns two snapshots, three own one
                                                  ("all_to_all", 3, 150, 4),      # a rank that owns nothing still takes part in the exchange
-                                                 ("all_gather", 6, 150, 4)])
+                                                 ("all_gather", 6, 150, 4),
+                                                 ("all_to_all", 16, 96, 8)])     # the north-star layout: 16 cumulative snapshots on 8 ranks, two each (LPT)
 def test_sharded_ctgcn_matches_unsharded(exchange, T, n, world):
     from _dist_worker import run
     mgr = mp.Manager()
@@ -41,6 +42,10 @@ def test_sharded_ctgcn_matches_unsharded(exchange, T, n, world):
     assert len(results) == world
     if T < world:
         assert [] in results[0][3]
+    if T == 2 * world:
+        assert all(len(a) == 2 for a in results[0][3])       # cumulative snapshots grow with t: LPT gives every rank two, a small one with a large one
+        loads = [sum(t + 1 for t in a) for a in results[0][3]]
+        assert max(loads) - min(loads) <= 2, results[0][3]
     for rank in range(world):
         err_fwd, err_bwd, err_full, assignment = results[rank]
         assert err_fwd < 1e-5 and err_full < 1e-5, (rank, err_fwd, err_full)

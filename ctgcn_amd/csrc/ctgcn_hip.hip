@@ -747,6 +747,157 @@ __global__ __launch_bounds__(256) void kcore_level_kernel(int n, int k, int chun
     }
 }
 
+// ------------------------------------------------------------------ k-core by local h-index sweeps (round 5)
+// core(v) is the greatest fixed point below deg of  h(v) <- H({h(u) : u in N(v)}),  H = the largest k with at least k values >= k
+// (Lu, Zhou, Zhang, Stanley 2016; the peel above needs one dependent cascade per level — 84 launches of ~86 us on the config-5 snapshot, a
+// latency chain — where a sweep is one bandwidth-bound pass over the CSR and a few tens of sweeps converge on power-law graphs).  Values only
+// ever decrease and never pass below the core number, in any update order, so sweeps update h IN PLACE and may read stale neighbours (another
+// XCD's L2): a stale value is a larger one, the result stays an upper bound.  What must not be lost is the knowledge that a neighbour changed:
+//   * a vertex is recomputed in sweep s when its byte in flags[s & 1] is set (the first FULL sweeps recompute everybody);
+//   * a vertex whose value drops to `now` sets the byte of every neighbour u with h(u) > now in flags[(s + 1) & 1] (plain byte stores of the
+//     value 1 — concurrent writers agree; L2 lines carry byte masks, so bytes written under different XCDs merge at write-back) and the block
+//     that owns a flag clears it after reading it — two sweeps before anybody sets it again, with kernel boundaries in between;
+//   * a sweep that sets no flag has reached the fixed point: ctl->marks[s & 31] == 0.
+// Same unique integers as the peel (tests compare both with the Batagelj-Zaversnik oracle); level_cap clips every value at the cap
+// (H of clipped values, clipped, is the clipped H: counts of values >= k for k <= cap do not change).
+constexpr int KH_CHUNK = 1024;      // vertices per block
+constexpr int KH_CACHE = 1024;      // neighbour values a wave keeps in LDS for a long list
+
+struct KhCtl {
+    int marks[32];
+    int max_core;
+    int pad[31];
+};
+
+__global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int all_active, int do_mark, int sweep, const int32_t *__restrict__ row_ptr,
+                                                           const int32_t *__restrict__ col, int32_t *h, uint8_t *flag_in, uint8_t *flag_out, KhCtl *ctl)
+{
+    __shared__ int q[KH_CHUNK];
+    __shared__ int cache[4][KH_CACHE];
+    __shared__ int s_tail, s_marks;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_tail = 0; s_marks = 0; }
+    __syncthreads();
+    const int lo = blockIdx.x * KH_CHUNK;
+    {   // this block's 1 024 flags, four per thread; read, clear, queue
+        const int v0 = lo + tid * 4;
+        uint32_t f = 0;
+        if (v0 + 3 < n) {
+            f = *(const uint32_t *)(flag_in + v0);
+            if (f) *(uint32_t *)(flag_in + v0) = 0;
+        } else {
+            for (int i = 0; i < 4; ++i) if (v0 + i < n && flag_in[v0 + i]) { f |= 0xffu << (8 * i); flag_in[v0 + i] = 0; }
+        }
+        if (all_active) f = 0xffffffffu;
+        for (int i = 0; i < 4; ++i)
+            if (((f >> (8 * i)) & 0xff) && v0 + i < n) q[atomicAdd(&s_tail, 1)] = v0 + i;
+    }
+    __syncthreads();
+    const int tail = s_tail;
+    int marks = 0;
+    // short lists: one 16-lane group per vertex, up to KC_LONG / 16 values per lane
+    const int grp = tid / KC_GROUP, lig = tid % KC_GROUP, ngrp = 256 / KC_GROUP;
+    constexpr int PER = KC_LONG / KC_GROUP;
+    for (int i = grp; i < tail; i += ngrp) {
+        const int v = q[i];
+        const int s0 = row_ptr[v], e0 = row_ptr[v + 1];
+        if (e0 - s0 > KC_LONG) continue;
+        const int c = h[v];
+        int val[PER], nb[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = s0 + lig + KC_GROUP * j;
+            nb[j] = e < e0 ? col[e] : v;
+            val[j] = nb[j] != v ? min(h[nb[j]], c) : 0;
+        }
+        int klo = 0, khi = c;
+        while (klo < khi) {                               // uniform across the group: c and the counts are
+            const int mid = (klo + khi + 1) >> 1;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) cnt += val[j] >= mid;
+            cnt += __shfl_xor(cnt, 1, KC_GROUP);
+            cnt += __shfl_xor(cnt, 2, KC_GROUP);
+            cnt += __shfl_xor(cnt, 4, KC_GROUP);
+            cnt += __shfl_xor(cnt, 8, KC_GROUP);
+            if (cnt >= mid) klo = mid; else khi = mid - 1;
+        }
+        if (klo < c) {
+            if (lig == 0) h[v] = klo;
+            if (do_mark) {
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    if (val[j] > klo) { flag_out[nb[j]] = 1; ++marks; }
+            }
+        }
+    }
+    // long lists: one wave per vertex, the clipped neighbour values in LDS (lists beyond KH_CACHE entries are gathered again for every probe)
+    const int wv = tid >> 6, wl = tid & 63;
+    for (int i = wv; i < tail; i += 4) {
+        const int v = q[i];
+        const int s0 = row_ptr[v], e0 = row_ptr[v + 1], deg = e0 - s0;
+        if (deg <= KC_LONG) continue;
+        const int c = h[v];
+        const bool cached = deg <= KH_CACHE;
+        if (cached)
+            for (int e = wl; e < deg; e += 64) {
+                const int u = col[s0 + e];
+                cache[wv][e] = u != v ? min(h[u], c) : 0;
+            }
+        int klo = 0, khi = c;
+        while (klo < khi) {
+            const int mid = (klo + khi + 1) >> 1;
+            int cnt = 0;
+            if (cached) {
+                for (int e = wl; e < deg; e += 64) cnt += cache[wv][e] >= mid;
+            } else {
+                for (int e = s0 + wl; e < e0; e += 64) { const int u = col[e]; cnt += (u != v) && h[u] >= mid; }
+            }
+#pragma unroll
+            for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (cnt >= mid) klo = mid; else khi = mid - 1;
+        }
+        if (klo < c) {
+            if (wl == 0) h[v] = klo;
+            if (do_mark)
+                for (int e = wl; e < deg; e += 64) {
+                    const int u = col[s0 + e];
+                    const int hu = cached ? cache[wv][e] : (u != v ? h[u] : 0);
+                    if (hu > klo) { flag_out[u] = 1; ++marks; }
+                }
+        }
+    }
+    if (marks) atomicAdd(&s_marks, marks);
+    __syncthreads();
+    if (tid == 0 && s_marks) atomicAdd(&ctl->marks[sweep & 31], s_marks);
+    (void)cap;
+}
+
+// h = min(degree without the self loop, cap); all flags of both sets cleared
+__global__ __launch_bounds__(256) void kcore_hindex_init_kernel(int n, int cap, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                                int32_t *__restrict__ h, uint8_t *__restrict__ flags)
+{
+    const int lig = threadIdx.x & 7;
+    const int64_t v = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    if (v >= n) return;
+    int cnt = 0;
+    for (int e = row_ptr[v] + lig, end = row_ptr[v + 1]; e < end; e += 8) cnt += (col[e] != (int)v);
+    cnt += __shfl_xor(cnt, 1, 8);
+    cnt += __shfl_xor(cnt, 2, 8);
+    cnt += __shfl_xor(cnt, 4, 8);
+    if (lig == 0) { h[v] = min(cnt, cap); flags[v] = 0; flags[(size_t)n + v] = 0; }
+}
+
+__global__ void kcore_hindex_finish_kernel(int n, const int32_t *__restrict__ h, int32_t *__restrict__ core, KhCtl *ctl)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int c = 0;
+    if (v < n) { c = h[v]; core[v] = c; }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) c = max(c, __shfl_xor(c, o));
+    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(&ctl->max_core, c);
+}
+
 // ------------------------------------------------------------------ edge levels + histogram
 constexpr int EL_HIST = 2048;
 
@@ -4345,9 +4496,41 @@ int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, i
     int32_t *pool_v = (int32_t *)ws; ws += align_up((size_t)n * 4, 256);
     int32_t *pool_prev = (int32_t *)ws;
 
+    const int nn = (int)n;
+    // CTGCN_KCORE=peel: the level-synchronous peel (rounds 1-4); default: h-index sweeps (round 5; same integers)
+    static const bool use_peel = [] { const char *e = getenv("CTGCN_KCORE"); return e && !strcmp(e, "peel"); }();
+    if (!use_peel) {
+        KhCtl *kc = (KhCtl *)ctl;                         // 256 bytes at the head of the workspace
+        uint8_t *flags = (uint8_t *)pool_v;               // 2 n bytes of the peel's 8 n byte pool
+        const int capv = level_cap > 0 ? level_cap : 0x7fffffff;
+        HIP_TRY(hipMemsetAsync(kc, 0, sizeof(KhCtl), st));
+        hipLaunchKernelGGL(kcore_hindex_init_kernel, dim3((unsigned)(((int64_t)nn * 8 + 255) / 256)), dim3(256), 0, st, nn, capv, row_ptr, col_idx, deg, flags);
+        const unsigned blocks = (unsigned)((nn + KH_CHUNK - 1) / KH_CHUNK);
+        constexpr int FULL = 3, BATCH = 8;                // sweeps that recompute every vertex (the last of them sets flags); sweeps per host check
+        KhCtl hk{};
+        for (int sweep = 0;;) {
+            HIP_TRY(hipMemsetAsync(&kc->marks[sweep & 31], 0, BATCH * sizeof(int), st));        // this batch's counters (32 is a multiple of BATCH)
+            const int first = sweep;
+            for (int b = 0; b < BATCH; ++b, ++sweep)
+                hipLaunchKernelGGL(kcore_hindex_kernel, dim3(blocks), dim3(256), 0, st, nn, capv, sweep < FULL ? 1 : 0, sweep >= FULL - 1 ? 1 : 0, sweep,
+                                   row_ptr, col_idx, deg, flags + (size_t)(sweep & 1) * nn, flags + (size_t)((sweep + 1) & 1) * nn, kc);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&hk, kc, sizeof(KhCtl), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            bool done = false;
+            for (int b = first; b < sweep; ++b) done = done || (b >= FULL - 1 && hk.marks[b & 31] == 0);      // a marking sweep that set no flag: fixed point
+            if (done) break;
+            if (sweep > nn + 64) return fail(CTGCN_E_HIP, "kcore: h-index sweeps did not converge");
+        }
+        hipLaunchKernelGGL(kcore_hindex_finish_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, deg, core, kc);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&hk, kc, sizeof(KhCtl), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (max_core_host) *max_core_host = hk.max_core;
+        return CTGCN_OK;
+    }
     HIP_TRY(hipMemsetAsync(ctl, 0, sizeof(KcoreCtl), st));
     HIP_TRY(hipMemsetAsync(claimed, 0, claimed_bytes, st));
-    const int nn = (int)n;
     hipLaunchKernelGGL(kcore_init_kernel, dim3((unsigned)(((int64_t)nn * 8 + 255) / 256)), dim3(256), 0, st, nn, row_ptr, col_idx, deg);
     HIP_TRY(hipGetLastError());
 

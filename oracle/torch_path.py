@@ -183,8 +183,8 @@ def ctgcn(sd, x_list, adj_list, rnn_type="GRU", model_type="C", activate="L"):
 def ambiguous_rows(pre_list, rel=1e-5):
     """bool [rows]: some pre-ReLU value of the row (any core, any feature) lies within rel x the row's largest |value| of zero"""
     stack = torch.stack(pre_list, 1).abs()                              # [rows, K, d]
-    big = stack.reshape(stack.shape[0], -1).max(1).values.clamp_min(1.0)
-    return (stack.reshape(stack.shape[0], -1).min(1).values <= rel * big)
+    big = stack.reshape(stack.shape[0], -1).max(1).values                # relative to the row's own scale: the sum's rounding error is
+    return (stack.reshape(stack.shape[0], -1).min(1).values <= rel * big)  # a few ulps of its largest partial sums, whatever their magnitude
 
 
 def _rows_of(mats, rows, dtype):

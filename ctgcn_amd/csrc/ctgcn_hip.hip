@@ -757,26 +757,34 @@ __global__ __launch_bounds__(256) void kcore_level_kernel(int n, int k, int chun
 //   * a vertex whose value drops to `now` sets the byte of every neighbour u with h(u) > now in flags[(s + 1) & 1] (plain byte stores of the
 //     value 1 — concurrent writers agree; L2 lines carry byte masks, so bytes written under different XCDs merge at write-back) and the block
 //     that owns a flag clears it after reading it — two sweeps before anybody sets it again, with kernel boundaries in between;
-//   * a sweep that sets no flag has reached the fixed point: ctl->marks[s & 31] == 0.
+//   * a sweep that sets no flag has reached the fixed point: ctl->marks[s & 15] == 0.
 // Same unique integers as the peel (tests compare both with the Batagelj-Zaversnik oracle); level_cap clips every value at the cap
 // (H of clipped values, clipped, is the clipped H: counts of values >= k for k <= cap do not change).
 constexpr int KH_CHUNK = 1024;      // vertices per block
 constexpr int KH_CACHE = 1024;      // neighbour values a wave keeps in LDS for a long list
 
-struct KhCtl {
-    int marks[32];
+struct KhCtl {               // 256 bytes: the head of the workspace (the peel's KcoreCtl region)
+    int marks[16];           // flags set by sweep s & 15
+    int hubs[16];            // active hub vertices (lists longer than KH_CACHE) queued by sweep s & 15 for kcore_hindex_hub_kernel
     int max_core;
     int pad[31];
 };
+static_assert(sizeof(KhCtl) == 256, "KhCtl must fit the 256-byte control block of the k-core workspace");
+constexpr int KH_BINS = 8192;
 
 __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int all_active, int do_mark, int sweep, const int32_t *__restrict__ row_ptr,
-                                                           const int32_t *__restrict__ col, int32_t *h, uint8_t *flag_in, uint8_t *flag_out, KhCtl *ctl)
+                                                           const int32_t *__restrict__ col, int32_t *h, uint8_t *flag_in, uint8_t *flag_out, KhCtl *ctl,
+                                                           int32_t *hub_list)
 {
-    __shared__ int q[KH_CHUNK];
+    // three queues by list length, filled by the threads that read the flags (each reads its vertices' row_ptr once, all in parallel: a
+    // queue scanned by every phase with a row_ptr load per entry to skip the others' vertices cost ~200 us per sweep, active or not)
+    __shared__ int q[3][KH_CHUNK];
     __shared__ int cache[4][KH_CACHE];
-    __shared__ int s_tail, s_marks;
+    __shared__ int s_tail[3], s_marks;
+    constexpr int KH_TINY = 16;
     const int tid = threadIdx.x;
-    if (tid == 0) { s_tail = 0; s_marks = 0; }
+    if (tid < 3) s_tail[tid] = 0;
+    if (tid == 0) s_marks = 0;
     __syncthreads();
     const int lo = blockIdx.x * KH_CHUNK;
     {   // this block's 1 024 flags, four per thread; read, clear, queue
@@ -789,19 +797,63 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
             for (int i = 0; i < 4; ++i) if (v0 + i < n && flag_in[v0 + i]) { f |= 0xffu << (8 * i); flag_in[v0 + i] = 0; }
         }
         if (all_active) f = 0xffffffffu;
-        for (int i = 0; i < 4; ++i)
-            if (((f >> (8 * i)) & 0xff) && v0 + i < n) q[atomicAdd(&s_tail, 1)] = v0 + i;
+        if (f) {
+            int rp[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) rp[i] = row_ptr[min(v0 + i, n)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (((f >> (8 * i)) & 0xff) && v0 + i < n) {
+                    const int deg = rp[i + 1] - rp[i];
+                    if (deg == 0) continue;               // h = 0 from the start
+                    if (deg > KH_CACHE) { hub_list[atomicAdd(&ctl->hubs[sweep & 15], 1)] = v0 + i; continue; }      // a block per hub: next kernel
+                    const int which = deg <= KH_TINY ? 0 : (deg <= KC_LONG ? 1 : 2);
+                    q[which][atomicAdd(&s_tail[which], 1)] = v0 + i;
+                }
+        }
     }
     __syncthreads();
-    const int tail = s_tail;
     int marks = 0;
-    // short lists: one 16-lane group per vertex, up to KC_LONG / 16 values per lane
+    // tiny lists (<= 16 entries: most vertices of a power-law graph): one LANE per vertex.  All 16 column loads, then all 16 value gathers, are
+    // independent requests — a 16-lane group per vertex walked its 64 vertices one dependent chain (row_ptr -> col -> h) after the other and a
+    // sweep took ~200 us whatever the number of active vertices.  The values (clipped at c <= 16) are counted in sixteen 8-bit counters.
+    for (int i = tid, tail = s_tail[0]; i < tail; i += 256) {
+        const int v = q[0][i];
+        const int s0 = row_ptr[v], deg = row_ptr[v + 1] - s0;
+        const int c = h[v];
+        if (c == 0) continue;
+        int nb[KH_TINY], hv[KH_TINY];
+#pragma unroll
+        for (int j = 0; j < KH_TINY; ++j) nb[j] = j < deg ? col[s0 + j] : v;
+#pragma unroll
+        for (int j = 0; j < KH_TINY; ++j) hv[j] = nb[j] != v ? min(h[nb[j]], c) : 0;
+        unsigned long long c_lo = 0, c_hi = 0;            // counters of the values 1 .. 8 and 9 .. 16
+#pragma unroll
+        for (int j = 0; j < KH_TINY; ++j) {
+            const int x = hv[j];
+            if (x >= 9) c_hi += 1ull << (8 * (x - 9));
+            else if (x >= 1) c_lo += 1ull << (8 * (x - 1));
+        }
+        int now = 0, cnt = 0;
+        for (int k = c; k >= 1; --k) {
+            cnt += (int)(((k >= 9 ? c_hi >> (8 * (k - 9)) : c_lo >> (8 * (k - 1)))) & 0xff);
+            if (cnt >= k) { now = k; break; }
+        }
+        if (now < c) {
+            h[v] = now;
+            if (do_mark) {
+#pragma unroll
+                for (int j = 0; j < KH_TINY; ++j)
+                    if (hv[j] > now) { flag_out[nb[j]] = 1; ++marks; }
+            }
+        }
+    }
+    // short lists (17 .. KC_LONG entries): one 16-lane group per vertex, up to KC_LONG / 16 values per lane
     const int grp = tid / KC_GROUP, lig = tid % KC_GROUP, ngrp = 256 / KC_GROUP;
     constexpr int PER = KC_LONG / KC_GROUP;
-    for (int i = grp; i < tail; i += ngrp) {
-        const int v = q[i];
+    for (int i = grp, tail = s_tail[1]; i < tail; i += ngrp) {
+        const int v = q[1][i];
         const int s0 = row_ptr[v], e0 = row_ptr[v + 1];
-        if (e0 - s0 > KC_LONG) continue;
         const int c = h[v];
         int val[PER], nb[PER];
 #pragma unroll
@@ -831,28 +883,21 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
             }
         }
     }
-    // long lists: one wave per vertex, the clipped neighbour values in LDS (lists beyond KH_CACHE entries are gathered again for every probe)
+    // long lists (up to KH_CACHE entries): one wave per vertex, the clipped neighbour values in LDS; longer ones: kcore_hindex_hub_kernel
     const int wv = tid >> 6, wl = tid & 63;
-    for (int i = wv; i < tail; i += 4) {
-        const int v = q[i];
+    for (int i = wv, tail = s_tail[2]; i < tail; i += 4) {
+        const int v = q[2][i];
         const int s0 = row_ptr[v], e0 = row_ptr[v + 1], deg = e0 - s0;
-        if (deg <= KC_LONG) continue;
         const int c = h[v];
-        const bool cached = deg <= KH_CACHE;
-        if (cached)
-            for (int e = wl; e < deg; e += 64) {
-                const int u = col[s0 + e];
-                cache[wv][e] = u != v ? min(h[u], c) : 0;
-            }
+        for (int e = wl; e < deg; e += 64) {
+            const int u = col[s0 + e];
+            cache[wv][e] = u != v ? min(h[u], c) : 0;
+        }
         int klo = 0, khi = c;
         while (klo < khi) {
             const int mid = (klo + khi + 1) >> 1;
             int cnt = 0;
-            if (cached) {
-                for (int e = wl; e < deg; e += 64) cnt += cache[wv][e] >= mid;
-            } else {
-                for (int e = s0 + wl; e < e0; e += 64) { const int u = col[e]; cnt += (u != v) && h[u] >= mid; }
-            }
+            for (int e = wl; e < deg; e += 64) cnt += cache[wv][e] >= mid;
 #pragma unroll
             for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
             if (cnt >= mid) klo = mid; else khi = mid - 1;
@@ -860,17 +905,78 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         if (klo < c) {
             if (wl == 0) h[v] = klo;
             if (do_mark)
-                for (int e = wl; e < deg; e += 64) {
-                    const int u = col[s0 + e];
-                    const int hu = cached ? cache[wv][e] : (u != v ? h[u] : 0);
-                    if (hu > klo) { flag_out[u] = 1; ++marks; }
-                }
+                for (int e = wl; e < deg; e += 64)
+                    if (cache[wv][e] > klo) { flag_out[col[s0 + e]] = 1; ++marks; }
         }
     }
     if (marks) atomicAdd(&s_marks, marks);
     __syncthreads();
-    if (tid == 0 && s_marks) atomicAdd(&ctl->marks[sweep & 31], s_marks);
+    if (tid == 0 && s_marks) atomicAdd(&ctl->marks[sweep & 15], s_marks);
     (void)cap;
+}
+
+// hub vertices (lists longer than KH_CACHE) of one sweep, a block each: ONE gather pass into an LDS histogram of the clipped values, then the
+// largest k with count(values >= k) >= k from per-thread suffix sums (a wave probing a 200 000-entry list eleven times would set the sweep's
+// time).  Values are clipped at KH_BINS: a hub whose estimate is still above that comes out at KH_BINS at most — an upper bound, a decrease —
+// and flags ITSELF for the next sweep.
+__global__ __launch_bounds__(256) void kcore_hindex_hub_kernel(int do_mark, int sweep, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col, int32_t *h,
+                                                               uint8_t *flag_out, KhCtl *ctl, const int32_t *__restrict__ hub_list)
+{
+    __shared__ int hist[KH_BINS + 1];
+    __shared__ int part[256];
+    __shared__ int s_best, s_marks;
+    const int tid = threadIdx.x;
+    const int count = ctl->hubs[sweep & 15];
+    int marks = 0;
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const int v = hub_list[i];
+        const int s0 = row_ptr[v], e0 = row_ptr[v + 1];
+        const int c = h[v];
+        const int B = min(c, KH_BINS);
+        __syncthreads();
+        for (int b = tid; b <= B; b += 256) hist[b] = 0;
+        if (tid == 0) { s_best = 0; s_marks = 0; }
+        __syncthreads();
+        for (int e = s0 + tid; e < e0; e += 256 * 8) {   // eight independent (column, value) request pairs per thread in flight
+            int u[8], x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = e + 256 * j < e0 ? col[e + 256 * j] : v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = u[j] != v ? min(h[u[j]], B) : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (x[j] >= 1) atomicAdd(&hist[x[j]], 1);
+        }
+        __syncthreads();
+        // thread t owns bins [t W + 1, (t + 1) W]: chunk sums, suffix over the chunks, then the bins from the top
+        const int W = (B + 255) / 256;
+        const int b0 = tid * W + 1, b1 = min(B, (tid + 1) * W);
+        int sum = 0;
+        for (int b = b0; b <= b1; ++b) sum += hist[b];
+        part[tid] = sum;
+        __syncthreads();
+        int above = 0;
+        for (int t = tid + 1; t < 256; ++t) above += part[t];
+        int run = above, best = 0;
+        for (int b = b1; b >= b0; --b) {
+            run += hist[b];
+            if (run >= b) { best = b; break; }
+        }
+        if (best) atomicMax(&s_best, best);
+        __syncthreads();
+        const int now = s_best;
+        if (now < c) {
+            if (tid == 0) {
+                h[v] = now;
+                if (now == B && B < c) { flag_out[v] = 1; ++marks; }      // clipped, not the h-index yet: look again
+            }
+            if (do_mark)
+                for (int e = s0 + tid; e < e0; e += 256) {
+                    const int u = col[e];
+                    if (u != v && h[u] > now) { flag_out[u] = 1; ++marks; }
+                }
+        }
+    }
+    if (marks) atomicAdd(&ctl->marks[sweep & 15], marks);
 }
 
 // h = min(degree without the self loop, cap); all flags of both sets cleared
@@ -888,14 +994,20 @@ __global__ __launch_bounds__(256) void kcore_hindex_init_kernel(int n, int cap, 
     if (lig == 0) { h[v] = min(cnt, cap); flags[v] = 0; flags[(size_t)n + v] = 0; }
 }
 
-__global__ void kcore_hindex_finish_kernel(int n, const int32_t *__restrict__ h, int32_t *__restrict__ core, KhCtl *ctl)
+__global__ __launch_bounds__(256) void kcore_hindex_finish_kernel(int n, const int32_t *__restrict__ h, int32_t *__restrict__ core, KhCtl *ctl)
 {
+    __shared__ int s_max;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
     const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int c = 0;
     if (v < n) { c = h[v]; core[v] = c; }
 #pragma unroll
     for (int o = 32; o; o >>= 1) c = max(c, __shfl_xor(c, o));
-    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(&ctl->max_core, c);
+    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(&s_max, c);
+    __syncthreads();
+    // one device atomic per block, and only from blocks that can raise the maximum (15 600 waves on one address took 180 us)
+    if (threadIdx.x == 0 && s_max > __hip_atomic_load(&ctl->max_core, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&ctl->max_core, s_max);
 }
 
 // ------------------------------------------------------------------ edge levels + histogram
@@ -4497,28 +4609,40 @@ int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, i
     int32_t *pool_prev = (int32_t *)ws;
 
     const int nn = (int)n;
-    // CTGCN_KCORE=peel: the level-synchronous peel (rounds 1-4); default: h-index sweeps (round 5; same integers)
-    static const bool use_peel = [] { const char *e = getenv("CTGCN_KCORE"); return e && !strcmp(e, "peel"); }();
+    // Two algorithms, the same integers.  The level-synchronous peel costs one dependent cascade per level (~86 us each on the config-5
+    // snapshots): unbeatable when the loader's max_core caps it at a few levels (0.58 ms at cap 8 against 0.9 ms of sweeps), 7.3 ms for all 84
+    // levels.  h-index sweeps cost ~40 sweeps whatever the depth: 4.0 ms there.  Default: peel up to a cap of 16 levels, sweeps beyond and for
+    // the exact core numbers; CTGCN_KCORE=peel / hindex forces one (tools/kcore_bench.py, profiles/r05_kcore_hindex.txt).
+    static const int forced = [] { const char *e = getenv("CTGCN_KCORE"); return !e ? 0 : (!strcmp(e, "peel") ? 1 : (!strcmp(e, "hindex") ? 2 : 0)); }();
+    const bool use_peel = forced == 1 || (forced == 0 && level_cap > 0 && level_cap <= 16);
     if (!use_peel) {
         KhCtl *kc = (KhCtl *)ctl;                         // 256 bytes at the head of the workspace
         uint8_t *flags = (uint8_t *)pool_v;               // 2 n bytes of the peel's 8 n byte pool
+        int32_t *hub_list = pool_prev;                    // up to n hub vertices
         const int capv = level_cap > 0 ? level_cap : 0x7fffffff;
         HIP_TRY(hipMemsetAsync(kc, 0, sizeof(KhCtl), st));
         hipLaunchKernelGGL(kcore_hindex_init_kernel, dim3((unsigned)(((int64_t)nn * 8 + 255) / 256)), dim3(256), 0, st, nn, capv, row_ptr, col_idx, deg, flags);
         const unsigned blocks = (unsigned)((nn + KH_CHUNK - 1) / KH_CHUNK);
-        constexpr int FULL = 3, BATCH = 8;                // sweeps that recompute every vertex (the last of them sets flags); sweeps per host check
+        static const int FULL = [] { const char *e = getenv("CTGCN_KCORE_FULL"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+        constexpr int BATCH = 8;                          // FULL sweeps recompute every vertex (the last of them sets flags); BATCH sweeps per host check
         KhCtl hk{};
         for (int sweep = 0;;) {
-            HIP_TRY(hipMemsetAsync(&kc->marks[sweep & 31], 0, BATCH * sizeof(int), st));        // this batch's counters (32 is a multiple of BATCH)
+            HIP_TRY(hipMemsetAsync(&kc->marks[sweep & 15], 0, BATCH * sizeof(int), st));        // this batch's counters (16 is a multiple of BATCH)
+            HIP_TRY(hipMemsetAsync(&kc->hubs[sweep & 15], 0, BATCH * sizeof(int), st));
             const int first = sweep;
-            for (int b = 0; b < BATCH; ++b, ++sweep)
+            for (int b = 0; b < BATCH; ++b, ++sweep) {
                 hipLaunchKernelGGL(kcore_hindex_kernel, dim3(blocks), dim3(256), 0, st, nn, capv, sweep < FULL ? 1 : 0, sweep >= FULL - 1 ? 1 : 0, sweep,
-                                   row_ptr, col_idx, deg, flags + (size_t)(sweep & 1) * nn, flags + (size_t)((sweep + 1) & 1) * nn, kc);
+                                   row_ptr, col_idx, deg, flags + (size_t)(sweep & 1) * nn, flags + (size_t)((sweep + 1) & 1) * nn, kc, hub_list);
+                hipLaunchKernelGGL(kcore_hindex_hub_kernel, dim3(256), dim3(256), 0, st, sweep >= FULL - 1 ? 1 : 0, sweep, row_ptr, col_idx, deg,
+                                   flags + (size_t)((sweep + 1) & 1) * nn, kc, hub_list);
+            }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&hk, kc, sizeof(KhCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             bool done = false;
-            for (int b = first; b < sweep; ++b) done = done || (b >= FULL - 1 && hk.marks[b & 31] == 0);      // a marking sweep that set no flag: fixed point
+            for (int b = first; b < sweep; ++b) done = done || (b >= FULL - 1 && hk.marks[b & 15] == 0);      // a marking sweep that set no flag: fixed point
+            static const bool trace = getenv("CTGCN_KCORE_TRACE") != nullptr;
+            if (trace) { fprintf(stderr, "kcore sweeps %d..%d flags set:", first, sweep - 1); for (int b = first; b < sweep; ++b) fprintf(stderr, " %d", hk.marks[b & 15]); fprintf(stderr, "\n"); }
             if (done) break;
             if (sweep > nn + 64) return fail(CTGCN_E_HIP, "kcore: h-index sweeps did not converge");
         }

@@ -41,4 +41,4 @@ for t in which:
             want = want if cap < 0 else np.minimum(want, cap)
             ok = " | equal to the Batagelj-Zaversnik oracle: %s" % bool(np.array_equal(core.cpu().numpy(), want))
         print("snapshot %d: n = %d, %d entries, level_cap %d (%s): %.3f ms per call, max core %d, %d distinct core numbers%s" % (
-            t, a.nodes, col.numel(), cap, os.environ.get("CTGCN_KCORE", "h-index sweeps"), ms, mk, torch.unique(core).numel(), ok), flush=True)
+            t, a.nodes, col.numel(), cap, os.environ.get("CTGCN_KCORE", "default: peel up to cap 16, h-index sweeps beyond"), ms, mk, torch.unique(core).numel(), ok), flush=True)

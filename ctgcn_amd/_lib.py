@@ -75,6 +75,7 @@ SIGNATURES = {
     "ctgcn_gru_input_grad_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "ctgcn_gru_weight_grad_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _int, _vp, _i32, _int, _vp]),
     "ctgcn_gru_row_granule": (_i64, []),
+    "ctgcn_compute_units": (_i32, []),
     "ctgcn_row_cumsum_f32": (_int, [_i64, _vp, _vp, _vp, _vp]),
     "ctgcn_random_walk_pairs": (_int, [_i64, _vp, _vp, _vp, _i32, _i32, _i32, _c.c_uint64, _int, _vp, _vp, _vp, _vp]),
     "ctgcn_neg_sampling_indices": (_int, [_i64, _vp, _vp, _vp, _i32, _i64, _vp, _c.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -545,17 +545,14 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 // CUs a persistent kernel (one block per CU) may count on: the device's, or fewer when the caller runs it on a stream with a CU mask
 // (ctgcn_set_persistent_cus: the snapshot pipeline gives the HBM-bound aggregation its own few CUs next to the matrix-core kernels)
-// CTGCN_LAYER_PAIR=1: the planes form of the GRU layer kernel with two tiles in flight per block and the two waves of a SIMD half a step out
-// of phase (gru_layer8_h2_pair_kernel).  Bit-identical, and 1.9 - 2.6 x SLOWER than the single-tile kernel (round 4, profiles/r04_layer_pair_ab.txt):
-// the second tile's state does not fit next to the resident weights — 150 spilled VGPRs, scratch reloads on the critical path of every slot.
-// Kept as the measured negative of VERDICT r3 item 2 (b / c); default off.
+// (round 4's gru_layer8_h2_pair_kernel — two tiles in flight per block, the two waves of a SIMD half a step out of phase — was bit-identical and
+// 1.9 - 2.6 x slower, profiles/r04_layer_pair_ab.txt; removed in round 5, git history has it.)
 #ifdef CTGCN_LAYER_TIMELINE
 // diagnostic build: per (block, wave) phase sums of the layer kernel, written to $CTGCN_LAYER_TIMELINE_FILE by every call (tools/layer_timeline.py)
 struct LayerArgs;
 const char *timeline_begin(LayerArgs &a, unsigned nb8, void *stream);
 void timeline_end(LayerArgs &a, unsigned nb8, const char *tl_file, void *stream);
 #endif
-bool layer_pair_enabled() { static const bool on = [] { const char *e = getenv("CTGCN_LAYER_PAIR"); return e && atoi(e) == 1; }(); return on; }
 int g_persistent_cus = 0;
 int persistent_cus(int device_cus) { return g_persistent_cus > 0 && g_persistent_cus < device_cus ? g_persistent_cus : device_cus; }
 
@@ -2516,9 +2513,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
                                 }
                             }
                             __builtin_amdgcn_sched_barrier(0);
-#ifndef LY_ABL_NO_HH
                             if (with_h) { CTGCN_H2_MFMA1(Wh[ut], c, h1, h2, ach) }
-#endif
                         }
                     };
                     if (t > 0) body(std::true_type{}); else body(std::false_type{});
@@ -2531,9 +2526,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
                     const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
                     const f4v hprev = t > 0 ? *(const f4v *)(&hold[r_][oc]) : zero4;
                     f4v h;
-#ifdef LY_ABL_NO_GATES
-                    h = gi[0] + gi[1] + gi[2] + ach[0] * csc[0] + ach[1] * csc[1] + ach[2] * csc[2] + b_hn + hprev;
-#else
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], gi[0][j]));
@@ -2542,7 +2534,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
                         const float nv = gru_tanh(fmaf(rv, an, gi[2][j]));
                         h[j] = nv + zv * (hprev[j] - nv);
                     }
-#endif
                     *(f4v *)(&hold[r_][oc]) = h;
                     if (REDUCE) {
                         f4v *sp_ = (f4v *)(&hsum[r_][oc]);
@@ -2583,18 +2574,6 @@ constexpr int L8_PITCH = 128;                            // halfs per plane row,
 // half index of element k of row r (r < 16): 16-byte segment k / 8 goes to segment (k / 8) ^ r
 __device__ __forceinline__ int l8_off(int r, int k) { return ((((k >> 3) ^ r) & 15) << 3) | (k & 7); }
 __device__ __forceinline__ constexpr int l8_lds_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : -1; }
-#ifndef CTGCN_L8_WL_PLAN
-#define CTGCN_L8_WL_PLAN 12
-#endif
-#ifndef CTGCN_L8_HPIPE
-#define CTGCN_L8_HPIPE 0
-#endif
-#ifndef CTGCN_L8_PRIO
-#define CTGCN_L8_PRIO 0
-#endif
-#ifndef CTGCN_L8_ABLATE
-#define CTGCN_L8_ABLATE 0            // diagnostic builds of the row-plan path (WRONG results): 1 no LayerNorm / row output, 2 no transcendentals in the gate math,
-#endif                               // 3 no x loads after the first two units, 4 no h products, 5 no x products, 6 no publish split, 7 no gate math, 8 no barrier, 9 no MFMA, 10 = 7 + 9
 // WL fragments of W_ih in LDS: the 12 of the residual plane, then the LAST WL - 12 of the leading plane
 template <int WL>
 __device__ __forceinline__ constexpr int l8_slot(int sp, int c, int g) { return sp == 1 ? c * 3 + g : (c * 3 + g >= 24 - WL ? c * 3 + g - (24 - WL) + 12 : -1); }
@@ -2620,7 +2599,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     __shared__ uint32_t msk_s[4];
     // the row-plan forms have no hrow staging: room for more fragments.  The recompute pass (SAVE) takes two more: with 12 the x prefetch
     // registers were spilled right behind their loads (s_waitcnt + scratch_store: the prefetch distance became zero)
-    constexpr int WL = (PRESPLIT && REDUCE) ? (SAVE ? 15 : CTGCN_L8_WL_PLAN) : L8_WL;
+    constexpr int WL = (PRESPLIT && REDUCE) ? (SAVE ? 15 : 12) : L8_WL;
     __shared__ h8v Wl[8][WL][64];
     // per-step form: h_t of the unit's 16 rows in fp32, double buffered by unit parity; the rows leave (LayerNorm, 512-byte stores) at the
     // start of the NEXT unit, two per wave — the staging the kernel pair uses, so the outputs are the pair's bit for bit
@@ -2875,7 +2854,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         if (stager) {
             load_xp();
             stage_xp(0);
-            if (CTGCN_L8_ABLATE != 3) load_xp();
+            load_xp();
         }
         __syncthreads();
         f4v acc0[3] = {zero4, zero4, zero4};
@@ -2917,13 +2896,13 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
             // the planes of the fresh unit after this one (in registers since the last call) go to the other slot; request the one after
             if (stager) {
                 stage_xp(xslot ^ 1);
-                if (CTGCN_L8_ABLATE != 3) load_xp();
+                load_xp();
             }
             xslot ^= 1;
         };
         auto x_products = [&]() {
             x_begin();
-            if (CTGCN_L8_ABLATE != 5 && CTGCN_L8_ABLATE != 9 && CTGCN_L8_ABLATE != 10) {
+            {
             x_chunk(std::integral_constant<int, 0>{}); x_chunk(std::integral_constant<int, 1>{});
             x_chunk(std::integral_constant<int, 2>{}); x_chunk(std::integral_constant<int, 3>{});
             }
@@ -2934,15 +2913,11 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         __syncthreads();                                  // its x_end staged the SECOND fresh unit, which the first unit's x_products reads — every other
                                                           // staging is a barrier ahead of its reader by construction, this one is not (found by
                                                           // tools/stress_group.py: one forward in 1 200 differed in four rows once waves 0-3 alone staged)
-#if CTGCN_L8_PRIO
-        if (wave < 4) __builtin_amdgcn_s_setprio(CTGCN_L8_PRIO);   // A/B: the older wave of each SIMD wins the issue arbitration
-#endif
         int pb = 0, ln_buf = 0, ln_last = -1;
         int cring = 0, ln_ring = 0;                       // ring slots of the running tile and of the one whose rows are about to leave
         const bool has_ln = a.gamma != nullptr;
         auto pending_layernorm = [&]() {
             if (ln_last < 0) return;
-            if (CTGCN_L8_ABLATE == 1) { ln_last = -1; return; }
             if (!stager) { ln_last = -1; return; }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -2977,36 +2952,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                         gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs_n) + *(const f4v *)(&bias_s[g][oc]);
                 }
                 f4v ach[3] = {zero4, zero4, zero4};
-#if CTGCN_L8_HPIPE
-                f4v csc[3], b_hn;
-                auto load_csc = [&]() {
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) csc[g] = *(const f4v *)(&csc_hh[g][oc]);
-                    b_hn = *(const f4v *)(&csc_hh[3][oc]);
-                };
                 if (t > 0) {
-                    // h operand reads two k chunks ahead of the MFMAs that use them (left to the compiler: ONE 4-register buffer, every
-                    // ds_read_b128 followed by s_waitcnt lgkmcnt(0) — seven exposed LDS latencies per unit on the recurrence's critical path)
-                    const int hp = pb ^ 1;                // the buffer step t-1 published into
-                    auto ldh = [&](int pl, int c) { return *(const h8v *)(&Hs[hp][pl][col][l8_off(col, c * 32 + 8 * grp)]); };
-                    h8v a2 = ldh(1, 0), a1 = ldh(0, 0), b2 = ldh(1, 1), b1 = ldh(0, 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    CTGCN_H2_MFMA1(Wh, 0, a1, a2, ach)
-                    __builtin_amdgcn_sched_barrier(0);
-                    a2 = ldh(1, 2); a1 = ldh(0, 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    CTGCN_H2_MFMA1(Wh, 1, b1, b2, ach)
-                    __builtin_amdgcn_sched_barrier(0);
-                    b2 = ldh(1, 3); b1 = ldh(0, 3);
-                    __builtin_amdgcn_sched_barrier(0);
-                    CTGCN_H2_MFMA1(Wh, 2, a1, a2, ach)
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_csc();                           // the gate math's scales: their latency passes under the last nine MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
-                    CTGCN_H2_MFMA1(Wh, 3, b1, b2, ach)
-                } else load_csc();
-#else
-                if (t > 0 && CTGCN_L8_ABLATE != 4 && CTGCN_L8_ABLATE != 9 && CTGCN_L8_ABLATE != 10) {
                     const int hp = pb ^ 1;                // the buffer step t-1 published into
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -3017,26 +2963,16 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 }
                 const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
                 const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
-#endif
                 // the next unit's x·W_ih, if it brings a new x (a repeat keeps gi): this tile's next step, or step 0 of the block's next tile
                 const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + nblk < ntiles;
                 TL_MARK(0)
                 f4v h, rv4, zv4, nv4, an4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-#if CTGCN_L8_ABLATE == 7 || CTGCN_L8_ABLATE == 10
-                    const float rv = ach[0][j] + gi[0][j] + csc[0][j], zv = ach[1][j] + gi[1][j], an = ach[2][j] + b_hn[j], nv = gi[2][j];
-#elif CTGCN_L8_ABLATE == 2
-                    const float rv = fmaf(ach[0][j], csc[0][j], gi[0][j]);
-                    const float zv = fmaf(ach[1][j], csc[1][j], gi[1][j]);
-                    const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
-                    const float nv = fmaf(rv, an, gi[2][j]);
-#else
                     const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], gi[0][j]));
                     const float zv = gru_sigmoid(fmaf(ach[1][j], csc[1][j], gi[1][j]));
                     const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
                     const float nv = gru_tanh(fmaf(rv, an, gi[2][j]));
-#endif
                     h[j] = nv + zv * (hprev[j] - nv);
                     if (SAVE) { rv4[j] = rv; zv4[j] = zv; nv4[j] = nv; an4[j] = an; }
                 }
@@ -3066,11 +3002,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         _Float16 x, y;
-#if CTGCN_L8_ABLATE == 6
-                        x = (_Float16)h[j]; y = x;
-#else
                         h2_split<1>(h[j] * 16384.f, x, y);
-#endif
                         p[j] = x; q[j] = y;
                     }
                     *(h4v *)(&Hs[pb][0][col][l8_off(col, oc)]) = p;
@@ -3085,7 +3017,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 TL_MARK(2)
                 if (next_fresh) x_products();
                 TL_MARK(8)
-                if (CTGCN_L8_ABLATE != 8) __syncthreads();
+                __syncthreads();
                 TL_MARK(4)
 #ifdef CTGCN_LAYER_TIMELINE
                 ++tl[6];
@@ -3258,271 +3190,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer8_h2_group_kernel(const Layer
     const int nblk = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x + 2]);
     const LayerArgs a = table[g];
     gru_layer8_h2_body<true, true, false>(a, bid, nblk);
-}
-
-// ------------------------------------------------------------------------------------------------
-// gru_layer8_h2_pair_kernel: the planes + row plan form of gru_layer8_h2_kernel with TWO 16-row tiles in flight per block and the two waves
-// of every SIMD half a step out of phase (round 4).
-// What bounded the single-tile kernel (profiles/r02_layer_timeline_summary.txt, r03_pmc_gru_layer_row_plan_sq_counters.json): all eight waves
-// are in the same phase at the same time — 72 (36) MFMAs per wave with both waves of a SIMD fighting for its matrix pipe, then gate math
-// with both fighting for the VALU while the matrix pipe idles, then a barrier: matrix pipe busy 35 %, waves waiting 47 %.
-// Here a unit (tile, step) is cut into an M phase (x·W_ih of a fresh unit, h·W_hh: MFMAs only) and a G phase (gate math, h planes out: VALU
-// + LDS only), and a block works on tiles A and B alternately:
-//     slot            4i        4i+1      4i+2      4i+3      4i+4
-//     waves 0-3      M(A,t)    G(A,t)    M(B,t)    G(B,t)    M(A,t+1)       (first wave of every SIMD)
-//     waves 4-7      G(B,t-1)  M(A,t)    G(A,t)    M(B,t)    G(B,t)         (second wave: one slot behind)
-// one barrier per slot.  On every SIMD one wave multiplies while the other does gate math: the matrix pipe runs one wave's stream
-// at full rate, the VALU the other's.  M(X,t+1) needs h_t(X) of all eight waves: written in slots 4i+1 / 4i+2 (A), read from 4i+4 on.
-// The x planes of a tile's next fresh step are staged at the head of the wave's M slot of the OTHER tile (both groups are then past the
-// products that read the old planes); h planes are double buffered by step parity per tile.  Per tile the arithmetic is that of the single-tile
-// kernel, MFMA for MFMA in the same order per accumulator: bit-identical results (tests/test_gpu_agg_split.py).
-// LDS: W_ih residual plane 96 KB + x planes 2 x 8 KB + h planes 2 x 16 KB + scale tables 6 KB = 150 KB.
-// SAVE: training's recompute pass (gates, raw h, pre-LayerNorm sum out, position order; no LayerNorm) — as gru_layer8_h2_kernel<true, true, true>.
-// ------------------------------------------------------------------------------------------------
-template <bool SAVE>
-__device__ __forceinline__ void gru_layer8_h2_pair_body(const LayerArgs &a, const int bid, const int nblk)
-{
-    __shared__ _Float16 Xs[2][2][16][L8_PITCH];          // [tile slot A / B][plane]: x planes of the slot's next fresh unit
-    __shared__ _Float16 Hs[2][2][2][16][L8_PITCH];       // [tile slot][step parity][plane]: h_t·2^14 (after the last step: the summed rows in fp32)
-    __shared__ float xscale[2][16];
-    __shared__ float wsc_ih[3][GRU_H];
-    __shared__ float csc_hh[4][GRU_H];
-    __shared__ float bias_s[3][GRU_H];
-    __shared__ h8v Wl[8][L8_WL][64];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int col = lane & 15, grp = lane >> 4;
-    const int oc = wave * 16 + 4 * grp;
-    const int S = a.steps;
-
-    h8v Wi[2][4][3], Wh[2][4][3];
-    h2_load_weight_tile<1>(a.wih, wave, col, grp, Wi, wsc_ih);
-    h2_load_weight_tile<1>(a.whh, wave, col, grp, Wh, csc_hh);
-#pragma unroll
-    for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                asm volatile("" : "+a"(Wh[sp][c][g]));
-                if (l8_lds_slot(sp, c, g) >= 0) Wl[wave][l8_lds_slot(sp, c, g)][lane] = Wi[sp][c][g];
-                else if (c * 3 + g < 8) asm volatile("" : "+a"(Wi[sp][c][g]));
-            }
-    __syncthreads();
-    for (int i = tid; i < 3 * GRU_H; i += 512) {
-        (&csc_hh[0][0])[i] *= (1.f / 16384.f);
-        (&bias_s[0][0])[i] = a.bias_gi ? a.bias_gi[i] : 0.f;
-    }
-    if (tid < GRU_H) csc_hh[3][tid] = a.bhn ? a.bhn[tid] : 0.f;
-    __syncthreads();
-
-    const int64_t ntiles = (a.rows + 15) / 16;
-    if ((int64_t)bid >= ntiles) return;
-    const int64_t ntl = (ntiles - bid + nblk - 1) / nblk;    // tiles of this block: bid + k nblk, k < ntl; slot A takes the even k, slot B the odd
-    const int64_t npairs = (ntl + 1) / 2;
-    const f4v zero4 = f4v{0.f, 0.f, 0.f, 0.f};
-    const int sr = tid >> 5, sc = (tid & 31) * 4;             // staging role: 16 rows x 32 lanes x 4 halfs per plane
-    auto mask_of = [&](int64_t k) -> uint32_t { return (a.tmask && k < ntl) ? a.tmask[bid + k * nblk] : 0xffffffffu; };
-
-    // ---- x streams: the fresh units of a slot's tiles in order.  Xs[slot] holds the unit the next fresh M phase multiplies, the registers
-    // the one after it (requested one fresh unit ahead)
-    struct XStream { int64_t k; int t; uint32_t mask; h4v q1, q2; float qs; bool consumed; };
-    auto xs_next = [&](XStream &x) {
-        do {
-            if (++x.t >= S) { x.t = 0; x.k += 2; x.mask = mask_of(x.k); }
-        } while (x.k < ntl && !((x.mask >> x.t) & 1));
-    };
-    auto xs_load = [&](XStream &x) {
-        if (x.k < ntl) {
-            const int64_t row = min((bid + x.k * nblk) * 16 + sr, a.rows - 1);
-            const int64_t rs_ = row * S + x.t;
-            x.q1 = *(const h4v *)(a.xp1 + rs_ * GRU_H + sc);
-            x.q2 = *(const h4v *)(a.xp2 + rs_ * GRU_H + sc);
-            x.qs = a.xps[rs_];
-        }
-    };
-    auto xs_stage = [&](XStream &x, int slot) {           // registers -> planes of the slot, then request the fresh unit after it
-        if (x.k < ntl) {
-            if ((tid & 31) == 0) xscale[slot][sr] = x.qs;
-            *(h4v *)(&Xs[slot][0][sr][l8_off(sr, sc)]) = x.q1;
-            *(h4v *)(&Xs[slot][1][sr][l8_off(sr, sc)]) = x.q2;
-        }
-        xs_next(x);
-        xs_load(x);
-        x.consumed = false;
-    };
-    XStream xa{0, 0, mask_of(0), {0, 0, 0, 0}, {0, 0, 0, 0}, 0.f, false}, xb{1, 0, mask_of(1), {0, 0, 0, 0}, {0, 0, 0, 0}, 0.f, false};
-    xs_load(xa);
-    xs_load(xb);
-    xs_stage(xa, 0);
-    xs_stage(xb, 1);
-    __syncthreads();
-
-    // ---- per tile slot state
-    struct Tile { f4v hprev, hsum, gi[3]; int64_t row0; int last; uint32_t mask; int pb; int ln_buf, ln_last; int64_t ln_row0; bool valid; };
-    Tile A{zero4, zero4, {zero4, zero4, zero4}, 0, -1, 0u, 0, 0, -1, 0, false}, B = A;
-    f4v acc0[3] = {zero4, zero4, zero4}, ach[3] = {zero4, zero4, zero4};      // one set: a wave's M and G of a unit are consecutive phases
-    float rs = 0.f;
-
-    auto begin_tile = [&](Tile &T, int64_t k) {
-        T.valid = k < ntl;
-        T.row0 = (bid + k * nblk) * 16;
-        T.last = T.valid ? (int)min((int64_t)16, a.rows - T.row0) - 1 : -1;
-        T.mask = mask_of(k);
-        T.hprev = zero4;
-    };
-    // M phase = up to eight product chunks (x chunks 0-3 of a fresh unit, then h chunks 0-3 of a step > 0), software-pipelined by hand: this
-    // wave is the only one of its SIMD that multiplies during the slot, so nobody covers its LDS latencies — the operand planes of chunk i + 1
-    // are requested before the MFMAs of chunk i, the LDS-resident residual-plane fragments of the next x chunk behind the MFMAs that used the
-    // current ones.  Same MFMAs in the same order per accumulator as the single-tile kernel.
-    auto m_phase = [&](Tile &T, const int slot, const int t, XStream &xst) {
-        if (!T.valid) return;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) { acc0[g] = zero4; ach[g] = zero4; }
-        const bool fresh = (T.mask >> t) & 1;
-        const int hp = T.pb ^ 1;                          // the buffer step t-1 published into
-        auto x_frag = [&](int pl, int c) { return *(const h8v *)(&Xs[slot][pl][col][l8_off(col, c * 32 + 8 * grp)]); };
-        auto h_frag = [&](int pl, int c) { return *(const h8v *)(&Hs[slot][hp][pl][col][l8_off(col, c * 32 + 8 * grp)]); };
-        auto w_frag = [&](int c, int g) { return Wl[wave][l8_lds_slot(1, c, g)][lane]; };
-        h8v b1, b2, n1, n2, wr[3];
-        if (fresh) {
-            rs = xscale[slot][col];
-            b1 = x_frag(0, 0); b2 = x_frag(1, 0);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) wr[g] = w_frag(0, g);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < 3) { n1 = x_frag(0, c + 1); n2 = x_frag(1, c + 1); }
-                else if (t > 0) { n1 = h_frag(0, 0); n2 = h_frag(1, 0); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wi[0][c][g], b2, acc0[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[g], b1, acc0[g], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (c < 3) {
-#pragma unroll
-                    for (int g = 0; g < 3; ++g) wr[g] = w_frag(c + 1, g);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wi[0][c][g], b1, acc0[g], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                b1 = n1; b2 = n2;
-            }
-            xst.consumed = true;
-        } else if (t > 0) {
-            b1 = h_frag(0, 0); b2 = h_frag(1, 0);
-        }
-        if (t > 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < 3) { n1 = h_frag(0, c + 1); n2 = h_frag(1, c + 1); }
-                __builtin_amdgcn_sched_barrier(0);
-                CTGCN_H2_MFMA1(Wh, c, b1, b2, ach)
-                __builtin_amdgcn_sched_barrier(0);
-                b1 = n1; b2 = n2;
-            }
-        }
-    };
-    auto pending_layernorm = [&](Tile &T, const int slot) {
-        if (T.ln_last < 0) return;
-        for (int r = wave * 2; r < wave * 2 + 2; ++r)
-            if (r <= T.ln_last) {
-                const int64_t orow = a.order ? (int64_t)a.order[T.ln_row0 + r] : T.ln_row0 + r;
-                gru_layernorm_row((const float *)&Hs[slot][T.ln_buf][0][0][0] + r * GRU_H, a.out + orow * a.ldo, lane, a.gamma, a.beta, a.eps);
-            }
-        T.ln_last = -1;
-    };
-    auto g_phase = [&](Tile &T, const int slot, const int t) {
-        if (t == 0 && !SAVE) pending_layernorm(T, slot);  // the slot's previous tile: its summed rows were written >= two barriers ago
-        if (!T.valid) return;
-        if ((T.mask >> t) & 1) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                T.gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs) + *(const f4v *)(&bias_s[g][oc]);
-        }
-        const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
-        const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
-        f4v h, rv4, zv4, nv4, an4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float rv = gru_sigmoid(fmaf(ach[0][j], csc[0][j], T.gi[0][j]));
-            const float zv = gru_sigmoid(fmaf(ach[1][j], csc[1][j], T.gi[1][j]));
-            const float an = fmaf(ach[2][j], csc[2][j], b_hn[j]);
-            const float nv = gru_tanh(fmaf(rv, an, T.gi[2][j]));
-            h[j] = nv + zv * (T.hprev[j] - nv);
-            if (SAVE) { rv4[j] = rv; zv4[j] = zv; nv4[j] = nv; an4[j] = an; }
-        }
-        if (SAVE && col <= T.last) {
-            const int64_t e = (T.row0 + col) * S + t;
-            if (a.gates3) {
-                float *gp = a.gates + e * (3 * GRU_H) + oc;
-                *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = an4;
-            } else {
-                float *gp = a.gates + e * (4 * GRU_H) + oc;
-                *(f4v *)gp = rv4; *(f4v *)(gp + GRU_H) = zv4; *(f4v *)(gp + 2 * GRU_H) = nv4; *(f4v *)(gp + 3 * GRU_H) = an4;
-            }
-            *(f4v *)(a.hseq + e * GRU_H + oc) = h;
-        }
-        T.hprev = h;
-        T.hsum = t > 0 ? T.hsum + h : h;
-        if (t + 1 < S) {
-            h4v p, q;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                _Float16 x, y;
-                h2_split<1>(h[j] * 16384.f, x, y);
-                p[j] = x; q[j] = y;
-            }
-            *(h4v *)(&Hs[slot][T.pb][0][col][l8_off(col, oc)]) = p;
-            *(h4v *)(&Hs[slot][T.pb][1][col][l8_off(col, oc)]) = q;
-        } else if (SAVE) {
-            if (col <= T.last) *(f4v *)(a.presum + (T.row0 + col) * GRU_H + oc) = T.hsum;
-        } else {
-            *(f4v *)((float *)&Hs[slot][T.pb][0][0][0] + col * GRU_H + oc) = T.hsum;
-            T.ln_buf = T.pb; T.ln_last = T.last; T.ln_row0 = T.row0;
-        }
-        T.pb ^= 1;
-    };
-
-    // ---- the slot loop.  Waves 4-7 (the second wave of every SIMD) run the SAME sequence one slot behind waves 0-3: one barrier in front
-    // of it instead of one behind it — every wave passes 4 S npairs + 1 barriers
-    if (wave >= 4) __syncthreads();
-    for (int64_t pair = 0; pair < npairs; ++pair) {
-        begin_tile(A, 2 * pair);
-        begin_tile(B, 2 * pair + 1);
-        for (int t = 0; t < S; ++t) {
-            if (xb.consumed) xs_stage(xb, 1);             // slot B's next fresh unit: both groups are past M(B, t-1)
-            m_phase(A, 0, t, xa);
-            __syncthreads();
-            g_phase(A, 0, t);
-            __syncthreads();
-            if (xa.consumed) xs_stage(xa, 0);             // slot A's next fresh unit: both groups are past M(A, t)
-            m_phase(B, 1, t, xb);
-            __syncthreads();
-            g_phase(B, 1, t);
-            __syncthreads();
-        }
-    }
-    if (wave < 4) __syncthreads();
-    if (!SAVE) {
-        pending_layernorm(A, 0);
-        pending_layernorm(B, 1);
-    }
-}
-
-template <bool SAVE>
-__global__ __launch_bounds__(512, 2) void gru_layer8_h2_pair_kernel(const LayerArgs a)
-{
-    gru_layer8_h2_pair_body<SAVE>(a, (int)blockIdx.x, (int)gridDim.x);
-}
-__global__ __launch_bounds__(512, 2) void gru_layer8_h2_pair_group_kernel(const LayerArgs *__restrict__ table, const int32_t *__restrict__ blockmap)
-{
-    const int g = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x]);
-    const int bid = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x + 1]);
-    const int nblk = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x + 2]);
-    const LayerArgs a = table[g];
-    gru_layer8_h2_pair_body<false>(a, bid, nblk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4714,6 +4381,14 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
     return CTGCN_OK;
 }
 
+int32_t ctgcn_compute_units(void)
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    return (int32_t)persistent_cus(cus);
+}
+
 int64_t ctgcn_gru_row_granule(void)
 {
     int dev = 0, cus = 256;
@@ -4891,13 +4566,7 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
     const unsigned nb8 = (unsigned)(nt8 < cus ? nt8 : cus);
     const char *tl_file = timeline_begin(a, nb8, stream);
 #endif
-    if (layer_pair_enabled()) {
-        // two tiles in flight per block: a block wants an even number of tiles and at least two
-        const int64_t nb = nt8 / 2 < cus ? (nt8 / 2 > 0 ? nt8 / 2 : 1) : cus;
-        hipLaunchKernelGGL((gru_layer8_h2_pair_kernel<false>), dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, a);
-    } else {
-        hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
-    }
+    hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
 #ifdef CTGCN_LAYER_TIMELINE
     timeline_end(a, nb8, tl_file, stream);
 #endif
@@ -4936,10 +4605,6 @@ int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidde
     a.timeline = nullptr;
 #endif
     const int64_t nt8 = (rows + 15) / 16;
-    if (layer_pair_enabled()) {
-        const int64_t nb = nt8 / 2 < cus ? (nt8 / 2 > 0 ? nt8 / 2 : 1) : cus;
-        hipLaunchKernelGGL((gru_layer8_h2_pair_kernel<true>), dim3((unsigned)nb), dim3(512), 0, (hipStream_t)stream, a);
-    } else
     hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
@@ -5044,8 +4709,7 @@ int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hid
     const size_t map_off = ((size_t)groups * (sizeof(AggSplitGroup) > sizeof(LayerArgs) ? sizeof(AggSplitGroup) : sizeof(LayerArgs)) + 255) / 256 * 256;
     HIP_TRY(hipMemcpyAsync(tb, host.data(), host.size() * sizeof(LayerArgs), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(tb + map_off, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (layer_pair_enabled()) hipLaunchKernelGGL(gru_layer8_h2_pair_group_kernel, dim3((unsigned)used), dim3(512), 0, st, (const LayerArgs *)tb, (const int32_t *)(tb + map_off));
-    else hipLaunchKernelGGL(gru_layer8_h2_group_kernel, dim3((unsigned)used), dim3(512), 0, st, (const LayerArgs *)tb, (const int32_t *)(tb + map_off));
+    hipLaunchKernelGGL(gru_layer8_h2_group_kernel, dim3((unsigned)used), dim3(512), 0, st, (const LayerArgs *)tb, (const int32_t *)(tb + map_off));
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -857,8 +857,8 @@ def core_diffusion_group_ok(xs, adjs, rnns, norms):
     """The width-128 CoreDiffusion layer of a window's snapshots in ONE aggregation launch + ONE GRU layer launch
     (ctgcn_core_aggregate_split_group_f32 / ctgcn_gru_layer_presplit_group_f32): inference, >= 2 snapshots of a small graph that share
     the node set, no hub rows, every snapshot fit for the per-snapshot split path."""
-    if not group_launch_enabled() or len(xs) < 2 or len(xs) > 200:
-        return False
+    if not group_launch_enabled() or len(xs) < 2 or len(xs) > int(_lib.load().ctgcn_compute_units()):
+        return False          # the grouped GRU launch gives every snapshot at least one block of the persistent grid: longer windows take the per-snapshot path
     n = adjs[0].n
     if n > _GROUP_MAX_NODES:
         return False

@@ -465,6 +465,9 @@ int ctgcn_gru_weight_grad_f32(int64_t rows, int32_t steps, int32_t hidden, const
 /* Rows one wave of persistent blocks covers (rows per block x compute units): callers that split `rows` into
  * chunks should use multiples of this so that every launch keeps all CUs equally busy. */
 int64_t ctgcn_gru_row_granule(void);
+/* Compute units the persistent kernels run one block on (the device's, or the number set with ctgcn_set_persistent_cus): the grouped
+ * launches take at most this many snapshots per call (ctgcn_gru_layer_presplit_group_f32 gives every snapshot at least one block). */
+int32_t ctgcn_compute_units(void);
 
 /*
  * Random-walk corpus (preprocessing/random_walk.py:8-69).  ctgcn_row_cumsum_f32: cumw[e] = inclusive prefix sum of the

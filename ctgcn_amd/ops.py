@@ -519,6 +519,12 @@ def _project_grad(dgi, w_ih, out):
         check(lib.ctgcn_gru_input_grad_f32(dgi.shape[0], 128, 128, ptr(dgi), ptr(w_ih), ptr(out), out.stride(0), _stream()),
               "ctgcn_gru_input_grad_f32")
         return
+    w_t = w_ih.t().contiguous()                    # [d_in, 3h]: the "weight" of out = dgi @ w_t^T (768 KB at d_in = 500, once per call)
+    if linear_split_ok(dgi, w_t) and out.stride(1) == 1:
+        # the 500-wide first layer (layers.py:59 with input_size = hid_dim): the fp32 library GEMM took 1.8 ms per Enron-like snapshot,
+        # 14 % of the training step; split of dgi (0.3 ms) + gemm_h2_panel_kernel (0.45 ms).  Same fp32-accurate arithmetic as the forward.
+        linear_split(dgi, w_t, None, out=out)
+        return
     torch.mm(dgi, w_ih, out=out)
 
 
@@ -740,6 +746,13 @@ def _u32ptr(t, offset=0):
     return None if t is None else t.data_ptr() + 4 * int(offset)
 
 
+_kept_planes = {"bytes": 0, "budget": int(float(_os.environ.get("CTGCN_TRAIN_PLANES_GB", "48")) * (1 << 30))}
+
+
+def _release_planes(nbytes):
+    _kept_planes["bytes"] -= nbytes
+
+
 class _CoreDiffusionFused(torch.autograd.Function):
     """out = LayerNorm(sum_k GRU(relu(cumulative A_k x))_k) with autograd, d_in = hidden = 128.
     forward  = ctgcn_core_aggregate_split_f32 (fp16 planes, row plan) + ctgcn_gru_layer_presplit_f32: exactly the inference path; the planes
@@ -763,13 +776,27 @@ class _CoreDiffusionFused(torch.autograd.Function):
                                                        ptr(plan["order"]) if plan is not None else None,
                                                        ptr(plan["tile_mask"]) if plan is not None else None, _stream()), "ctgcn_gru_layer_presplit_f32")
         ctx.adj, ctx.plan, ctx.eps = adj, plan, eps
-        ctx.save_for_backward(ws, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b)
+        # The planes are what the backward reads (recompute pass, dx / dW_ih kernel).  Keeping them for every layer of a config-5 window is
+        # 132 GB (226 GB peak of 288); beyond a budget of kept bytes (CTGCN_TRAIN_PLANES_GB, default 48) a layer keeps only its INPUT — which
+        # autograd holds anyway as the previous layer's output — and writes the planes again in its backward: the same kernel on the same
+        # input, bit-identical gradients, +1 ms per 1 M-node layer.
+        nbytes = ws.numel()
+        keep = _kept_planes["bytes"] + nbytes <= _kept_planes["budget"]
+        ctx.kept = keep
+        if keep:                                          # accounted for as long as the planes live (freed by the backward, or with a dropped graph)
+            import weakref
+            _kept_planes["bytes"] += nbytes
+            weakref.finalize(ws, _release_planes, nbytes)
+        ctx.save_for_backward(ws if keep else x_d, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         ws, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b = ctx.saved_tensors
+        if not ctx.kept:
+            with torch.cuda.device(ws.device):
+                ws, _ = aggregate_split_planes(ws, ctx.adj, 1, ctx.plan)          # ws was the layer's input x
         adj, plan, eps = ctx.adj, ctx.plan, ctx.eps
         n, K, hid = adj.n, adj.K, w_hh.shape[1]
         dev = ws.device

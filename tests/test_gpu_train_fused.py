@@ -171,3 +171,31 @@ def test_fused_training_with_saturated_update_gate(z_bias):
         # relative to the tensor's largest entry as everywhere else, with an absolute floor: at z = 1.0f every gradient through the GRU is
         # ~1e-10 (the state never moves) and "relative to the largest entry" compares rounding noise with rounding noise
         assert e_new <= max(1e-4 * scale, 3.0 * e_old) + 1e-7, (k, e_new, e_old, scale)
+
+
+def test_planes_are_written_again_beyond_the_memory_budget():
+    """ops._CoreDiffusionFused keeps a layer's operand planes for its backward only while the kept bytes stay under the budget
+    (CTGCN_TRAIN_PLANES_GB); beyond it the backward writes them again from the layer's input: the same kernel on the same input — every
+    gradient bit-identical — and the accounting returns to zero when the graph is gone (also for a forward that never ran its backward)."""
+    import gc
+    from ctgcn_amd import ops
+    adj, _ = _graph(6000, 10, 31, 8)
+    layer = _layer(31)
+    torch.manual_seed(32)
+    x, G = torch.randn(6000, 128), torch.randn(6000, 128)
+    assert ops._kept_planes["bytes"] == 0
+    _, kept = _run(layer, x, adj, G, fused=True)
+    old = ops._kept_planes["budget"]
+    try:
+        ops._kept_planes["budget"] = 0
+        _, again = _run(layer, x, adj, G, fused=True)
+    finally:
+        ops._kept_planes["budget"] = old
+    for k in kept:
+        assert torch.equal(kept[k], again[k]), k
+    dev_layer = layer.to(DEV)
+    out = dev_layer(x.to(DEV).requires_grad_(True), adj)       # a forward whose backward never runs
+    assert ops._kept_planes["bytes"] > 0
+    del out
+    gc.collect()
+    assert ops._kept_planes["bytes"] == 0

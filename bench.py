@@ -542,13 +542,16 @@ def main():
                 res[label] = (statistics.median(times), mk)
             nb = kcore_bytes(n, int(col.numel()))
             ms_k = res["exact"][0]
-            roof_kcore = {"kernel": "kcore_init_kernel + kcore_level_kernel x levels (integer peel, bit-exact core numbers)", "bound": "hbm",
+            roof_kcore = {"kernel": "exact core numbers: kcore_hindex_kernel + kcore_hindex_hub_kernel x ~40 sweeps (local h-index iteration, round 5; "
+                                    "CTGCN_KCORE=peel: one kcore_level_kernel per level, 7.3 ms here); capped at the loader's max_core: the "
+                                    "level-synchronous peel (<= 16 levels).  Integer, bit-exact either way", "bound": "hbm",
                           "achieved": round(nb / (ms_k * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(nb / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                           "algorithmic_bytes": nb, "peel_ms_exact": round(ms_k, 3), "max_core": int(res["exact"][1]),
                           "peel_ms_capped_at_max_core_%d" % max_core: round(res["capped"][0], 3),
                           "snapshot": kc_t, "stored_entries": int(col.numel()),
-                          "note": "includes the host read-back of the level counter every 16 levels; latency-bound (peel depth), not bandwidth-bound"}
+                          "note": "includes the host read-backs of the convergence counters (every 8 sweeps / 16 levels); bound by the number of dependent "
+                                  "sweeps x (launch + a pass over the active vertices), not by bandwidth: profiles/r05_kcore_hindex.txt"}
     # ------------------------------------------------------------------------- the reference's own GPU path on THIS GPU (baseline only)
     torch_rocm = None
     if world == 1 and not use_dist and not args.no_cpu_baseline and not args.train and not args.graph:
@@ -870,6 +873,12 @@ def training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log):
             lambda m: rs(m) * m["fresh"] * (1536.0 + 516.0 + 512.0),
             lambda m: rs(m) * m["fresh"] * 2.0 * 128 * 384 * (3 + 4))
         log("training step: %.1f ms" % ms)
+        if os.environ.get("CTGCN_BENCH_REFERENCE_LOSS", "1") != "0":
+            try:
+                res["reference_loss_batch_step"] = reference_loss_leg(model, x_list, adj_list, first, opt, log)
+            except Exception as exc:
+                res["reference_loss_batch_step"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+                log("reference-loss leg failed: %s" % res["reference_loss_batch_step"]["error"])
         return res
     finally:
         ops.set_launch_timer(None)
@@ -936,6 +945,67 @@ def torch_rocm_baseline(model, x_list, adj_list, W, our_ms, first, log):
                     "nn.LayerNorm on the same GPU" % torch.__version__, max_abs_diff_vs_this_library=err, baseline_only=True)
     log("torch-ROCm baseline: %.2f ms vs %.2f ms (x%.1f), max |diff| %.1e" % (out["ms"], out["this_library_ms"], out["ratio"], err))
     return out
+
+
+def reference_loss_leg(model, x_list, adj_list, first, opt, log):
+    """The reference's REAL training batch (embedding.py:340-352 with metrics.py:38-93): full-graph forward of the window, NegativeSamplingLoss on
+    ONE batch of 2 048 nodes (config/uci.json:21 batch_size; neg_num 20, Q 20) with positives from a random-walk corpus (walk_time 20, walk_length 5, config/uci.json:750-751:
+    preprocessing/random_walk.py:8-69, here ctgcn_walks.hip) + negatives from the node-frequency table, loss.backward().  The reference steps the
+    optimizer once per EPOCH (gradient accumulation over the batches, embedding.py:349-351), so a batch is forward + loss + backward; the
+    optimizer step is timed on its own.  Corpus generation (once per dataset in the reference's preprocessing task) is outside the timed region."""
+    import numpy as np
+    import torch
+    from ctgcn_amd.metrics import NegativeSamplingLoss
+    from ctgcn_amd.walks import negative_table, random_walk_corpus
+    owned = [t for t, a in enumerate(adj_list) if a is not None]
+    n = adj_list[owned[0]].n
+    dev = next(model.parameters()).device
+    t0 = time.perf_counter()
+    pairs, tables = [], []
+    for t in owned:
+        a = adj_list[t]
+        # the snapshot graph = the largest matrix of the k-core list without the + I (every stored entry of the slot-tagged CSR)
+        pr, fr = random_walk_corpus(a.row_ptr, a.col, a.val, walk_length=5, walk_time=20, weighted=True, seed=1000 + t)
+        pairs.append(pr)
+        tables.append(torch.from_numpy(negative_table(fr).astype(np.int32)).to(dev))
+    torch.cuda.synchronize()
+    corpus_s = time.perf_counter() - t0
+    loss_model = NegativeSamplingLoss(pairs, tables, neg_num=20, Q=20, seed=7)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    batch = torch.randperm(n, device=dev, generator=gen)[:2048]
+
+    def one():
+        out = first(model(x_list, adj_list))
+        loss = loss_model([list(out), batch])
+        loss.backward()
+        return loss
+
+    model.zero_grad(set_to_none=True)
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 3
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    ms = 1000.0 * (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(loss).all())
+    for name, prm in model.named_parameters():
+        if prm.grad is not None:
+            assert bool(torch.isfinite(prm.grad).all()), "reference-loss batch: non-finite gradient in %s" % name
+    t0 = time.perf_counter()
+    opt.step()
+    torch.cuda.synchronize()
+    opt_ms = 1000.0 * (time.perf_counter() - t0)
+    model.zero_grad(set_to_none=True)
+    res = {"ms_per_batch": round(ms, 2), "batch_nodes": 2048, "neg_num": 20, "Q": 20, "walk_time": 20, "walk_length": 5, "steps": steps,
+           "loss": float(loss.item()), "optimizer_step_ms": round(opt_ms, 2), "corpus_generation_s": round(corpus_s, 2),
+           "walk_partner_entries": int(sum(p.col.numel() for p in pairs)),
+           "what": "forward of the window + NegativeSamplingLoss on one batch + backward (reference embedding.py:346-348); the optimizer steps once per epoch there"}
+    log("reference-loss batch: %.1f ms (+ optimizer step %.1f ms; corpus %.1f s)" % (ms, opt_ms, corpus_s))
+    return res
 
 
 def cpu_baseline(adj_list, widths, budget_s, log):

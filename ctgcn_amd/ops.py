@@ -746,7 +746,7 @@ def _u32ptr(t, offset=0):
     return None if t is None else t.data_ptr() + 4 * int(offset)
 
 
-_kept_planes = {"bytes": 0, "budget": int(float(_os.environ.get("CTGCN_TRAIN_PLANES_GB", "48")) * (1 << 30))}
+_kept_planes = {"bytes": 0, "budget": int(float(_os.environ.get("CTGCN_TRAIN_PLANES_GB", "32")) * (1 << 30))}
 
 
 def _release_planes(nbytes):
@@ -777,7 +777,7 @@ class _CoreDiffusionFused(torch.autograd.Function):
                                                        ptr(plan["tile_mask"]) if plan is not None else None, _stream()), "ctgcn_gru_layer_presplit_f32")
         ctx.adj, ctx.plan, ctx.eps = adj, plan, eps
         # The planes are what the backward reads (recompute pass, dx / dW_ih kernel).  Keeping them for every layer of a config-5 window is
-        # 132 GB (226 GB peak of 288); beyond a budget of kept bytes (CTGCN_TRAIN_PLANES_GB, default 48) a layer keeps only its INPUT — which
+        # 132 GB (226 GB peak of 288); beyond a budget of kept bytes (CTGCN_TRAIN_PLANES_GB, default 32) a layer keeps only its INPUT — which
         # autograd holds anyway as the previous layer's output — and writes the planes again in its backward: the same kernel on the same
         # input, bit-identical gradients, +1 ms per 1 M-node layer.
         nbytes = ws.numel()

@@ -190,3 +190,20 @@ def test_panel_kernel_edges(rows, k, n_out):
     assert torch.allclose(act, torch.nn.functional.selu(got), rtol=2e-6, atol=1e-7)
     again = ops.linear_split(x, w, b, out=torch.empty(rows, n_out, device=DEV))
     assert torch.equal(again, got)                                    # aligned (16-byte stores) and unaligned outputs: the same values
+
+
+@pytest.mark.parametrize("rows,k,n_out", [(1500, 200, 96), (40_000, 500, 128), (40_000, 500, 500), (300_000, 500, 384)])
+def test_panel_kernel_is_deterministic_under_repetition(rows, k, n_out):
+    """Twenty launches on the same operands, bit for bit — the check that caught the round-5 variant with inline-asm W-fragment loads (wrong
+    128-row panels in one run of ten at n_out <= 128, invisible to a single accuracy test): few panels per block, one k stage per panel,
+    several panels per block, all CUs busy."""
+    from ctgcn_amd import ops
+    torch.manual_seed(rows)
+    x = torch.randn(rows, k, device=DEV)
+    w = torch.randn(n_out, k, device=DEV) / k ** 0.5
+    b = torch.randn(n_out, device=DEV)
+    ref = ops.linear_split(x, w, b)
+    scale = (x.double().abs() @ w.double().abs().t()) + 1e-30
+    assert ((ref.double() - (x.double() @ w.double().t() + b.double())).abs() / scale).max().item() <= 4e-7
+    for _ in range(20):
+        assert torch.equal(ops.linear_split(x, w, b), ref)

@@ -14,7 +14,7 @@ ACT_NONE, ACT_SELU = 0, 1
 OP_KCORE = 1
 OP_INGEST = 2
 MAX_SLOTS = 255
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _c = ctypes
 _vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_int, _c.c_size_t
@@ -22,13 +22,20 @@ _vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uin
 class AggSplitGroup(_c.Structure):
     """ctgcn_agg_split_group_t (include/ctgcn_hip.h)"""
     _fields_ = [("row_ptr", _vp), ("col_idx", _vp), ("val", _vp), ("slot", _vp), ("X", _vp), ("ldx", _i64), ("K", _i32), ("flags", _u32),
-                ("row_order", _vp), ("tile_mask", _vp), ("workspace", _vp), ("workspace_bytes", _sz)]
+                ("row_order", _vp), ("tile_mask", _vp), ("workspace", _vp), ("workspace_bytes", _sz),
+                ("planes1", _vp), ("planes2", _vp), ("scales", _vp), ("tile_base", _vp)]
 
 
 class GruLayerGroup(_c.Structure):
     """ctgcn_gru_layer_group_t (include/ctgcn_hip.h)"""
     _fields_ = [("planes", _vp), ("w_ih", _vp), ("w_hh", _vp), ("bias_gi", _vp), ("b_hn", _vp), ("ln_weight", _vp), ("ln_bias", _vp),
                 ("ln_eps", _c.c_float), ("steps", _i32), ("out", _vp), ("ld_out", _i64), ("row_order", _vp), ("tile_mask", _vp), ("work", _i64)]
+
+
+class GruSeqGroup(_c.Structure):
+    """ctgcn_gru_seq_group_t (include/ctgcn_hip.h)"""
+    _fields_ = [("gi", _vp), ("w_hh", _vp), ("b_hn", _vp), ("ln_weight", _vp), ("ln_bias", _vp), ("ln_eps", _c.c_float), ("steps", _i32),
+                ("out", _vp), ("ld_out", _i64), ("row_order", _vp), ("tile_mask", _vp), ("tile_base", _vp), ("work", _i64)]
 
 
 # name -> (restype, argtypes); must list every symbol include/ctgcn_hip.h declares
@@ -52,6 +59,9 @@ SIGNATURES = {
     "ctgcn_group_table_bytes": (_sz, [_i32]),
     "ctgcn_core_aggregate_split_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
     "ctgcn_gru_layer_presplit_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "ctgcn_transpose_bias_group_f32": (_int, [_i32, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "ctgcn_gru_seq_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "ctgcn_linear_packed_group_f32": (_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _sz, _vp]),
     "ctgcn_gru_bwd_blocks": (_i32, [_i64]),
     "ctgcn_gru_layer_presplit_save_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_bwd_rec_f32": (_int, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),

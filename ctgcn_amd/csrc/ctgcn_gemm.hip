@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(256) void pack_weight_h2_kernel(int32_t n_out, int3
 }
 
 // ------------------------------------------------------------------------------------------------ the GEMM
+struct PanelGroup { const _Float16 *bp; const float *sb, *bias; };
 struct PanelArgs {
     int64_t M;
     int32_t N, Kp;                           // columns of this chunk, padded k
@@ -220,6 +222,10 @@ struct PanelArgs {
     float *y;                                // first column of this chunk
     int64_t ldy;
     int64_t mtiles;
+    // grouped launch (round 5: the projections of a small window's snapshots in ONE launch): the X planes, the row scales and Y hold the rows of all
+    // groups one after the other (every group padded to whole panels), W / column scales / bias are per group: panel -> group, group -> operands
+    const int32_t *panel_group;              // [mtiles] or null (one group: bp / sb / bias above)
+    const struct PanelGroup *groups;
 #ifdef CTGCN_GEMM_TIMELINE
     unsigned long long *timeline;            // diagnostic build: [block][wave 0 / 7][stage < 48][6] s_memtime stamps, see tools/gemm_timeline.py
 #endif
@@ -257,26 +263,39 @@ struct PanelArgs {
 //   * Registers (NT = 3): 96 accumulators + 48 W fragments (two slabs) + 32 X fragments (two row-tile groups) = 176 + addresses; 251 allocated.
 //   * Measured (tools/gemm_bench.py, GEMM alone): 435 180 x 500 x 384 0.55 ms (round 4's 128 x 128 tiles: 0.77), 60 730 x 1 737 x 500 0.27 (0.35),
 //     60 730 x 500 x 500 0.10 (0.15); SQ counters: matrix pipe busy 44 % of the SIMD cycles at the 1.85 GHz the chip holds here, waves parked 40 %.
-template <int NT>
+template <int NT, bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a)
 {
     constexpr int PLANE = PBM * PSK;                      // halfs of one plane of a stage (16 KB)
     __shared__ __attribute__((aligned(1024))) _Float16 As[3][2 * PLANE];      // [slot][plane][row][64 k], 16-byte segment g of row r at g ^ (r & 7)
-    __shared__ __attribute__((aligned(16))) float s_sb[NT * 128];
-    __shared__ __attribute__((aligned(16))) float s_bias[NT * 128];
+    __shared__ __attribute__((aligned(16))) float s_sb[2][NT * 128];          // column scales / bias of the group of the current panel and of the one before
+    __shared__ __attribute__((aligned(16))) float s_bias[2][NT * 128];
     __shared__ __attribute__((aligned(256))) float s_sa[4][PBM];               // row scales of panel count & 3 (four: one k stage per panel leaves no barrier between
                                                                               // a late wave's epilogue reads and an early wave's request for the panel after next)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;        // wave: in an SGPR
     const int nks = a.Kp / PSK, KS = a.Kp / 32;
-    const int64_t stride = gridDim.x;
-    if ((int64_t)blockIdx.x >= a.mtiles) return;
-    const int64_t npan = (a.mtiles - blockIdx.x + stride - 1) / stride;
+    // panels of this block: blockIdx, blockIdx + grid, ... — or, in a grouped launch, a contiguous range (the group changes once or twice
+    // per block instead of with every panel)
+    constexpr bool grouped = GROUPED;
+    const int64_t per_block = (a.mtiles + gridDim.x - 1) / gridDim.x;
+    const int64_t first = grouped ? blockIdx.x * per_block : (int64_t)blockIdx.x;
+    const int64_t stride = grouped ? 1 : (int64_t)gridDim.x;
+    const int64_t pend = grouped ? min(first + per_block, a.mtiles) : a.mtiles;
+    if (first >= pend) return;
+    const int64_t npan = (pend - first + stride - 1) / stride;
     const int64_t total = npan * nks;
 
-    for (int i = tid; i < NT * 128; i += 512) {
-        s_sb[i] = a.sb[i];
-        s_bias[i] = (a.bias && i < a.N) ? a.bias[i] : 0.f;
-    }
+    auto load_scales = [&](int slot_, const float *sb_, const float *bias_) __attribute__((always_inline)) {
+        for (int i = tid; i < NT * 128; i += 512) {
+            s_sb[slot_][i] = sb_[i];
+            s_bias[slot_][i] = (bias_ && i < a.N) ? bias_[i] : 0.f;
+        }
+    };
+    int grp_c = grouped ? a.panel_group[first] : 0;          // group of the panel being multiplied
+    int sslot = 0;                                        // its slot of s_sb / s_bias (the panel before: sslot_prev)
+    int sslot_prev = 0;
+    if (grouped) load_scales(0, a.groups[grp_c].sb, a.groups[grp_c].bias);
+    else load_scales(0, a.sb, a.bias);
 
     // X staging: a wave instruction fills 8 rows x 128 B of one plane linearly (lane l -> row l >> 3, stored segment l & 7), so the lane fetches
     // the segment that belongs there: (l & 7) ^ (row & 7).  32 instructions per stage, four per wave: waves 0-3 plane 1, waves 4-7 plane 2.
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     const int gseg = ((lane & 7) ^ lrow) * 8;
     const uint32_t ldst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) _Float16 *)&As[0][(wave >> 2) * PLANE + rg0 * PSK];
     auto dma1 = [&](int64_t pn, int ksn, int slot, int i) __attribute__((always_inline)) {
-        if ((CTGCN_GEMM_ABLATE & 2) && (pn != (int64_t)blockIdx.x || ksn > 1)) { asm volatile("s_nop 0"); return; }
+        if ((CTGCN_GEMM_ABLATE & 2) && (pn != first || ksn > 1)) { asm volatile("s_nop 0"); return; }
         const int64_t row = min(pn * PBM + rg0 + i * 8 + lrow, a.M - 1);
         const _Float16 *src = aplane + row * a.Kp + ksn * PSK + gseg;
         const uint32_t dst = ldst + (uint32_t)(slot * 2 * PLANE + i * 8 * PSK) * 2u;
@@ -310,10 +329,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     // one 32-bit lane offset: the address costs no vector registers.  Plain loads the compiler tracks: it waits for them (vmcnt) in front of
     // their first MFMA.  (Inline-asm loads with hand-counted waits were built, measured 2-5 % faster — and gave wrong panels in one run of
     // ten at N <= 128, also with every wait at vmcnt(0): removed, profiles/r05_gemm_panel_kernel.txt.)
-    const _Float16 *const bwave = a.bp + (size_t)wave * NT * KS * 1024;
+    const size_t wave_off = (size_t)wave * NT * KS * 1024;
+    const _Float16 *bw_c = (grouped ? a.groups[grp_c].bp : a.bp) + wave_off;         // W fragments of the current panel's group / the next stage's
+    const _Float16 *bw_n = bw_c;
     const uint32_t blane = lane * 16;                     // bytes
     h8v fb[2][NT][2];
-    auto loadB1 = [&](int buf, int s, int q) __attribute__((always_inline)) {         // request q = 2 j + p of slab s
+    auto loadB1 = [&](const _Float16 *bwave, int buf, int s, int q) __attribute__((always_inline)) {         // request q = 2 j + p of slab s
         if ((CTGCN_GEMM_ABLATE & 1) && s > 1) return;
         const int j = q >> 1, p = q & 1;
         fb[buf][j][p] = *(const h8v *)((const char *)(bwave + ((size_t)(j * KS + s) * 2 + p) * 512) + blane);
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     // y = act(acc sa[m] sb[n] + bias[n]): lane l holds columns 4 (l >> 4) .. + 3 of row (l & 15) of every 16 x 16 tile.  A panel that lies
     // inside the matrix (rows) whose wave's columns all exist takes the straight-line path — 8 NT 16-byte stores back to back; with a test
     // around every store the compiler branches around each one and waits for vmcnt(0) in front of it (stores count in vmcnt on gfx9).
-    auto epilogue_as = [&](int64_t pn, int par, int r0, int r1, auto selu, auto whole) __attribute__((always_inline)) {
+    auto epilogue_as = [&](int64_t pn, int par, int ss, int r0, int r1, auto selu, auto whole) __attribute__((always_inline)) {
         const int64_t m0 = pn * PBM;
 #pragma unroll
         for (int r = r0; r < r1; ++r) {
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = (wave * NT + j) * 16 + 4 * (lane >> 4);
-                const f4v sbv = *(const f4v *)&s_sb[n], bv = *(const f4v *)&s_bias[n];
+                const f4v sbv = *(const f4v *)&s_sb[ss][n], bv = *(const f4v *)&s_bias[ss][n];
                 f4v o;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -407,23 +428,23 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         }
     };
     const bool cols_whole = a.vec && (wave * NT + NT) * 16 <= a.N;
-    auto epilogue = [&](int64_t pn, int par, int r0, int r1) __attribute__((always_inline)) {
+    auto epilogue = [&](int64_t pn, int par, int ss, int r0, int r1) __attribute__((always_inline)) {
         const bool whole = cols_whole && (pn + 1) * PBM <= a.M;
         if (a.act == 1) {
-            if (whole) epilogue_as(pn, par, r0, r1, std::true_type{}, std::true_type{});
-            else epilogue_as(pn, par, r0, r1, std::true_type{}, std::false_type{});
+            if (whole) epilogue_as(pn, par, ss, r0, r1, std::true_type{}, std::true_type{});
+            else epilogue_as(pn, par, ss, r0, r1, std::true_type{}, std::false_type{});
         } else {
-            if (whole) epilogue_as(pn, par, r0, r1, std::false_type{}, std::true_type{});
-            else epilogue_as(pn, par, r0, r1, std::false_type{}, std::false_type{});
+            if (whole) epilogue_as(pn, par, ss, r0, r1, std::false_type{}, std::true_type{});
+            else epilogue_as(pn, par, ss, r0, r1, std::false_type{}, std::false_type{});
         }
     };
 
-    int64_t pan_c = blockIdx.x, pan_2 = blockIdx.x;       // the stage being multiplied: (panel, k stage); the stage requested two ahead
+    int64_t pan_c = first, pan_2 = first;                 // the stage being multiplied: (panel, k stage); the stage requested two ahead
     int ks_c = 0, ks_2 = 0, par = 0, slot = 0;             // par: (panels finished so far) & 3
     auto advance = [&](int64_t &pn, int &ks) __attribute__((always_inline)) { if (++ks == nks) { ks = 0; pn += stride; } };
     // prologue: W fragments of stage 0 / slab 0, X lines of stages 0 and 1, the first panel's scales — the request pattern of a stage's slab 1
 #pragma unroll
-    for (int q = 0; q < 2 * NT; ++q) loadB1(0, 0, q);
+    for (int q = 0; q < 2 * NT; ++q) loadB1(bw_c, 0, 0, q);
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma1(pan_2, ks_2, 0, i);
     advance(pan_2, ks_2);
@@ -442,19 +463,27 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         unsigned long long *tl = (a.timeline && it < 48 && (wave == 0 || wave == 7) && lane == 0) ? a.timeline + (((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 48 + it) * 6 : nullptr;
         if (tl) tl[0] = clock64();
 #endif
+        // grouped launch: the next stage's panel may belong to another snapshot (its W), and this stage may be the first of a panel of another
+        // snapshot than the panel before (below: its column scales / bias into the other slot of s_sb — the leaving panel's rows need the old ones)
+        if (grouped && ks_n == 0 && pan_n < pend) bw_n = a.groups[a.panel_group[pan_n]].bp + wave_off;
         // everything requested so far has landed: the W fragments of this stage's slab 0, this wave's share of the X lines of stages it .. it + 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef CTGCN_GEMM_TIMELINE
         if (tl) tl[1] = clock64();
 #endif
         __syncthreads();                                  // the stage is complete for every wave; the slot of stage it - 1 has been read by every wave
+        if (grouped && ks_c == 0 && it > 0) {             // behind the barrier: no wave is still inside the stores that read the slot written here
+            const int g_ = a.panel_group[pan_c];
+            sslot_prev = sslot;
+            if (g_ != grp_c) { grp_c = g_; sslot ^= 1; load_scales(sslot, a.groups[g_].sb, a.groups[g_].bias); }
+        }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef CTGCN_GEMM_TIMELINE
         if (tl) tl[2] = clock64();
 #endif
         auto side0 = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = g * Q0; q < (g + 1) * Q0 && q < 2 * NT; ++q) loadB1(1, ks_c * 2 + 1, q);
+            for (int q = g * Q0; q < (g + 1) * Q0 && q < 2 * NT; ++q) loadB1(bw_c, 1, ks_c * 2 + 1, q);
         };
         // a panel is finished: its rows leave group by group, each right in front of the first products of the NEXT panel into the same
         // accumulators — the stores of rows 32 .. 127 are issued among the MFMAs of rows 0 .. 95 (one block of 8 NT stores in front of
@@ -463,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         const bool leave = ks_c == 0 && it > 0;
         const int64_t pprev = pan_c - stride;
         const int sprev = (par + 3) & 3;
-        slab(slot, 0, 0, [&](int g) __attribute__((always_inline)) { if (leave) epilogue(pprev, sprev, g * RG, g * RG + RG); }, side0);
+        slab(slot, 0, 0, [&](int g) __attribute__((always_inline)) { if (leave) epilogue(pprev, sprev, sslot_prev, g * RG, g * RG + RG); }, side0);
 #ifdef CTGCN_GEMM_TIMELINE
         if (tl) tl[3] = clock64();
 #endif
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         slab(slot, 1, 1, [&](int) __attribute__((always_inline)) {}, [&](int g) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = g * Q1; q < (g + 1) * Q1 && q < 2 * NT + 5; ++q) {
-                if (q < 2 * NT) loadB1(0, ks_n * 2, q);   // the next stage's first slab (past the end: a valid, unused address)
+                if (q < 2 * NT) loadB1(bw_n, 0, ks_n * 2, q);   // the next stage's first slab (past the end: a valid, unused address)
                 else if (q < 2 * NT + 4) dma1(pan_2, ks_2, nslot, q - 2 * NT);       // never conditional (past the end: a valid address, a dead slot)
                 else dma_sa(pan_n, ks_n == 0 ? (par + 1) & 3 : par);                        // the scales of the NEXT stage's panel
             }
@@ -485,13 +514,14 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
 #endif
         advance(pan_2, ks_2);
         if (ks_n == 0) par = (par + 1) & 3;
+        bw_c = bw_n;
         pan_c = pan_n;
         ks_c = ks_n;
         slot = slot == 2 ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue(pan_c - stride, (par + 3) & 3, 0, 8);
+    epilogue(pan_c - stride, (par + 3) & 3, sslot, 0, 8);
 }
 
 int device_cus()
@@ -638,6 +668,48 @@ int ctgcn_linear_packed_f32(int64_t rows, int32_t n_out, int32_t k, const void *
         (void)hipFree(a.timeline);
     }
 #endif
+    GEMM_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_linear_packed_group_f32(int32_t groups, int64_t total_rows, int32_t n_out, int32_t k, const void *planes1, const void *planes2,
+                                  const float *scales, const int32_t *panel_group, const void *const *w_packed, const float *const *bias,
+                                  int32_t activation, float *y, int64_t ldy, void *table, size_t table_bytes, void *stream)
+{
+    if (groups < 1 || groups > 1024 || total_rows < 0 || (total_rows % PBM) || n_out < 1 || n_out > PCHUNK || k < 1 || ldy < n_out)
+        return ctgcn_set_error_(CTGCN_E_INVALID, "linear_packed_group: bad sizes (rows in whole panels of 128, n_out <= 512)");
+    if (activation != CTGCN_ACT_NONE && activation != CTGCN_ACT_SELU) return ctgcn_set_error_(CTGCN_E_INVALID, "linear_packed_group: unknown activation");
+    if (total_rows == 0) return CTGCN_OK;
+    if (!planes1 || !planes2 || !scales || !panel_group || !w_packed || !y || (reinterpret_cast<uintptr_t>(planes1) & 255u) ||
+        (reinterpret_cast<uintptr_t>(planes2) & 255u) || (reinterpret_cast<uintptr_t>(scales) & 255u))
+        return ctgcn_set_error_(CTGCN_E_INVALID, "linear_packed_group: null or misaligned (256 bytes) operand buffers");
+    if (!table || (reinterpret_cast<uintptr_t>(table) & 255u) || table_bytes < (size_t)groups * sizeof(PanelGroup))
+        return ctgcn_set_error_(CTGCN_E_WORKSPACE, "linear_packed_group: table must be 256-byte aligned and hold 24 bytes per group");
+    const PackGeom g = pack_geom(n_out, k);
+    std::vector<PanelGroup> host((size_t)groups);
+    for (int i = 0; i < groups; ++i) {
+        if (!w_packed[i] || (reinterpret_cast<uintptr_t>(w_packed[i]) & 255u))
+            return ctgcn_set_error_(CTGCN_E_INVALID, "linear_packed_group: null or misaligned packed weight");
+        const _Float16 *frags = (const _Float16 *)w_packed[i];
+        host[i] = PanelGroup{frags, (const float *)(frags + g.frag_halfs), bias ? bias[i] : nullptr};
+    }
+    GEMM_TRY(hipMemcpyAsync(table, host.data(), host.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, (hipStream_t)stream));   // pageable: consumed on return
+    PanelArgs a{};
+    a.M = total_rows; a.N = n_out; a.Kp = g.kp;
+    a.a1 = (const _Float16 *)planes1; a.a2 = (const _Float16 *)planes2; a.sa = scales;
+    a.act = activation; a.ldy = ldy; a.y = y;
+    a.vec = (!(ldy & 3) && !(reinterpret_cast<uintptr_t>(y) & 15u)) ? 1 : 0;
+    a.mtiles = total_rows / PBM;
+    a.panel_group = panel_group; a.groups = (const PanelGroup *)table;
+    a.bp = host[0].bp; a.sb = host[0].sb; a.bias = host[0].bias;
+    const int64_t blocks = a.mtiles < device_cus() ? a.mtiles : device_cus();
+    const dim3 grid((unsigned)blocks), blk(512);
+    switch (chunk_nt(n_out)) {
+    case 1: hipLaunchKernelGGL((gemm_h2_panel_kernel<1, true>), grid, blk, 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL((gemm_h2_panel_kernel<2, true>), grid, blk, 0, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL((gemm_h2_panel_kernel<3, true>), grid, blk, 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL((gemm_h2_panel_kernel<4, true>), grid, blk, 0, (hipStream_t)stream, a); break;
+    }
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

@@ -1842,6 +1842,15 @@ __global__ __launch_bounds__(256) void agg_fwd_split32_group_kernel(const AggSpl
     const AggSplitGroup G = table[g];
     agg_fwd_split_body<32, 1, 8>(G.a, G.p1, G.p2, G.scale, kp, residual_scale, (int64_t)(blockIdx.x % (unsigned)blocks_per_group));
 }
+// the same for rows wider than 128 (a whole wave per row; the 500-wide first layer of the shipped configs, GEMM consumer: compact operand rows)
+template <int CH>
+__global__ __launch_bounds__(256) void agg_fwd_split_group_kernel(const AggSplitGroup *__restrict__ table, int32_t blocks_per_group, int32_t kp,
+                                                                  float residual_scale)
+{
+    const int g = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)blocks_per_group));
+    const AggSplitGroup G = table[g];
+    agg_fwd_split_body<64, CH, 8>(G.a, G.p1, G.p2, G.scale, kp, residual_scale, (int64_t)(blockIdx.x % (unsigned)blocks_per_group));
+}
 
 // 8 consecutive fp32 weights, already multiplied by 1/s, -> two fp16x8 fragments
 template <int RS>
@@ -2002,8 +2011,10 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
 // GRU recurrence, fp16x2 arithmetic: gru_seq_x3_kernel with two fp16 planes of h·2^14 (|h| < 1) instead of three bf16
 // planes, W_hh rows scaled individually, 36 instead of 72 MFMAs per 16-row tile and step.  The scale of a product
 // (row scale of W_hh × 2^-14) is folded into the gate pre-activation FMA, so the gate math costs what it did.
+// bid / nblk: this block's index among the nblk blocks that share the work of `a` (the whole grid, or — grouped launch of a window's snapshots,
+// gru_seq_h2_group_kernel — the blocks dealt to this snapshot)
 template <bool REDUCE, bool SAVE>
-__global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
+__device__ __forceinline__ void gru_seq_h2_body(const GruArgs &a, const int bid, const int nblk)
 {
     __shared__ _Float16 Hs[2][2][GRU_BM][PJ_PITCH];
     __shared__ float sbuf_[REDUCE ? 1 : 2][GRU_BM][GRU_PITCH];   // REDUCE: running sum over steps; otherwise fp32 h_t staged for the row-wise
@@ -2028,7 +2039,7 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
     const int64_t ntiles = (a.rows + GRU_BM - 1) / GRU_BM;
     const int gstride = steps * 3 * GRU_H;
 
-    for (int64_t tile_ = blockIdx.x; tile_ < ntiles; tile_ += gridDim.x) {
+    for (int64_t tile_ = bid; tile_ < ntiles; tile_ += nblk) {
         const int64_t tile = ntiles - 1 - tile_;      // newest GI first: the projection kernel wrote the high tiles last
         const int64_t row0 = tile * GRU_BM;
         const int last = (int)min((int64_t)GRU_BM, a.rows - row0) - 1;
@@ -2195,6 +2206,23 @@ __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
             }
         __syncthreads();       // LDS is reused by the next tile
     }
+}
+
+template <bool REDUCE, bool SAVE>
+__global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
+{
+    gru_seq_h2_body<REDUCE, SAVE>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// the recurrences of a small window's snapshots in one launch (round 5: the 500-wide first layer): block -> (snapshot, index among its blocks,
+// their number) from the block map, the snapshot's arguments (its own W_hh, LayerNorm, gi, row plan) from the table; the body is the kernel's
+__global__ __launch_bounds__(512, 2) void gru_seq_h2_group_kernel(const GruArgs *__restrict__ table, const int32_t *__restrict__ blockmap)
+{
+    const int g = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x]);
+    const int bid = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x + 1]);
+    const int nblk = __builtin_amdgcn_readfirstlane(blockmap[3 * blockIdx.x + 2]);
+    const GruArgs a = table[g];
+    gru_seq_h2_body<true, false>(a, bid, nblk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3975,9 +4003,10 @@ __global__ __launch_bounds__(512, 2) void gru_dw_x3_kernel(const DwArgs a)
 // (reference helper.py:161-172 builds the identity, layers.py:95-106 multiplies by it).  One 64 x 64 tile per block through
 // LDS: 256-byte reads along i, 256-byte writes along j, 16 bytes per lane both ways (VEC; otherwise element by element at
 // the edges and for unaligned rows).  HBM-bound: 4 B read + 4 B written per element.
+struct TransposeGroup { const float *w, *bias; float *out; };
 template <bool VEC>
-__global__ __launch_bounds__(256) void transpose_bias_kernel(int64_t n, int d, const float *__restrict__ w, int64_t ldw,
-                                                             const float *__restrict__ bias, float *__restrict__ out, int64_t ldo)
+__device__ __forceinline__ void transpose_bias_body(int64_t n, int d, const float *__restrict__ w, int64_t ldw,
+                                                    const float *__restrict__ bias, float *__restrict__ out, int64_t ldo)
 {
     __shared__ float tile[64][65];                        // [j][i]
     const int tid = threadIdx.x, r = tid >> 4, c4 = (tid & 15) * 4;
@@ -4012,6 +4041,19 @@ __global__ __launch_bounds__(256) void transpose_bias_kernel(int64_t n, int d, c
         else
             for (int q = 0; q < 4; ++q) if (j0 + c4 + q < d) dst[q] = v[q];
     }
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void transpose_bias_kernel(int64_t n, int d, const float *__restrict__ w, int64_t ldw,
+                                                             const float *__restrict__ bias, float *__restrict__ out, int64_t ldo)
+{
+    transpose_bias_body<VEC>(n, d, w, ldw, bias, out, ldo);
+}
+// Linear(I) of every snapshot of a window in one launch: blockIdx.z = snapshot (its own weight, models.py:225-227)
+template <bool VEC>
+__global__ __launch_bounds__(256) void transpose_bias_group_kernel(int64_t n, int d, const TransposeGroup *__restrict__ table, int64_t ldw, int64_t ldo)
+{
+    const TransposeGroup G = table[blockIdx.z];
+    transpose_bias_body<VEC>(n, d, G.w, ldw, G.bias, G.out, ldo);
 }
 
 // final core numbers; with a level cap the unpeeled vertices (current degree >= cap) are reported as `cap`
@@ -4613,45 +4655,141 @@ int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidde
 size_t ctgcn_group_table_bytes(int32_t groups)
 {
     if (groups < 1) return 0;
-    const size_t per = sizeof(AggSplitGroup) > sizeof(LayerArgs) ? sizeof(AggSplitGroup) : sizeof(LayerArgs);
-    return ((size_t)groups * per + 255) / 256 * 256 + 3 * sizeof(int32_t) * 1024;      // + the block map of the layer launch (<= 1024 blocks)
+    size_t per = sizeof(AggSplitGroup) > sizeof(LayerArgs) ? sizeof(AggSplitGroup) : sizeof(LayerArgs);
+    if (sizeof(GruArgs) > per) per = sizeof(GruArgs);
+    return ((size_t)groups * per + 255) / 256 * 256 + 3 * sizeof(int32_t) * 1024;      // + the block map of the persistent launches (<= 1024 blocks)
 }
 
 int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t d, const ctgcn_agg_split_group_t *g, void *table, size_t table_bytes,
                                          void *stream)
 {
     if (groups < 1 || groups > 1024 || !g) return fail(CTGCN_E_INVALID, "core_aggregate_split_group: groups=%d", groups);
-    if (d != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split_group: only d = %d (the GRU layer kernel as consumer) is built", GRU_H);
+    if ((d & 3) || d < 32 || d > 512) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split_group: needs d %% 4 == 0, 32 <= d <= 512 (got %d)", d);
     if (n_rows < 1) return fail(CTGCN_E_INVALID, "core_aggregate_split_group: n_rows=%lld", (long long)n_rows);
     if (!table || (reinterpret_cast<uintptr_t>(table) & 255u) || table_bytes < ctgcn_group_table_bytes(groups))
         return fail(CTGCN_E_WORKSPACE, "core_aggregate_split_group: table must be 256-byte aligned and hold ctgcn_group_table_bytes(groups) bytes");
     std::vector<AggSplitGroup> host((size_t)groups);
     const AggPlan p = plan_for(d, true);
+    const int32_t kp = (d + 63) / 64 * 64;
+    const bool layer_form = d == GRU_H && !g[0].planes1;      // consumer = the GRU layer kernel: planes with holes in the group's own workspace
     for (int i = 0; i < groups; ++i) {
         const ctgcn_agg_split_group_t &q = g[i];
-        if (q.K < 1 || q.K > CTGCN_MAX_SLOTS || !q.row_ptr || !q.X || !q.workspace || (!q.slot && q.K != 1) || q.ldx < d || (q.ldx & 3) || !aligned16(q.X) ||
-            (reinterpret_cast<uintptr_t>(q.workspace) & 255u))
+        if (q.K < 1 || q.K > CTGCN_MAX_SLOTS || !q.row_ptr || !q.X || (!q.slot && q.K != 1) || q.ldx < d || (q.ldx & 3) || !aligned16(q.X))
             return fail(CTGCN_E_INVALID, "core_aggregate_split_group: bad arguments of group %d", i);
         if ((q.row_order == nullptr) != (q.tile_mask == nullptr) || (q.row_order && q.K > 32))
             return fail(CTGCN_E_INVALID, "core_aggregate_split_group: group %d: row_order and tile_mask come together, K <= 32 under a plan", i);
-        if (q.workspace_bytes < ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, q.K, 1, 0))
-            return fail(CTGCN_E_WORKSPACE, "core_aggregate_split_group: workspace of group %d too small", i);
         AggSplitGroup &h = host[i];
         h = AggSplitGroup{};
-        const int64_t rows = n_rows * q.K;
-        h.p1 = (_Float16 *)q.workspace; h.p2 = h.p1 + (size_t)rows * GRU_H; h.scale = (float *)(h.p2 + (size_t)rows * GRU_H);
         AggArgs &a = h.a;
+        if (layer_form) {
+            if (!q.workspace || (reinterpret_cast<uintptr_t>(q.workspace) & 255u) || q.planes1 || q.tile_base)
+                return fail(CTGCN_E_INVALID, "core_aggregate_split_group: group %d: the layer-kernel form takes a workspace per group and no tile_base", i);
+            if (q.workspace_bytes < ctgcn_core_aggregate_split_workspace_bytes(n_rows, d, q.K, 1, 0))
+                return fail(CTGCN_E_WORKSPACE, "core_aggregate_split_group: workspace of group %d too small", i);
+            const int64_t rows = n_rows * q.K;
+            h.p1 = (_Float16 *)q.workspace; h.p2 = h.p1 + (size_t)rows * GRU_H; h.scale = (float *)(h.p2 + (size_t)rows * GRU_H);
+            a.tbase = nullptr; a.tile_shift = 4;
+        } else {
+            // consumer = the split GEMM: the group's operand rows sit at [first_row, first_row + operand_rows) of planes SHARED by the window
+            // (planes1 / planes2 / scales point at the group's first row) so that ONE grouped GEMM launch walks all of them; a row plan makes
+            // them compact (tile 64: tile_base), without one every (node, core) row is written
+            if (!q.planes1 || !q.planes2 || !q.scales || (reinterpret_cast<uintptr_t>(q.planes1) & 15u) || (reinterpret_cast<uintptr_t>(q.planes2) & 15u))
+                return fail(CTGCN_E_INVALID, "core_aggregate_split_group: group %d: the GEMM form takes planes1 / planes2 / scales", i);
+            if ((q.row_order != nullptr) != (q.tile_base != nullptr))
+                return fail(CTGCN_E_INVALID, "core_aggregate_split_group: group %d: the GEMM form's row plan comes with tile_base", i);
+            h.p1 = (_Float16 *)q.planes1; h.p2 = (_Float16 *)q.planes2; h.scale = q.scales;
+            a.tbase = q.tile_base; a.tile_shift = q.tile_base ? 6 : 4;
+        }
         a.n = n_rows; a.d = d; a.K = q.K; a.row_ptr = q.row_ptr; a.col = q.col_idx; a.val = q.val; a.slot = q.slot;
         a.src = q.X; a.ldsrc = q.ldx; a.out = nullptr; a.out_ld = (int64_t)q.K * d; a.flags = q.flags;
         a.n_long = 0; a.long_thresh = 0x7fffffff;          // hub rows are the caller's business (none in the windows this serves)
-        a.order = q.row_order; a.tmask = q.tile_mask; a.tbase = nullptr; a.tile_shift = 4;
+        a.order = q.row_order; a.tmask = q.tile_mask;
         a.chunks = p.chunks; a.passes = p.passes; a.hub_split = 1;
     }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(table, host.data(), host.size() * sizeof(AggSplitGroup), hipMemcpyHostToDevice, st));
-    const int64_t bpg = (n_rows + 7) / 8;
+    const int rows_per_block = p.chunks <= 32 ? 8 : 4;
+    const int64_t bpg = (n_rows + rows_per_block - 1) / rows_per_block;
     if (bpg * groups > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split_group: grid too large");
-    hipLaunchKernelGGL(agg_fwd_split32_group_kernel, dim3((unsigned)(bpg * groups)), dim3(256), 0, st, (const AggSplitGroup *)table, (int32_t)bpg, GRU_H, 1.f);
+    const dim3 grid((unsigned)(bpg * groups));
+    if (p.chunks <= 32) hipLaunchKernelGGL(agg_fwd_split32_group_kernel, grid, dim3(256), 0, st, (const AggSplitGroup *)table, (int32_t)bpg, kp, 1.f);
+    else if (p.chunks <= 64) hipLaunchKernelGGL(agg_fwd_split_group_kernel<1>, grid, dim3(256), 0, st, (const AggSplitGroup *)table, (int32_t)bpg, kp, 1.f);
+    else hipLaunchKernelGGL(agg_fwd_split_group_kernel<2>, grid, dim3(256), 0, st, (const AggSplitGroup *)table, (int32_t)bpg, kp, 1.f);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_transpose_bias_group_f32(int32_t groups, int64_t n, int32_t d, const float *const *w, int64_t ldw, const float *const *bias, float *const *out,
+                                   int64_t ldo, void *table, size_t table_bytes, void *stream)
+{
+    if (groups < 1 || groups > 1024 || n < 1 || d < 1 || ldw < n || ldo < d || !w || !out) return fail(CTGCN_E_INVALID, "transpose_bias_group: bad arguments");
+    if (!table || (reinterpret_cast<uintptr_t>(table) & 255u) || table_bytes < ctgcn_group_table_bytes(groups))
+        return fail(CTGCN_E_WORKSPACE, "transpose_bias_group: table must be 256-byte aligned and hold ctgcn_group_table_bytes(groups) bytes");
+    std::vector<TransposeGroup> host((size_t)groups);
+    bool vec = !(ldw & 3) && !(ldo & 3);
+    for (int i = 0; i < groups; ++i) {
+        if (!w[i] || !out[i]) return fail(CTGCN_E_INVALID, "transpose_bias_group: null pointer in group %d", i);
+        host[i] = TransposeGroup{w[i], bias ? bias[i] : nullptr, out[i]};
+        vec = vec && aligned16(w[i]) && aligned16(out[i]);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(table, host.data(), host.size() * sizeof(TransposeGroup), hipMemcpyHostToDevice, st));      // pageable source: consumed on return
+    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((d + 63) / 64), (unsigned)groups);
+    if (vec) hipLaunchKernelGGL(transpose_bias_group_kernel<true>, grid, dim3(256), 0, st, n, d, (const TransposeGroup *)table, ldw, ldo);
+    else hipLaunchKernelGGL(transpose_bias_group_kernel<false>, grid, dim3(256), 0, st, n, d, (const TransposeGroup *)table, ldw, ldo);
+    HIP_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_gru_seq_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_seq_group_t *g, void *table, size_t table_bytes, void *stream)
+{
+    if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq_group: only hidden = %d is built (got %d)", GRU_H, hidden);
+    if (groups < 1 || groups > 1024 || !g || rows < 1) return fail(CTGCN_E_INVALID, "gru_seq_group: groups=%d rows=%lld", groups, (long long)rows);
+    if (!table || (reinterpret_cast<uintptr_t>(table) & 255u) || table_bytes < ctgcn_group_table_bytes(groups))
+        return fail(CTGCN_E_WORKSPACE, "gru_seq_group: table must be 256-byte aligned and hold ctgcn_group_table_bytes(groups) bytes");
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = persistent_cus(cus);
+    if (cus > 1024) cus = 1024;
+    if (groups > cus) return fail(CTGCN_E_UNSUPPORTED, "gru_seq_group: more snapshots (%d) than CUs (%d): split the window", groups, cus);
+    std::vector<GruArgs> host((size_t)groups);
+    const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
+    double total = 0.0;
+    for (int i = 0; i < groups; ++i) {
+        const ctgcn_gru_seq_group_t &q = g[i];
+        if (q.steps < 1 || !q.gi || !q.w_hh || !q.out || !aligned16(q.gi) || !aligned16(q.w_hh) || (reinterpret_cast<uintptr_t>(q.out) & 7u) ||
+            (q.ld_out > 0 && (q.ld_out < GRU_H || (q.ld_out & 1))) || (q.row_order == nullptr) != (q.tile_mask == nullptr) ||
+            (q.row_order == nullptr) != (q.tile_base == nullptr) || (q.row_order && q.steps > 32))
+            return fail(CTGCN_E_INVALID, "gru_seq_group: bad arguments of group %d", i);
+        GruArgs &a = host[i];
+        a = GruArgs{};
+        a.rows = rows; a.steps = q.steps; a.gi = q.gi; a.whh = q.w_hh; a.bhn = q.b_hn; a.gamma = q.ln_weight; a.beta = q.ln_bias; a.eps = q.ln_eps;
+        a.reduce_sum = 1; a.out = q.out; a.gates = nullptr; a.gi_blocked = 0; a.ldo = q.ld_out > 0 ? q.ld_out : GRU_H;
+        a.order = q.row_order; a.tmask = q.tile_mask; a.tbase = q.tile_base;
+        total += q.work > 0 ? (double)q.work : 1.0;
+    }
+    std::vector<int32_t> nb((size_t)groups), map;
+    int64_t used = 0;
+    for (int i = 0; i < groups; ++i) {
+        const double w = g[i].work > 0 ? (double)g[i].work : 1.0;
+        int64_t b = (int64_t)(w / total * (cus - groups)) + 1;
+        if (b > ntiles) b = ntiles;
+        nb[i] = (int32_t)b;
+        used += b;
+    }
+    map.reserve((size_t)used * 3);
+    for (int32_t b = 0, more = 1; more; ++b) {
+        more = 0;
+        for (int i = 0; i < groups; ++i)
+            if (b < nb[i]) { map.push_back(i); map.push_back(b); map.push_back(nb[i]); more = 1; }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    char *tb = (char *)table;
+    const size_t map_off = ctgcn_group_table_bytes(groups) - 3 * sizeof(int32_t) * 1024;
+    HIP_TRY(hipMemcpyAsync(tb, host.data(), host.size() * sizeof(GruArgs), hipMemcpyHostToDevice, st));            // pageable sources: consumed on return
+    HIP_TRY(hipMemcpyAsync(tb + map_off, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(gru_seq_h2_group_kernel, dim3((unsigned)used), dim3(512), 0, st, (const GruArgs *)tb, (const int32_t *)(tb + map_off));
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }
@@ -4706,7 +4844,10 @@ int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hid
     }
     hipStream_t st = (hipStream_t)stream;
     char *tb = (char *)table;
-    const size_t map_off = ((size_t)groups * (sizeof(AggSplitGroup) > sizeof(LayerArgs) ? sizeof(AggSplitGroup) : sizeof(LayerArgs)) + 255) / 256 * 256;
+    const size_t map_off = ctgcn_group_table_bytes(groups) - 3 * sizeof(int32_t) * 1024;
+    // `host` / `map` are function-local PAGEABLE vectors: a host-to-device hipMemcpyAsync from pageable memory has consumed its source when it
+    // returns (the runtime stages it; documented HIP behaviour), so they may die with this frame — the price is that the call is not
+    // captured into a hipGraph (ops.group_launch_enabled) and that the host waits for the staging (a few KB).
     HIP_TRY(hipMemcpyAsync(tb, host.data(), host.size() * sizeof(LayerArgs), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(tb + map_off, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(gru_layer8_h2_group_kernel, dim3((unsigned)used), dim3(512), 0, st, (const LayerArgs *)tb, (const int32_t *)(tb + map_off));

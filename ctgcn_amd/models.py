@@ -229,6 +229,43 @@ class CTGCN(nn.Module):
                 break
         return g0 if g0 < L else None
 
+    _HEAD_GROUP_MAX = 120_000      # nodes x snapshots up to which the first layer runs as grouped launches
+
+    def _grouped_head(self, x_list, adj_list, seq):
+        """(first-layer outputs, MLP outputs) of every snapshot with the first CoreDiffusion layer (d_in != 128) of the window in one
+        launch per kernel (ops.core_diffusion_wide_group), or None when the window does not fit that path.  The MLPs in front: one transpose
+        launch when every snapshot's is a single Linear on one-hot features without activation, else per snapshot.
+        Only for the smallest windows (nodes x snapshots <= _HEAD_GROUP_MAX; CTGCN_GROUP_HEAD=1 / 0 forces / forbids it): measured
+        (profiles/r05_group_head.txt) AS-like 1.87 -> 1.32 ms per window, math-like 4.70 -> 5.01, Enron-like 14.5 -> 15.4 — at 0.2 - 0.5 ms
+        per kernel the per-snapshot launches on two lanes overlap one snapshot's HBM-bound aggregation with another's GEMM and recurrence,
+        which one launch per kernel cannot (neither can two half-window groups on two lanes: every launch already fills all CUs)."""
+        from . import ops
+        from .layers import as_core_adj, _is_identity
+        T = len(x_list)
+        dev = seq.device
+        mods = [self.duffision_list[t].diffusion_list[0] for t in range(T)]
+        if any(m.input_dim == 128 or m.output_dim != 128 for m in mods) or not ops.group_launch_enabled():
+            return None
+        adjs = [as_core_adj(adj_list[t], dev) for t in range(T)]
+        env = os.environ.get("CTGCN_GROUP_HEAD")
+        if env == "0" or (env != "1" and adjs[0].n * T > self._HEAD_GROUP_MAX):
+            return None
+        mlps = [self.mlp_list[t] for t in range(T)]
+        one_hot = all(m.layer_num == 1 and m.activate_type == 'L' and torch.is_tensor(x) and x.is_sparse and x.is_cuda and _is_identity(x)
+                      for m, x in zip(mlps, x_list))
+        ws, bs = [m.linear.weight for m in mlps] if one_hot else None, [m.linear.bias for m in mlps] if one_hot else None
+        if one_hot and ops.linear_of_identity_group_ok(ws, bs):
+            trans = ops.linear_of_identity_group(ws, bs)
+        else:
+            trans = [mlps[t](x_list[t]) for t in range(T)]
+        rnns, norms = [m.rnn for m in mods], [m.norm for m in mods]
+        if ops.core_diffusion_wide_group_ok(trans, adjs, rnns, norms):
+            outs = [torch.empty(trans[t].shape[0], self.output_dim, dtype=trans[t].dtype, device=dev) for t in range(T)]
+            ops.core_diffusion_wide_group(trans, adjs, rnns, norms, outs)
+        else:
+            outs = [mods[t](trans[t], adjs[t]) for t in range(T)]
+        return outs, trans
+
     def _grouped_layers(self, g0, hs, adj_list, seq):
         """CoreDiffusion layers g0 .. of every snapshot, one aggregation launch + one GRU launch per layer for the whole window (reference
         models.py:243-247 loops over the snapshots); the last layer writes column t of the temporal GRU's input."""
@@ -267,7 +304,12 @@ class CTGCN(nn.Module):
             seq = torch.empty(n, T, self.output_dim, dtype=p0.dtype, device=p0.device)
         lanes = self._snapshot_streams(seq, n if seq is not None else 0, T, x_list)
         g0 = self._group_start(adj_list, T) if (seq is not None and seq.is_cuda) else None
-        if g0 is not None:
+        grouped_head = self._grouped_head(x_list, adj_list, seq) if g0 == 1 else None
+        if grouped_head is not None:
+            # small 'C' window: Linear(I), then the 500-wide first layer of ALL snapshots in one launch per kernel, then the width-128 layers
+            hx, trans = grouped_head
+            self._grouped_layers(g0, hx, adj_list, seq)
+        elif g0 is not None:
             # small window: the MLP and the layers before g0 per snapshot (on the lanes), then the width-128 layers of ALL snapshots per launch
             def head(t):
                 tr = self.mlp_list[t](x_list[t])

@@ -949,6 +949,149 @@ def core_diffusion_split_group(xs, adjs, rnns, norms, outs):
     return outs
 
 
+def core_diffusion_wide_group_ok(xs, adjs, rnns, norms):
+    """The first CoreDiffusion layer (d_in != 128: the 500-wide GRU input of the 'C' configs, layers.py:59) of a window's snapshots in one
+    launch per kernel — aggregation into operand planes shared by the window, ONE panel GEMM over all snapshots' rows, one recurrence launch:
+    the conditions of core_diffusion_group_ok with the split GEMM (packed weights) as consumer."""
+    if not group_launch_enabled() or len(xs) < 2 or len(xs) > int(_lib.load().ctgcn_compute_units()):
+        return False
+    if forward_split_mode() != 2 or not plane_cache_enabled():
+        return False
+    n, d = adjs[0].n, xs[0].shape[1] if xs[0].dim() == 2 else 0
+    if n > _GROUP_MAX_NODES or d == 128:
+        return False
+    planned = None
+    for x, adj, rnn, norm in zip(xs, adjs, rnns, norms):
+        if adj.n != n or x.dim() != 2 or x.shape[1] != d or rnn.hidden_size != 128 or not aggregate_split_ok(rnn, x, adj):
+            return False
+        if adj.K > 32 or adj.long_rows() is not None or not isinstance(norm, torch.nn.LayerNorm) or norm.weight is None or norm.bias is None:
+            return False
+        p = (adj.row_plan(adj.PLAN_TILE_GEMM) is not None) if row_plan_enabled() else False
+        if planned is None:
+            planned = p
+        if p != planned:
+            return False
+    return True
+
+
+_panel_group_cache = {}
+
+
+def _panel_groups(padded, dev):
+    """int32 [sum(padded) / 128] on the device: the group of every 128-row panel of the shared operand planes (a function of the graphs'
+    row counts only: built once per window shape)"""
+    key = (str(dev), tuple(padded))
+    hit = _panel_group_cache.get(key)
+    if hit is None:
+        if len(_panel_group_cache) > 64:
+            _panel_group_cache.clear()
+        counts = torch.tensor([p // 128 for p in padded], dtype=torch.int64)
+        hit = _panel_group_cache[key] = torch.repeat_interleave(torch.arange(len(padded), dtype=torch.int32), counts).to(dev)
+    return hit
+
+
+def core_diffusion_wide_group(xs, adjs, rnns, norms, outs):
+    """outs[t] = LayerNorm(sum_k GRU_t(relu(cumulative A_{t,k} xs[t]))_k) for every snapshot t — core_diffusion_split(d_in != 128) per snapshot,
+    as three launches for the whole window (reference models.py:243-247 loops over the snapshots).  The operand rows of all snapshots (compact
+    under the row plans, every snapshot padded to whole 128-row panels) share one pair of planes and one gi buffer.  Bit-identical to the
+    per-snapshot calls: the same kernels' code per row."""
+    lib = _lib.load()
+    T = len(xs)
+    n, d = xs[0].shape
+    dev = xs[0].device
+    hid, n_out = 128, 384
+    kp = -(-d // 64) * 64
+    use_plan = row_plan_enabled()
+    plans = [adj.row_plan(adj.PLAN_TILE_GEMM) if use_plan else None for adj in adjs]
+    rows = [(pl["operand_rows"] if pl is not None else n * adj.K) for pl, adj in zip(plans, adjs)]
+    padded = [-(-r // 128) * 128 for r in rows]
+    first = [0] * T
+    for t in range(1, T):
+        first[t] = first[t - 1] + padded[t - 1]
+    total = first[-1] + padded[-1]
+    agg = (_lib.AggSplitGroup * T)()
+    seq = (_lib.GruSeqGroup * T)()
+    w_arr, b_arr = (ctypes.c_void_p * T)(), (ctypes.c_void_p * T)()
+    keep = []
+    with torch.cuda.device(dev):
+        p1 = torch.empty(total * kp, dtype=torch.float16, device=dev)
+        p2 = torch.empty(total * kp, dtype=torch.float16, device=dev)
+        sc = torch.empty(total, dtype=torch.float32, device=dev)
+        gi = torch.empty(total, n_out, dtype=torch.float32, device=dev)
+        pg = _panel_groups(padded, dev)
+        tb_bytes = int(lib.ctgcn_group_table_bytes(T))
+        table = torch.empty(tb_bytes, dtype=torch.uint8, device=dev)
+        for t, (x, adj, rnn, norm, out, plan) in enumerate(zip(xs, adjs, rnns, norms, outs, plans)):
+            K = adj.K
+            bias, b_hn = _gru_bias(rnn, hid)
+            w_hh = rnn.weight_hh_l0.detach().contiguous()
+            wp = _plane_cache.packed(rnn.weight_ih_l0, lib)
+            keep.append((bias, b_hn, w_hh, wp, x))
+            a = agg[t]
+            a.row_ptr, a.col_idx, a.val, a.slot = ptr(adj.row_ptr), ptr(adj.col), ptr(adj.val), ptr(adj.slot)
+            a.X, a.ldx, a.K, a.flags = ptr(x), x.stride(0), K, adj.flags | _lib.F_RELU
+            a.row_order = ptr(plan["order"]) if plan is not None else None
+            a.tile_mask = ptr(plan["tile_mask"]) if plan is not None else None
+            a.tile_base = ptr(plan["tile_base"]) if plan is not None else None
+            a.workspace, a.workspace_bytes = None, 0
+            a.planes1 = ctypes.c_void_p(p1.data_ptr() + first[t] * kp * 2)
+            a.planes2 = ctypes.c_void_p(p2.data_ptr() + first[t] * kp * 2)
+            a.scales = ctypes.c_void_p(sc.data_ptr() + first[t] * 4)
+            w_arr[t], b_arr[t] = wp.data_ptr(), (bias.data_ptr() if bias is not None else None)
+            g = seq[t]
+            g.gi, g.w_hh, g.b_hn = ctypes.c_void_p(gi.data_ptr() + first[t] * n_out * 4), ptr(w_hh), ptr(b_hn)
+            g.ln_weight, g.ln_bias, g.ln_eps, g.steps = ptr(norm.weight), ptr(norm.bias), float(norm.eps), K
+            g.out, g.ld_out = ptr(out), out.stride(0)
+            g.row_order, g.tile_mask, g.tile_base = a.row_order, a.tile_mask, a.tile_base
+            g.work = n * K + rows[t]
+        nnz = sum(adj.nnz for adj in adjs)
+        Kmax = max(adj.K for adj in adjs)
+        with _timed("agg_fwd", n=n, d=d, K=Kmax, nnz=nnz, split=True, group=T, rows_written=sum(rows), K_sum=sum(adj.K for adj in adjs)):
+            check(lib.ctgcn_core_aggregate_split_group_f32(T, n, d, agg, ptr(table), tb_bytes, _stream()), "ctgcn_core_aggregate_split_group_f32")
+        with _timed("linear_split", rows=total, k=d, n_out=n_out, presplit=True, group=T):
+            check(lib.ctgcn_linear_packed_group_f32(T, total, n_out, d, ptr(p1), ptr(p2), ptr(sc), ptr(pg), w_arr, b_arr, _lib.ACT_NONE, ptr(gi), n_out,
+                                                    ptr(table), tb_bytes, _stream()), "ctgcn_linear_packed_group_f32")
+        with _timed("gru_seq", rows=n, steps=Kmax, group=T, row_steps=sum(n * adj.K for adj in adjs)):
+            check(lib.ctgcn_gru_seq_group_f32(T, n, hid, seq, ptr(table), tb_bytes, _stream()), "ctgcn_gru_seq_group_f32")
+    del keep
+    return outs
+
+
+def linear_of_identity_group(weights, biases):
+    """[W_t^T + b_t for t] — nn.Linear applied to one-hot features (helper.py:161-172 with x = I, layers.py:95-106) for every snapshot of a
+    window in ONE transpose launch (inference; weights [d, n] fp32 of one shape and stride)."""
+    lib = _lib.load()
+    T = len(weights)
+    d, n = weights[0].shape
+    dev = weights[0].device
+    ws = [w.detach() for w in weights]
+    outs = [torch.empty(n, d, dtype=torch.float32, device=dev) for _ in range(T)]
+    w_arr, o_arr = (ctypes.c_void_p * T)(*[w.data_ptr() for w in ws]), (ctypes.c_void_p * T)(*[o.data_ptr() for o in outs])
+    has_bias = all(b is not None for b in biases)
+    b_arr = (ctypes.c_void_p * T)(*[b.detach().data_ptr() for b in biases]) if has_bias else None
+    with torch.cuda.device(dev):
+        tb_bytes = int(lib.ctgcn_group_table_bytes(T))
+        table = torch.empty(tb_bytes, dtype=torch.uint8, device=dev)
+        with _timed("transpose_bias", n=n, d=d, group=T):
+            check(lib.ctgcn_transpose_bias_group_f32(T, n, d, w_arr, ws[0].stride(0), b_arr, o_arr, d, ptr(table), tb_bytes, _stream()),
+                  "ctgcn_transpose_bias_group_f32")
+    return outs
+
+
+def linear_of_identity_group_ok(weights, biases):
+    if not group_launch_enabled() or len(weights) < 2 or len(weights) > 1024:
+        return False
+    w0 = weights[0]
+    none = biases[0] is None
+    for w, b in zip(weights, biases):
+        if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.shape == w0.shape and w.stride() == w0.stride() and w.stride(1) == 1
+                and w.device == w0.device):
+            return False
+        if (b is None) != none or (b is not None and not (b.is_cuda and b.dtype == torch.float32 and b.is_contiguous())):
+            return False
+    return True
+
+
 def _accumulate_tn(out, a2d, b2d):
     """out[M,N] += a2d[R,M]^T @ b2d[R,N] for R >> M,N (weight gradients: R = rows*steps).  A plain TN GEMM with a
     384x128 output only fills a few dozen workgroups; splitting R into S batches (strided batched GEMM, no copies)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 25
+#define CTGCN_ABI_VERSION 26
 
 enum {
     CTGCN_OK = 0,
@@ -325,8 +325,15 @@ typedef struct {
     uint32_t flags;
     const int32_t *row_order;      /* row plan (both or neither), as ctgcn_core_aggregate_split_f32 */
     const uint32_t *tile_mask;
-    void *workspace;               /* planes + row scales: ctgcn_core_aggregate_split_workspace_bytes(n_rows, 128, K, 1, 0) bytes, 256-byte aligned */
+    void *workspace;               /* d = 128, consumer = the GRU layer kernel: planes + row scales of the group,
+                                      ctgcn_core_aggregate_split_workspace_bytes(n_rows, 128, K, 1, 0) bytes, 256-byte aligned (planes1 = NULL) */
     size_t workspace_bytes;
+    /* consumer = the split GEMM (round 5: the 500-wide first layer, any d <= 512): the group's operand rows inside planes SHARED by the window —
+     * pointers to the group's first row of plane 1 / plane 2 (row length = d rounded up to 64 halfs) and of the scales; with a row plan the
+     * rows are compact (tile 64) and tile_base gives each tile's first row RELATIVE to the group's first row */
+    void *planes1, *planes2;
+    float *scales;
+    const int32_t *tile_base;
 } ctgcn_agg_split_group_t;
 typedef struct {
     const void *planes;            /* the group's aggregation workspace */
@@ -339,7 +346,25 @@ typedef struct {
     const uint32_t *tile_mask;
     int64_t work;                  /* relative cost (e.g. (position, step) rows that bring a new x + rows x steps); <= 0: equal shares */
 } ctgcn_gru_layer_group_t;
+typedef struct {
+    const float *gi;               /* gate pre-activations of the group's (compact) operand rows, [rows, 384] */
+    const float *w_hh, *b_hn, *ln_weight, *ln_bias;
+    float ln_eps;
+    int32_t steps;
+    float *out;
+    int64_t ld_out;
+    const int32_t *row_order;      /* the aggregation's row plan (tile 64): all three or none */
+    const uint32_t *tile_mask;
+    const int32_t *tile_base;
+    int64_t work;
+} ctgcn_gru_seq_group_t;
 size_t ctgcn_group_table_bytes(int32_t groups);
+/* Round 5, the 500-wide first CoreDiffusion layer of a small window in one launch per kernel (reference models.py:243-247 loops over the
+ * snapshots): Linear(I) = W^T + b of every snapshot; the aggregation into shared operand planes (ctgcn_agg_split_group_t, GEMM form);
+ * ctgcn_linear_packed_group_f32 (one panel GEMM over all snapshots' rows, weights per snapshot); the recurrences. */
+int ctgcn_transpose_bias_group_f32(int32_t groups, int64_t n, int32_t d, const float *const *w, int64_t ldw, const float *const *bias, float *const *out,
+                                   int64_t ldo, void *table, size_t table_bytes, void *stream);
+int ctgcn_gru_seq_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_seq_group_t *g, void *table, size_t table_bytes, void *stream);
 int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t d, const ctgcn_agg_split_group_t *g, void *table, size_t table_bytes,
                                          void *stream);
 int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_layer_group_t *g, void *table, size_t table_bytes,
@@ -375,6 +400,15 @@ int ctgcn_split_rows_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, v
 int ctgcn_pack_weight_f32(int32_t n_out, int32_t k, const float *w, int64_t ldw, void *packed, size_t packed_bytes, void *stream);
 int ctgcn_linear_packed_f32(int64_t rows, int32_t n_out, int32_t k, const void *x_planes, const void *w_packed, const float *bias,
                             int32_t activation, float *y, int64_t ldy, void *stream);
+/* ctgcn_linear_packed_f32 for the operand rows of `groups` snapshots in ONE launch (the 500-wide first layer of a small window): planes1 /
+ * planes2 / scales / y hold the rows of all groups one after the other, every group padded to whole panels of 128 rows (total_rows % 128 == 0;
+ * rows a group does not fill are multiplied and written like any other: give them finite contents or ignore them); panel_group (DEVICE,
+ * total_rows / 128 entries) names the group of every panel; w_packed[i] / bias[i] (host arrays of device pointers): the group's packed weight
+ * and bias.  n_out <= 512.  table: device scratch, 256-byte aligned, >= 24 bytes per group (ctgcn_group_table_bytes covers it), written by an
+ * asynchronous copy on `stream`.  Same arithmetic per row as ctgcn_linear_packed_f32: bit-identical to the per-group calls. */
+int ctgcn_linear_packed_group_f32(int32_t groups, int64_t total_rows, int32_t n_out, int32_t k, const void *planes1, const void *planes2,
+                                  const float *scales, const int32_t *panel_group, const void *const *w_packed, const float *const *bias,
+                                  int32_t activation, float *y, int64_t ldy, void *table, size_t table_bytes, void *stream);
 int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
                      int32_t activation, float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
 

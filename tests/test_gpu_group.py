@@ -83,3 +83,64 @@ def test_repeated_small_window_forwards_stay_bit_identical(monkeypatch):
         if ref is None:
             ref = out.clone()
         assert torch.equal(out, ref), it
+
+
+@pytest.mark.parametrize("d", [500, 64, 200])
+@pytest.mark.parametrize("dedup", ["1", "0"])
+def test_wide_first_layer_group_is_bit_identical(d, dedup, monkeypatch):
+    """ops.core_diffusion_wide_group (aggregation into shared operand planes, one panel GEMM over all snapshots' rows with per-snapshot
+    weights, one recurrence launch) against ops.core_diffusion_split per snapshot: the same bits (reference loop: models.py:243-247,
+    layers.py:41-62 with input_size = hid_dim)."""
+    from ctgcn_amd import ops
+    from ctgcn_amd.layers import CoreDiffusion
+    monkeypatch.setenv("CTGCN_DEDUP", dedup)
+    n, T = 3001, 5
+    adjs = _window(n, T, 6, 6, seed=11)
+    torch.manual_seed(2)
+    mods = [CoreDiffusion(d, 128, a.K).to(DEV).eval() for a in adjs]
+    xs = [torch.randn(n, d, device=DEV) for _ in range(T)]
+    rnns, norms = [m.rnn for m in mods], [m.norm for m in mods]
+    with torch.no_grad():
+        assert ops.core_diffusion_wide_group_ok(xs, adjs, rnns, norms)
+        outs = [torch.empty(n, 128, device=DEV) for _ in range(T)]
+        ops.core_diffusion_wide_group(xs, adjs, rnns, norms, outs)
+        for t in range(T):
+            ref = ops.core_diffusion_split(xs[t], adjs[t], rnns[t], norms[t])
+            assert torch.isfinite(ref).all()
+            assert torch.equal(outs[t], ref), "snapshot %d" % t
+        again = [torch.empty(n, 128, device=DEV) for _ in range(T)]
+        ops.core_diffusion_wide_group(xs, adjs, rnns, norms, again)
+        assert all(torch.equal(a, b) for a, b in zip(outs, again))
+
+
+def test_one_hot_window_takes_the_grouped_head(monkeypatch):
+    """a 'C' window on one-hot features (configs 2 / 4 in small): Linear(I) of all snapshots in one transpose launch, the 500-wide first
+    layer in one launch per kernel, then the width-128 layers — the bits of the per-snapshot launches"""
+    from ctgcn_amd import CTGCN, ops
+    n, T = 2003, 4
+    adjs = _window(n, T, 5, 5, seed=7)
+    torch.manual_seed(3)
+    model = CTGCN(n, 500, 128, 1, 2, T, model_type="C", trans_activate_type="L").to(DEV).eval()
+    idx = torch.arange(n, device=DEV)
+    eye = torch.sparse_coo_tensor(torch.stack([idx, idx]), torch.ones(n, device=DEV), (n, n)).coalesce()
+    xs = [eye for _ in range(T)]
+    calls = []
+    for name in ("core_diffusion_wide_group", "linear_of_identity_group", "core_diffusion_split_group"):
+        real = getattr(ops, name)
+        monkeypatch.setattr(ops, name, (lambda real_, name_: lambda *a, **k: (calls.append(name_), real_(*a, **k))[1])(real, name))
+    a = _forward(model, xs, adjs, monkeypatch, True)
+    assert calls == ["linear_of_identity_group", "core_diffusion_wide_group", "core_diffusion_split_group"], calls
+    b = _forward(model, xs, adjs, monkeypatch, False)
+    assert torch.equal(a, b)
+
+
+def test_grouped_linear_of_identity_matches_the_single_launches():
+    from ctgcn_amd import ops
+    torch.manual_seed(4)
+    for d, n, bias in ((500, 2003, True), (37, 130, False), (128, 64, True)):
+        ws = [torch.randn(d, n, device=DEV) for _ in range(3)]
+        bs = [torch.randn(d, device=DEV) if bias else None for _ in range(3)]
+        assert ops.linear_of_identity_group_ok(ws, bs)
+        outs = ops.linear_of_identity_group(ws, bs)
+        for w, b, o in zip(ws, bs, outs):
+            assert torch.equal(o, w.t() + b if b is not None else w.t().contiguous())

@@ -164,6 +164,29 @@ class CTGCN(nn.Module):
             cache = self._stream_cache = ((seq.device, k), [torch.cuda.Stream(device=seq.device) for _ in range(k)])
         return cache[1]
 
+    def _training_streams(self, x_list, adj_list, T):
+        """HIP streams for the snapshot branches of a TRAINING forward (and, through autograd, of its backward), or None.
+        CTGCN_TRAIN_STREAMS=k (1 = off; default 3: measured Enron-like 115 -> 103 ms per training step, math-like 38 -> 34, AS-like
+        17 -> 14, profiles/r05_train_small.txt; the gradients are the same bits).  Only where every dense step of a branch and of its backward runs in this library's
+        kernels — one-hot features, GRU width 128, fp16x2 arithmetic (see _snapshot_streams on concurrent library GEMMs) — and the graph is
+        small (<= 200 000 nodes)."""
+        from . import ops
+        from .layers import _is_identity
+        k = min(int(os.environ.get("CTGCN_TRAIN_STREAMS", "3")), T)
+        if k <= 1 or self.rnn_type != 'GRU' or self.output_dim != 128 or not ops.split_mfma_enabled() or not ops.linear_split_enabled() \
+                or not ops.wide_weight_grad_enabled() or torch.cuda.is_current_stream_capturing():
+            return None
+        p0 = next(self.parameters())
+        if not p0.is_cuda or not all(torch.is_tensor(x) and x.is_sparse and x.is_cuda and _is_identity(x) for x in x_list):
+            return None
+        n = adj_list[0].n if hasattr(adj_list[0], "n") else adj_list[0][0].shape[0]
+        if n > 200_000 or any(m.layer_num != 1 for m in self.mlp_list):
+            return None
+        cache = getattr(self, "_train_stream_cache", None)
+        if cache is None or cache[0] != (p0.device, k):
+            cache = self._train_stream_cache = ((p0.device, k), [torch.cuda.Stream(device=p0.device) for _ in range(k)])
+        return cache[1]
+
     def _branches_use_own_kernels(self, x_list):
         """The verdict is cached on what it depends on — the inputs' KIND (identity or not, checked by layers._is_identity, whose own cache
         keeps the tensor alive), shape, strides and alignment — never on id(x): a recycled id with another tensor must not reuse it."""
@@ -351,6 +374,22 @@ class CTGCN(nn.Module):
                 hx.append(h)
                 trans.append(tr)
             for s_ in lanes:
+                main.wait_stream(s_)
+        elif seq is None and self._training_streams(x_list, adj_list, T):
+            # training on a small window: the snapshot branches on a few HIP streams, like the inference lanes — autograd runs a node's
+            # backward on the stream of its forward, so the backward kernels of different snapshots overlap as well
+            tl = self._training_streams(x_list, adj_list, T)
+            main = torch.cuda.current_stream(tl[0].device)
+            for s_ in tl:
+                s_.wait_stream(main)
+            for t in range(T):
+                with torch.cuda.stream(tl[t % len(tl)]):
+                    h, tr = self.snapshot_branch(t, x_list[t], adj_list[t])
+                    h.record_stream(main)
+                    tr.record_stream(main)
+                hx.append(h)
+                trans.append(tr)
+            for s_ in tl:
                 main.wait_stream(s_)
         else:
             for t in range(T):

@@ -528,6 +528,12 @@ def _project_grad(dgi, w_ih, out):
     torch.mm(dgi, w_ih, out=out)
 
 
+def wide_weight_grad_enabled():
+    """CTGCN_WIDE_DW=0: dW_ih of a GRU with d_in > 128 stays an fp32 library GEMM (A/B runs)"""
+    import os
+    return os.environ.get("CTGCN_WIDE_DW", "1") != "0"
+
+
 _DW_PAIRS = 128          # block pairs of ctgcn_gru_weight_grad_f32: 256 blocks = one per CU of an MI355X
 
 
@@ -1183,6 +1189,10 @@ class _GruSeq(torch.autograd.Function):
         elif split:
             dw_part_ih = torch.empty(_DW_PAIRS, 3 * hid, hid, dtype=torch.float32, device=dev)    # summed once at the end
             dw_part_hh = torch.empty(_DW_PAIRS, 3 * hid, hid, dtype=torch.float32, device=dev)
+        wide_dw = split and not fused_bwd and hid < d_in <= 1024 and wide_weight_grad_enabled() and seq.stride(2) == 1
+        if wide_dw:
+            wide_cols = [min(c0, d_in - hid) for c0 in range(0, d_in, hid)]
+            dw_part_wide = [torch.empty(_DW_PAIRS, 3 * hid, hid, dtype=torch.float32, device=dev) for _ in wide_cols]
         else:
             hprev_buf = torch.zeros(cmax, steps, hid, dtype=torch.float32, device=dev)     # [:, 0] stays 0
         with torch.cuda.device(dev):
@@ -1235,6 +1245,12 @@ class _GruSeq(torch.autograd.Function):
                 db_all += bias_part.sum(0)          # per-block column sums written by the kernel (no re-read of d_gi / d_ghn)
                 if split and d_in == hid:
                     _weight_grad(dw_part_ih, dgi, dgi[:, 2 * hid:], x2d, steps, False, lo > 0)
+                elif wide_dw:
+                    # d_in = 500 (the 'C' configs' first layer): the 128-column weight-gradient kernel on column slices of x (the last one
+                    # moved left to end at d_in: its overlap with the slice before is computed twice and stored once) — 4 x 0.26 ms per
+                    # Enron-like snapshot against 1.6 ms of the fp32 library TN GEMM (which already runs at 104 TFLOP/s)
+                    for part_, c0 in zip(dw_part_wide, wide_cols):
+                        _weight_grad(part_, dgi, dgi[:, 2 * hid:], x2d[:, c0:], steps, False, lo > 0)
                 else:
                     _accumulate_tn(dw_ih, dgi, x2d)
                 if split:                            # h_{t-1} is read from the h sequence with the shift applied in the kernel
@@ -1252,6 +1268,9 @@ class _GruSeq(torch.autograd.Function):
             dw_hh += dw_part_hh.sum(0)
             if d_in == hid:
                 dw_ih += dw_part_ih.sum(0)
+            elif wide_dw:
+                for part_, c0 in zip(dw_part_wide, wide_cols):
+                    dw_ih[:, c0:c0 + hid] = part_.sum(0)
         db_ih = db_hh = None
         if b_ih is not None:
             db_ih = db_all[: 3 * hid].clone()

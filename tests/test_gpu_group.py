@@ -144,3 +144,34 @@ def test_grouped_linear_of_identity_matches_the_single_launches():
         outs = ops.linear_of_identity_group(ws, bs)
         for w, b, o in zip(ws, bs, outs):
             assert torch.equal(o, w.t() + b if b is not None else w.t().contiguous())
+
+
+def test_training_on_streams_gives_the_same_gradients(monkeypatch):
+    """a small one-hot 'C' window trained with its snapshot branches on three HIP streams (CTGCN._training_streams; autograd runs the
+    backward of a branch on the stream of its forward): output and every gradient bit-identical to the single-stream step"""
+    from ctgcn_amd import CTGCN
+    n, T = 1500, 4
+    adjs = _window(n, T, 5, 5, seed=9)
+    torch.manual_seed(5)
+    model = CTGCN(n, 200, 128, 1, 2, T, model_type="C", trans_activate_type="L").to(DEV).train()
+    idx = torch.arange(n, device=DEV)
+    eye = torch.sparse_coo_tensor(torch.stack([idx, idx]), torch.ones(n, device=DEV), (n, n)).coalesce()
+    xs = [eye for _ in range(T)]
+    G = torch.randn(T, n, 128, device=DEV)
+    res = {}
+    for k in ("1", "3", "3"):
+        monkeypatch.setenv("CTGCN_TRAIN_STREAMS", k)
+        assert (model._training_streams(xs, adjs, T) is not None) == (k != "1")
+        for p in model.parameters():
+            p.grad = None
+        out = model(xs, adjs)
+        (out * G).sum().backward()
+        torch.cuda.synchronize()
+        got = [out.detach().clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+        assert len(got) > 20 and all(torch.isfinite(g).all() for g in got)
+        if k in res:
+            assert all(torch.equal(a, b) for a, b in zip(res[k], got))
+        res[k] = got
+    assert len(res["1"]) == len(res["3"])
+    for a, b in zip(res["1"], res["3"]):
+        assert torch.equal(a, b)

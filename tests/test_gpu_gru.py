@@ -62,6 +62,7 @@ def test_fused_gru_row_chunking_and_determinism():
 @pytest.mark.parametrize("rows,steps,d_in,reduce_sum,bias,use_norm", [
     (70, 8, 128, True, True, True), (1000, 5, 40, True, True, True), (513, 6, 128, False, True, True),
     (90, 3, 128, True, False, True), (33, 1, 16, True, True, True), (200, 4, 128, False, True, False),
+    (700, 5, 500, True, True, True), (130, 3, 200, True, True, True),      # d_in > 128: dW_ih by column slices (ops.wide_weight_grad_enabled)
 ])
 def test_fused_gru_gradients_match_torch_autograd(rows, steps, d_in, reduce_sum, bias, use_norm):
     """d/d{x, W_ih, W_hh, b_ih, b_hh, ln.weight, ln.bias} of sum(out * G) vs CPU nn.GRU autograd."""

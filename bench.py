@@ -452,8 +452,10 @@ def main():
                    "6 x v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate)",
                 0: "gru_seq_kernel (GRU recurrence + sum + LayerNorm, v_mfma_f32_16x16x4_f32)"}[mode]
         pname = {2: "gru_proj_h2_kernel", 1: "gru_proj_x3_kernel", 0: "hipBLASLt fp32 GEMM"}[mode]
-        flops = sum(m["rows"] * (m["steps"] - 1) * 2.0 * 128 * 384 for _, m in gru)
-        gi_bytes = sum(m["rows"] * m["steps"] * 1536.0 for _, m in gru)    # the projection's output read back, 1536 B per row-step
+        # (a grouped launch — the first layer of a small window's snapshots in one grid — carries row_steps = sum of rows x steps, group = T)
+        grs = lambda m: m.get("row_steps", m["rows"] * m["steps"])
+        flops = sum((grs(m) - m["rows"] * m.get("group", 1)) * 2.0 * 128 * 384 for _, m in gru)
+        gi_bytes = sum(grs(m) * 1536.0 for _, m in gru)    # the projection's output read back, 1536 B per row-step
         ms = sum(t for t, _ in gru)
         roof_mfma = {"kernel": name,
                      "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),

@@ -21,6 +21,12 @@ from . import _lib
 _SENTINEL = 255
 
 
+def _as_i32_words(words):
+    """int64 tensor of 32-bit patterns -> int32 with the same bits (bit 31 set: negative)"""
+    w = words & 0xffffffff
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+
 class CoreAdj(object):
     """Slot-tagged CSR of the K matrices the reference loader would return for one snapshot.
 
@@ -125,7 +131,7 @@ class CoreAdj(object):
     PLAN_TILE_GEMM = 64 # ... and of the recurrence kernel behind the split GEMM (gru_seq_h2_kernel)
 
     def row_plan(self, tile=None):
-        """Row plan for the inference path (ctgcn_core_aggregate_split_f32 and its consumers), or None (K > 32).
+        """Row plan for the inference path (ctgcn_core_aggregate_split_f32 and its consumers), or None (K > 64).
 
         layers.py:41-48: res_j = res_{j-1} + A_j x, so as long as no entry of row v has arrived (slots below the row's first tag f;
         nested lists: f = K - capped core number) H[v, 0..f-1] is the same row relu(x_v) f times, and the GRU multiplies it by W_ih f
@@ -133,14 +139,15 @@ class CoreAdj(object):
           order      int32[n]   matrix row handled at position p.  Rows with equal repeat patterns are neighbours, so that the
                                 sequences of a GRU tile share one; inside a pattern rows go by falling degree (the two rows of a
                                 wave and the eight of a block are equally long, and the long blocks of a launch start first).
-          tile_mask  int32[ceil(n / tile)]  bit j set = slot j carries a new row for at least one of the tile's positions (bit 0 always)
+          tile_mask  int32[ceil(n / tile)]  bit j set = slot j carries a new row for at least one of the tile's positions (bit 0 always);
+                                K > 32 (America-Air: 64, Europe-Air: 33): int32[2 tiles], word 2 T = slots 0-31, word 2 T + 1 = slots 32-63
           tile_base  int32[tiles]  first COMPACT operand row of the tile (tile * popcount(mask) rows per tile, incl. the padding
                                 of the last one) and operand_rows, their total: the GEMM consumer's layout (tile = 64)
           inverse    int32[n]   position of matrix row v (hub rows are looked up here)
         tile: PLAN_TILE (16: the GRU layer kernel reads the planes with holes) or PLAN_TILE_GEMM (64).
         Static per graph: built once on the device, cached."""
         tile = self.PLAN_TILE if tile is None else int(tile)
-        if self.K > 32 or self.n == 0:
+        if self.K > 64 or self.n == 0:
             return None
         if self._plan is None:
             self._plan = {}
@@ -153,40 +160,63 @@ class CoreAdj(object):
                 first = torch.full((n,), K, dtype=torch.int64, device=dev)
                 has = deg > 0
                 first[has] = self.slot[rp[:-1][has]].long()
-                # bits first .. K-1 (first = K: none) | bit 0 — arithmetic on n values, no [n, K] temporaries
-                mask = ((1 << K) - (torch.ones_like(first) << first)) | 1
+                # bits first .. K-1 (first = K: none) | bit 0 — arithmetic on n values, no [n, K] temporaries.  Two 32-bit halves (in int64):
+                # half w holds slots 32 w .. 32 w + 31
+                def half(w):
+                    lo, hi = 32 * w, min(K, 32 * w + 32)
+                    if hi <= lo:
+                        return torch.zeros_like(first)
+                    f = (first - lo).clamp(0, hi - lo)
+                    return (1 << (hi - lo)) - (torch.ones_like(first) << f)
+                mask_lo, mask_hi = half(0) | 1, half(1)
             else:
                 rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
-                mask = torch.ones(n, dtype=torch.int64, device=dev)
+                mask_lo = torch.ones(n, dtype=torch.int64, device=dev)
+                mask_hi = torch.zeros(n, dtype=torch.int64, device=dev)
                 for j in range(K):                                        # one [n] bool per slot instead of an [n, K] product
                     hit = torch.zeros(n, dtype=torch.bool, device=dev)
                     hit[rows[self.slot == j]] = True
-                    mask |= hit.long() << j
+                    if j < 32:
+                        mask_lo |= hit.long() << j
+                    else:
+                        mask_hi |= hit.long() << (j - 32)
             o1 = torch.argsort(deg, descending=True, stable=True)
-            order = o1[torch.argsort(mask[o1], descending=True, stable=True)]
+            # rows with equal patterns become neighbours: by the 64-bit pattern (hi, lo), falling — two stable sorts (K <= 32: hi = 0, the one sort of before)
+            order = o1[torch.argsort(mask_lo[o1], descending=True, stable=True)]
+            if K > 32:
+                order = order[torch.argsort(mask_hi[order], descending=True, stable=True)]
             inverse = torch.empty(n, dtype=torch.int64, device=dev)
             inverse[order] = torch.arange(n, device=dev)
             self._plan.update(order=order.to(torch.int32).contiguous(), inverse=inverse.to(torch.int32).contiguous(),
-                              _sorted_mask=mask[order])
+                              _sorted_mask=mask_lo[order], _sorted_mask_hi=mask_hi[order])
         if tile not in self._plan:
             dev, n, K = self.device, self.n, self.K
             ntiles = -(-n // tile)
             padded = torch.ones(ntiles * tile, dtype=torch.int64, device=dev)
             padded[:n] = self._plan["_sorted_mask"]
             tiles = padded.view(ntiles, tile)
+            padded_hi = torch.zeros(ntiles * tile, dtype=torch.int64, device=dev)
+            padded_hi[:n] = self._plan["_sorted_mask_hi"]
+            tiles_hi = padded_hi.view(ntiles, tile)
             tmask = torch.zeros(ntiles, dtype=torch.int64, device=dev)
+            tmask_hi = torch.zeros(ntiles, dtype=torch.int64, device=dev)
             fresh = torch.zeros(ntiles, dtype=torch.int64, device=dev)
             for j in range(K):
-                anyj = ((tiles >> j) & 1).any(1).long()
-                tmask |= anyj << j
+                anyj = (((tiles if j < 32 else tiles_hi) >> (j & 31)) & 1).any(1).long()
+                if j < 32:
+                    tmask |= anyj << j
+                else:
+                    tmask_hi |= anyj << (j - 32)
                 fresh += anyj
+            if K > 32:                                                # two words per tile, interleaved
+                tmask = torch.stack([tmask, tmask_hi], 1).reshape(-1)
             per_tile = fresh * tile                                   # compact operand rows of each tile
             base = torch.cumsum(per_tile, 0) - per_tile
             total = int(per_tile.sum().item())
             if total >= 2 ** 31:
                 return None
             self._plan[tile] = dict(order=self._plan["order"], inverse=self._plan["inverse"], tile=tile,
-                                    tile_mask=tmask.to(torch.int32).contiguous(), tile_base=base.to(torch.int32).contiguous(),
+                                    tile_mask=_as_i32_words(tmask), tile_base=base.to(torch.int32).contiguous(),
                                     new_rows=total, operand_rows=total)      # (position, slot) rows written per layer (incl. tile padding)
         return self._plan[tile]
 
@@ -200,9 +230,13 @@ class CoreAdj(object):
             return hit
         pos = plan["inverse"][rows.long()].long()
         t = torch.div(pos, tile, rounding_mode="floor")
-        need = plan["tile_mask"][t].long() & 0xffffffff
         j = torch.arange(K, device=pos.device)[None, :]
-        bits = (need[:, None] >> j) & 1
+        if K > 32:
+            lo, hi = plan["tile_mask"][2 * t].long() & 0xffffffff, plan["tile_mask"][2 * t + 1].long() & 0xffffffff
+            bits = torch.where(j < 32, lo[:, None] >> j.clamp(max=31), hi[:, None] >> (j - 32).clamp(min=0)) & 1
+        else:
+            need = plan["tile_mask"][t].long() & 0xffffffff
+            bits = (need[:, None] >> j) & 1
         if compact:
             rank = torch.cumsum(bits, 1) - bits
             dest = plan["tile_base"][t].long()[:, None] + (pos % tile)[:, None] * bits.sum(1, keepdim=True) + rank

@@ -1693,7 +1693,8 @@ __device__ __forceinline__ float group_max(float m)       // m >= 0: its bit pat
 // the mapping of agg_fwd_kernel at d = 128).  The fp32 H [n, K, d] is never written and never read back: per (row, slot)
 // 4 d bytes written instead of 4 d written + 4 d read + 4 d written, and one pass over the entries instead of d / 256.
 // ------------------------------------------------------------------------------------------------
-template <int LPR, int CH, int U>
+// WIDE (round 5): a row plan over 33-64 slots: two mask words per tile.  Separate instantiations: the K <= 32 kernels keep their code.
+template <int LPR, int CH, int U, bool WIDE = false>
 __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2,
                                                    float *__restrict__ scale, int32_t kp, float residual_scale, const int64_t bid)
 {
@@ -1704,8 +1705,19 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
     const int64_t row = a.order ? (int64_t)a.order[pos] : pos;
     // the block's 256 / LPR positions lie in one 16-position tile: a scalar load
     const int64_t tile = (bid * (256 / LPR)) >> a.tile_shift;
-    const uint32_t need = a.tmask ? a.tmask[tile] : 0xffffffffu;
-    const int64_t obase = a.tbase ? (int64_t)a.tbase[tile] + (pos & ((1 << a.tile_shift) - 1)) * __popc(need) : pos * a.K;
+    // step mask of the tile: one word, or (WIDE) two: tmask[2 tile] = slots 0-31, tmask[2 tile + 1] = slots 32-63
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type mask_t;
+    constexpr int MB = WIDE ? 63 : 31;
+    mask_t need;
+    int nneed;
+    if constexpr (WIDE) {
+        need = a.tmask ? ((mask_t)a.tmask[2 * tile] | ((mask_t)a.tmask[2 * tile + 1] << (WIDE ? 32 : 0))) : ~(mask_t)0;
+        nneed = __popcll(need);
+    } else {
+        need = a.tmask ? a.tmask[tile] : 0xffffffffu;
+        nneed = __popc(need);
+    }
+    const int64_t obase = a.tbase ? (int64_t)a.tbase[tile] + (pos & ((1 << a.tile_shift) - 1)) * nneed : pos * a.K;
     const int start = a.row_ptr[row], end = a.row_ptr[row + 1];
     if (end - start > a.long_thresh) return;          // hub row: agg_fwd_hub_kernel into the compact scratch, split afterwards
     const bool self = (a.flags & CTGCN_F_SELF_LOOP) != 0;
@@ -1734,7 +1746,7 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
             R[c] += P[c];
             if (!nested) P[c] = vzero<4>();
         }
-        if (!((need >> (cur & 31)) & 1)) { ++cur; return; }      // a repeat of the previous slot's row that the consumer never reads
+        if (!((need >> (cur & MB)) & 1)) { ++cur; return; }      // a repeat of the previous slot's row that the consumer never reads
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             v[c] = relu ? vmax0(R[c]) : R[c];
@@ -1744,7 +1756,9 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
         m = group_max<LPR>(m);
         float s, inv;
         h2_scale(m, s, inv);
-        const int64_t orow = obase + (a.tbase ? __popc(need & ((1u << cur) - 1u)) : cur);
+        int64_t orow;                                 // compact layout: the set bits of `need` below slot cur
+        if constexpr (WIDE) orow = obase + (a.tbase ? __popcll(need & (((mask_t)1 << (cur & 63)) - (mask_t)1)) : cur);
+        else orow = obase + (a.tbase ? __popc(need & ((1u << cur) - 1u)) : cur);
         if (lig == 0) scale[orow] = s;
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -1809,11 +1823,11 @@ __device__ __forceinline__ void agg_fwd_split_body(const AggArgs &a, _Float16 *_
     while (cur < a.K) close_slot();
 }
 
-template <int LPR, int CH, int U>
+template <int LPR, int CH, int U, bool WIDE = false>
 __global__ __launch_bounds__(256) void agg_fwd_split_kernel(const AggArgs a, _Float16 *__restrict__ p1, _Float16 *__restrict__ p2,
                                                             float *__restrict__ scale, int32_t kp, float residual_scale)
 {
-    agg_fwd_split_body<LPR, CH, U>(a, p1, p2, scale, kp, residual_scale, blockIdx.x);
+    agg_fwd_split_body<LPR, CH, U, WIDE>(a, p1, p2, scale, kp, residual_scale, blockIdx.x);
 }
 // d <= 128: held to the 72 registers of seven waves per SIMD, like agg_fwd_kernel<4,32,4> (left alone the epilogue takes 74: six)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void agg_fwd_split32_kernel(
@@ -2013,7 +2027,7 @@ __global__ __launch_bounds__(512, 2) void gru_proj_h2_kernel(const ProjArgs a)
 // (row scale of W_hh × 2^-14) is folded into the gate pre-activation FMA, so the gate math costs what it did.
 // bid / nblk: this block's index among the nblk blocks that share the work of `a` (the whole grid, or — grouped launch of a window's snapshots,
 // gru_seq_h2_group_kernel — the blocks dealt to this snapshot)
-template <bool REDUCE, bool SAVE>
+template <bool REDUCE, bool SAVE, bool WIDE = false>        // WIDE: a row plan over 33-64 steps, two mask words per tile (its own instantiation)
 __device__ __forceinline__ void gru_seq_h2_body(const GruArgs &a, const int bid, const int nblk)
 {
     __shared__ _Float16 Hs[2][2][GRU_BM][PJ_PITCH];
@@ -2049,14 +2063,21 @@ __device__ __forceinline__ void gru_seq_h2_body(const GruArgs &a, const int bid,
         const int gi_gs = a.gi_blocked ? 8 * 1024 : GRU_H;
         // compact gi under a row plan (REDUCE form only): see GruArgs
         const bool planned = REDUCE && !SAVE && a.tmask != nullptr;
-        const uint32_t tm = planned ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tmask[tile]) : 0u;
-        const int nfresh = __popc(tm);
+        typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type mask_t;
+        mask_t tm = 0;
+        if (planned) {
+            if constexpr (WIDE) tm = (mask_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.tmask[2 * tile]) |
+                                     ((mask_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)a.tmask[2 * tile + 1]) << (WIDE ? 32 : 0));
+            else tm = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tmask[tile]);
+        }
+        auto popc = [](mask_t m) __attribute__((always_inline)) -> int { if constexpr (WIDE) return __popcll(m); else return __popc(m); };
+        const int nfresh = popc(tm);
         const float *gi_base = planned ? a.gi + (int64_t)__builtin_amdgcn_readfirstlane(a.tbase[tile]) * (3 * GRU_H)
                                        : (a.gi_blocked ? a.gi + tile * (int64_t)gstride * GRU_BM : a.gi + row0 * gstride);
         const uint32_t gi_lane = a.gi_blocked ? (uint32_t)(wave * 1024 + col * 16 + 4 * grp) : (uint32_t)oc;
         auto gaddr = [&](int t, int rt) {
             uint32_t off;
-            if (planned) off = (uint32_t)(min(rt * 16 + col, last) * nfresh + (__popc(tm & ((2u << t) - 1u)) - 1)) * (uint32_t)(3 * GRU_H);
+            if (planned) off = (uint32_t)(min(rt * 16 + col, last) * nfresh + (popc(tm & (WIDE && t == 63 ? ~(mask_t)0 : (((mask_t)2 << t) - (mask_t)1))) - 1)) * (uint32_t)(3 * GRU_H);
             else off = a.gi_blocked ? (uint32_t)(t * (3 * 8 * 1024) + rt * 256) : (uint32_t)(t * 3 * GRU_H) + (uint32_t)min(rt * 16 + col, last) * (uint32_t)gstride;
             return gi_base + (gi_lane + off);
         };
@@ -2208,10 +2229,10 @@ __device__ __forceinline__ void gru_seq_h2_body(const GruArgs &a, const int bid,
     }
 }
 
-template <bool REDUCE, bool SAVE>
+template <bool REDUCE, bool SAVE, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void gru_seq_h2_kernel(const GruArgs a)
 {
-    gru_seq_h2_body<REDUCE, SAVE>(a, (int)blockIdx.x, (int)gridDim.x);
+    gru_seq_h2_body<REDUCE, SAVE, WIDE>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // the recurrences of a small window's snapshots in one launch (round 5: the 500-wide first layer): block -> (snapshot, index among its blocks,
@@ -2608,9 +2629,23 @@ __device__ __forceinline__ constexpr int l8_slot(int sp, int c, int g) { return 
 
 // bid / nblk: this block's index among the nblk blocks that share the work of `a` (the whole grid, or — grouped launch of a window's
 // snapshots, gru_layer8_h2_group_kernel — the blocks assigned to this snapshot)
-template <bool PRESPLIT, bool REDUCE, bool SAVE>
+// WIDE (round 5): a row plan over up to 64 steps (America-Air max core 64, Europe-Air 33): two mask words per tile, tmask[2 tile] = steps
+// 0-31, tmask[2 tile + 1] = steps 32-63.  A separate instantiation: the K <= 32 kernels keep their 32-bit masks and their code.
+template <bool PRESPLIT, bool REDUCE, bool SAVE, bool WIDE = false>
 __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int bid, const int nblk)
 {
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type mask_t;
+    constexpr mask_t MASK_ALL = ~(mask_t)0;
+    // bit t of a step mask.  Without a plan the mask is all ones and t runs to steps - 1 (up to 254): the shift count is reduced to the mask's
+    // width (a C++ shift by >= the width is undefined — round 4's plan-less kernel at 40 steps gave rows off by 1e-1, found in round 5 by
+    // the first comparison of that path with the fp32-H path at K > 32)
+    constexpr int MASK_BITS = WIDE ? 63 : 31;
+    auto mask_bit = [](mask_t m, int t) __attribute__((always_inline)) -> bool { return ((m >> (t & MASK_BITS)) & 1) != 0; };
+    auto uniform_mask = [](mask_t m) __attribute__((always_inline)) -> mask_t {
+        if constexpr (WIDE) return (mask_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m) |
+                                   ((mask_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)m >> 32)) << (WIDE ? 32 : 0));
+        else return (mask_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    };
     // x and h planes: 16 rows of 128 halfs, unpadded; the 16-byte segment q of row r is stored at segment q ^ r (l8_off).  Every access
     // pattern of the kernel is then conflict-free: the MFMA operand reads (ds_read_b128: lane = (row, k group) — with the 8-half row
     // padding of the other GRU kernels rows 11 and 12 met in one bank group: SQ_LDS_BANK_CONFLICT was 26 % of the LDS cycles), the
@@ -2624,7 +2659,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     __shared__ float ln_gb[2][GRU_H];                    // LayerNorm weight / bias and the temporal layout's step offsets: no vector-memory load
     __shared__ int64_t soff_s[32];                       // outside the x pipeline (any wait on one is a wait for the x rows in flight, see below)
     __shared__ int32_t ord_s[4][16];                     // row-plan forms: output rows and step mask of the tiles in flight (ring of four, see below)
-    __shared__ uint32_t msk_s[4];
+    __shared__ mask_t msk_s[4];
     // the row-plan forms have no hrow staging: room for more fragments.  The recompute pass (SAVE) takes two more: with 12 the x prefetch
     // registers were spilled right behind their loads (s_waitcnt + scratch_store: the prefetch distance became zero)
     constexpr int WL = (PRESPLIT && REDUCE) ? (SAVE ? 15 : 12) : L8_WL;
@@ -2750,15 +2785,19 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         }
     };
     // units that need x: all of them, or (DEDUP) the steps whose tmask bit is set — the x pipeline below runs over those only
-    auto tile_mask = [&](int64_t tile) -> uint32_t {
-        if (DEDUP) return (a.tmask && tile < ntiles) ? a.tmask[tile] : 0xffffffffu;
-        return 0xffffffffu;
+    auto load_mask = [&](int64_t tile) __attribute__((always_inline)) -> mask_t {
+        if constexpr (WIDE) return (mask_t)a.tmask[2 * tile] | ((mask_t)a.tmask[2 * tile + 1] << (WIDE ? 32 : 0));
+        else return a.tmask[tile];
     };
-    uint32_t pmask = 0xffffffffu;                          // mask of the tile the x pipeline is at
+    auto tile_mask = [&](int64_t tile) -> mask_t {
+        if (DEDUP) return (a.tmask && tile < ntiles) ? load_mask(tile) : MASK_ALL;
+        return MASK_ALL;
+    };
+    mask_t pmask = MASK_ALL;                               // mask of the tile the x pipeline is at
     auto next_unit = [&](int64_t &tile, int &t) {
         do {
             if (++t >= S) { t = 0; tile += nblk; if (DEDUP) pmask = tile_mask(tile); }
-        } while (DEDUP && !((pmask >> t) & 1));
+        } while (DEDUP && !mask_bit(pmask, t));
     };
 
     if ((int64_t)bid >= ntiles) return;
@@ -2860,7 +2899,9 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 xmr[0] = __float_as_uint(a.xps[rs_]);
                 if (pt == 0) {
                     xmr[1] = a.order ? (uint32_t)a.order[row] : (uint32_t)row;
-                    xmr[2] = a.tmask ? a.tmask[ptile] : 0xffffffffu;
+                    const mask_t m_ = a.tmask ? load_mask(ptile) : MASK_ALL;
+                    xmr[2] = (uint32_t)m_;
+                    if constexpr (WIDE) xmr[3] = (uint32_t)((uint64_t)m_ >> 32);
                 }
             }
         };
@@ -2871,13 +2912,14 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 *(h8v *)(&Xs[slot][1][qr][l8_off(qr, qc)]) = xp2r;
                 if (pt == 0) {
                     if ((tid & 15) == 0) ord_s[pring][qr] = (int32_t)xmr[1];
-                    if (tid == 0) msk_s[pring] = xmr[2];
-                    pmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)xmr[2]);
+                    const mask_t m_ = WIDE ? (mask_t)(((uint64_t)xmr[3] << 32) | xmr[2]) : (mask_t)xmr[2];
+                    if (tid == 0) msk_s[pring] = m_;
+                    pmask = uniform_mask(m_);
                 }
             }
             do {
                 if (++pt >= S) { pt = 0; ptile += nblk; pring = (pring + 1) & 3; break; }     // step 0 of a tile is always fresh
-            } while (!((pmask >> pt) & 1));
+            } while (!mask_bit(pmask, pt));
         };
         if (stager) {
             load_xp();
@@ -2969,12 +3011,12 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
             const int64_t row0 = tile * 16;
             const int last = (int)min((int64_t)16, a.rows - row0) - 1;
             f4v hprev = zero4, hsum = zero4;
-            const uint32_t tmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)msk_s[cring]);
+            const mask_t tmask = uniform_mask(msk_s[cring]);
             f4v gi[3] = {zero4, zero4, zero4};
             for (int t = 0; t < S; ++t) {
                 if (t == 0) pending_layernorm();          // the previous tile's rows (its last unit ended with a barrier)
                 TL_MARK(5)                                // row-plan form: [0] h products issued, [1] gate math, [2] publish, [3] x products issued, [4] barrier, [5] LayerNorm, [6] units, [7] fresh, [8] x staging + next request
-                if ((tmask >> t) & 1) {
+                if (mask_bit(tmask, t)) {
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
                         gi[g] = acc0[g] * (*(const f4v *)(&wsc_ih[g][oc]) * rs_n) + *(const f4v *)(&bias_s[g][oc]);
@@ -2992,7 +3034,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 const f4v csc[3] = {*(const f4v *)(&csc_hh[0][oc]), *(const f4v *)(&csc_hh[1][oc]), *(const f4v *)(&csc_hh[2][oc])};
                 const f4v b_hn = *(const f4v *)(&csc_hh[3][oc]);
                 // the next unit's x·W_ih, if it brings a new x (a repeat keeps gi): this tile's next step, or step 0 of the block's next tile
-                const bool next_fresh = t + 1 < S ? ((tmask >> (t + 1)) & 1) != 0 : tile + nblk < ntiles;
+                const bool next_fresh = t + 1 < S ? mask_bit(tmask, t + 1) : tile + nblk < ntiles;
                 TL_MARK(0)
                 f4v h, rv4, zv4, nv4, an4;
 #pragma unroll
@@ -3066,10 +3108,10 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         const int64_t row0 = tile * 16;
         const int last = (int)min((int64_t)16, a.rows - row0) - 1;
         f4v hprev = zero4, hsum = zero4;
-        const uint32_t tmask = tile_mask(tile);
+        const mask_t tmask = tile_mask(tile);
         f4v gi[3] = {zero4, zero4, zero4};               // x_t·W_ih + b of the last step that brought a new x (kept over its repeats)
         for (int t = 0; t < S; ++t) {
-            const bool fresh = !DEDUP || ((tmask >> t) & 1);
+            const bool fresh = !DEDUP || mask_bit(tmask, t);
             if (REDUCE && t == 0) pending_layernorm();
             if (!REDUCE) pending_rows();                   // the previous unit's rows (staged before its barrier)
             // ---- x of the next unit (registers -> planes of the other slot, then the request for the unit after it) is staged in
@@ -3203,10 +3245,10 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
 #undef TL_MARK
 }
 
-template <bool PRESPLIT, bool REDUCE, bool SAVE = false>
+template <bool PRESPLIT, bool REDUCE, bool SAVE = false, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void gru_layer8_h2_kernel(const LayerArgs a)
 {
-    gru_layer8_h2_body<PRESPLIT, REDUCE, SAVE>(a, (int)blockIdx.x, (int)gridDim.x);
+    gru_layer8_h2_body<PRESPLIT, REDUCE, SAVE, WIDE>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 // One launch for the width-128 CoreDiffusion layer of EVERY snapshot of a window (small graphs: a snapshot alone is 25-500 us of kernel, most
 // of it ramp and tail).  Snapshots own their weights (reference models.py:225-231: duffision_list[t]), so a block serves one snapshot:
@@ -4172,7 +4214,7 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
         return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: needs d %% 4 == 0, d <= 512, 16-byte aligned rows, 256-byte aligned workspace");
     if (n_long < 0 || (n_long > 0 && (!long_rows || long_threshold < 1))) return fail(CTGCN_E_INVALID, "core_aggregate_split: bad hub row list");
     if ((row_order == nullptr) != (tile_mask == nullptr)) return fail(CTGCN_E_INVALID, "core_aggregate_split: row_order and tile_mask come together");
-    if (row_order && K > 32) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: a row plan needs K <= 32");
+    if (row_order && K > 64) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split: a row plan needs K <= 64");
     if (row_order && ((d == 128 && n_out == 1) != (tile_base == nullptr)))
         return fail(CTGCN_E_INVALID, "core_aggregate_split: tile_base (compact operand rows, tiles of 64) goes with the GEMM consumer, tiles of 16 without it with the GRU layer kernel");
     if (!row_order && tile_base) return fail(CTGCN_E_INVALID, "core_aggregate_split: tile_base without a row plan");
@@ -4207,6 +4249,11 @@ int ctgcn_core_aggregate_split_f32(int64_t n_rows, int32_t d, int32_t K, const i
     const float rsc = 1.f;
     static const int force_u8 = [] { const char *e = getenv("CTGCN_AGG_U8"); return e ? atoi(e) : -1; }();      // A/B: 1 = always eight gathers in flight, 0 = never
     const bool u8 = force_u8 >= 0 ? force_u8 != 0 : n_rows <= 200000;
+    if (row_order && K > 32) {        // a row plan over 33-64 slots (two mask words per tile): lists this deep belong to graphs of ~1 000 nodes
+        if (p.chunks <= 32) hipLaunchKernelGGL((agg_fwd_split_kernel<32, 1, 8, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
+        else if (p.chunks <= 64) hipLaunchKernelGGL((agg_fwd_split_kernel<64, 1, 8, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
+        else hipLaunchKernelGGL((agg_fwd_split_kernel<64, 2, 8, true>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
+    } else
     if (p.chunks <= 32 && u8) hipLaunchKernelGGL(agg_fwd_split32_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
     else if (p.chunks <= 32) hipLaunchKernelGGL(agg_fwd_split32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
     else if (p.chunks <= 64) hipLaunchKernelGGL((agg_fwd_split_kernel<64, 1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a, p1, p2, scale, kp, rsc);
@@ -4447,8 +4494,8 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq: hidden=%d, only %d is built", hidden, GRU_H);
     if ((row_order == nullptr) != (tile_mask == nullptr) || (row_order == nullptr) != (tile_base == nullptr))
         return fail(CTGCN_E_INVALID, "gru_seq: row_order, tile_mask and tile_base come together");
-    if (row_order && (!reduce_sum || gates_out || gi_blocked || split_bf16 != CTGCN_SPLIT_F16X2 || steps > 32))
-        return fail(CTGCN_E_UNSUPPORTED, "gru_seq: a row plan needs the sum-over-steps form, CTGCN_SPLIT_F16X2, the plain gi layout and steps <= 32");
+    if (row_order && (!reduce_sum || gates_out || gi_blocked || split_bf16 != CTGCN_SPLIT_F16X2 || steps > 64))
+        return fail(CTGCN_E_UNSUPPORTED, "gru_seq: a row plan needs the sum-over-steps form, CTGCN_SPLIT_F16X2, the plain gi layout and steps <= 64");
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_seq: bad sizes rows=%lld steps=%d", (long long)rows, steps);
     if (rows == 0) return CTGCN_OK;
     if (!gi || !w_hh || !out) return fail(CTGCN_E_INVALID, "gru_seq: null pointer");
@@ -4468,7 +4515,9 @@ int ctgcn_gru_seq_f32(int64_t rows, int32_t steps, int32_t hidden, const float *
     cus = persistent_cus(cus);
     const int64_t ntiles = (rows + GRU_BM - 1) / GRU_BM;
     const int64_t blocks = ntiles < cus ? ntiles : cus;          // persistent: one 8-wave block per CU
-    if (split_bf16 == 2 && a.reduce_sum)
+    if (split_bf16 == 2 && a.reduce_sum && row_order && steps > 32)      // two mask words per tile
+        hipLaunchKernelGGL((gru_seq_h2_kernel<true, false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    else if (split_bf16 == 2 && a.reduce_sum)
         hipLaunchKernelGGL((gru_seq_h2_kernel<true, false>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else if (split_bf16 == 2 && a.gates)
         hipLaunchKernelGGL((gru_seq_h2_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
@@ -4581,7 +4630,7 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit: only d_in = hidden = %d is built (got %d)", GRU_H, hidden);
     if ((row_order == nullptr) != (tile_mask == nullptr)) return fail(CTGCN_E_INVALID, "gru_layer_presplit: row_order and tile_mask come together");
-    if (row_order && steps > 32) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit: a row plan needs steps <= 32");
+    if (row_order && steps > 64) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit: a row plan needs steps <= 64");
     if (rows < 0 || steps < 1) return fail(CTGCN_E_INVALID, "gru_layer_presplit: bad sizes rows=%lld steps=%d", (long long)rows, steps);
     if (rows == 0) return CTGCN_OK;
     if (!planes || !w_ih || !w_hh || !out) return fail(CTGCN_E_INVALID, "gru_layer_presplit: null pointer");
@@ -4608,7 +4657,10 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
     const unsigned nb8 = (unsigned)(nt8 < cus ? nt8 : cus);
     const char *tl_file = timeline_begin(a, nb8, stream);
 #endif
-    hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+    if (row_order && steps > 32)       // two mask words per tile (tile_mask[2 tile], [2 tile + 1])
+        hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true, false, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
 #ifdef CTGCN_LAYER_TIMELINE
     timeline_end(a, nb8, tl_file, stream);
 #endif

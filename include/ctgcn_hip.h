@@ -194,7 +194,7 @@ int ctgcn_slot_reorder(int64_t n, int32_t K, const int32_t *row_ptr, const int32
  *   ([node tile of 64][step][gate][16-column group][node in tile][16]; the buffer must cover ceil(rows/64)*64 rows).
  * gates_out (optional; requires reduce_sum == 0 and ln_weight == NULL): [rows, steps, 4, 128] receives r, z, n and
  * q = W_hn·h_{t-1} + b_hn for ctgcn_gru_seq_bwd_f32.
- * row_order / tile_mask / tile_base (all or none; reduce_sum, CTGCN_SPLIT_F16X2, plain gi layout, steps <= 32): gi was projected from
+ * row_order / tile_mask / tile_base (all or none; reduce_sum, CTGCN_SPLIT_F16X2, plain gi layout, steps <= 64): gi was projected from
  * the COMPACT operand rows ctgcn_core_aggregate_split_f32 wrote under a row plan with tiles of 64 — only the steps that bring a new x
  * row exist: tile T starts at gi row tile_base[T], sequence p of it owns popcount(tile_mask[T]) consecutive rows, step t reads the row of
  * the last set bit <= t.  Sequence p is written to out row row_order[p].  Same arithmetic on the same numbers: bit-identical.
@@ -259,7 +259,7 @@ int ctgcn_gru_layer_f32(int64_t rows, int32_t steps, int32_t d_in, int32_t hidde
  * max / scale / split, this matrix-core-bound kernel only copies the planes into LDS: the whole CoreDiffusion layer of
  * layers.py:41-62 in two kernels, x [rows, steps, 128] never exists in fp32.  Bit-identical to ctgcn_core_aggregate_f32 +
  * ctgcn_gru_layer_f32.  Inference only.
- *   row_order / tile_mask (both or neither; steps <= 32): the row plan the aggregation call was given (see there).  Sequence p of the
+ *   row_order / tile_mask (both or neither; steps <= 64): the row plan the aggregation call was given (see there).  Sequence p of the
  *   planes is written to out row row_order[p]; a step whose tile_mask bit is clear re-uses the x·W_ih products of the step before
  *   (its x row is the same row again: layers.py:41-48 with no entry of that slot or below in any of the tile's 16 rows) and costs the
  *   h·W_hh half only.  Same products in the same order: results are bit-identical to the call without a plan.
@@ -424,7 +424,8 @@ int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int
  *   width of the projection that follows (its weight planes share the workspace); n_long hub rows pass through an fp32
  *   scratch at the end of it.
  * ctgcn_linear_presplit_f32(rows = n_rows*K, n_out, k = d, w, ...) then runs the GEMM on that workspace.
- *   Row plan (row_order, tile_mask: both or neither; only with the GRU layer kernel as consumer: d = 128, n_out = 1, K <= 32).
+ *   Row plan (row_order, tile_mask: both or neither; K <= 64.  K <= 32: one mask word per tile; 33 <= K <= 64 (America-Air max core 64,
+ *   Europe-Air 33): two, tile_mask[2 T] = slots 0-31, tile_mask[2 T + 1] = slots 32-63 - for every consumer of the same plan).
  *   A node whose first stored entry is tagged f has H[v, 0] = ... = H[v, f-1] = relu(x_v) (only the self loop has arrived): rows the
  *   reference computes, stacks and multiplies by W_ih f times (layers.py:41-48,58-59).  With a plan, operand rows p K .. p K + K - 1
  *   belong to matrix row row_order[p] (a permutation that puts rows with equal repeat patterns next to each other, so that the 16

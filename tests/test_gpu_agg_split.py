@@ -34,6 +34,25 @@ def _nested_adj(n, m, max_core, seed, hub=0, with_mats=False):
     return (adj, kept) if with_mats else adj
 
 
+def _deep_nested_adj(n, top, max_core, seed):
+    """a nested list with more than 32 cores: a clique of `top` nodes, every other node attached to 1 .. top - 4 of them (its core number)"""
+    from ctgcn_amd import CoreAdj
+    from ctgcn_amd.utils import symmetric_csr_from_rows
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    src, dst = [], []
+    for i in range(top):
+        for j in range(i):
+            src.append(i); dst.append(j)
+    for i in range(top, n):
+        for j in rng.choice(top, 1 + (i * 7) % (top - 4), replace=False):
+            src.append(i); dst.append(int(j))
+    src, dst = np.array(src), np.array(dst)
+    csr = symmetric_csr_from_rows(src, dst, rng.integers(1, 5, len(src)) * 0.5, n)
+    kept = O.core_adj_list([O.kcore_matrices(csr)], 0, 1, 1, max_core=max_core)[0]
+    return CoreAdj.from_matrices(kept, device=_dev())
+
+
 def _both(layer, x, adj, monkeypatch, out_view=False):
     from ctgcn_amd import ops
     names = []
@@ -223,8 +242,21 @@ def test_row_plan_with_hub_rows_general_lists_and_k1(monkeypatch):
         cases.append(CoreAdj.from_matrices([mats[0]], device=_dev(), self_loop=True))
         many = CoreAdj.from_matrices([sp.random(300, 300, density=0.01, random_state=100 + j, format="csr", dtype=np.float32) for j in range(40)],
                                      device=_dev(), self_loop=False)
-        assert many.K == 40 and many.row_plan() is None          # masks are 32 bits wide: longer lists run without a plan
+        # 33-64 slots (America-Air max core 64, Europe-Air 33, reference README.md:175-176): two mask words per tile
+        assert many.K == 40 and many.row_plan() is not None and len(many.row_plan()["tile_mask"]) == 2 * -(-300 // 16)
         cases.append(many)
+        cases.append(CoreAdj.from_matrices([sp.random(250, 250, density=0.0004 * (1 + 3 * (j % 5 == 0)), random_state=300 + j, format="csr", dtype=np.float32)
+                                            for j in range(64)], device=_dev(), self_loop=False))
+        assert cases[-1].K == 64 and cases[-1].row_plan() is not None and cases[-1].row_plan()["new_rows"] < -(-250 // 16) * 16 * 64      # repeats in both words
+        # nested lists this deep: a dense graph whose cores reach 45 (max_core caps the list at 64 / 40)
+        for top, mc in ((70, 64), (70, 40), (45, 64)):
+            deep = _deep_nested_adj(600, top, mc, seed=17 + mc)
+            assert 32 < deep.K <= mc and deep.row_plan() is not None and deep.row_plan()["new_rows"] < -(-600 // 16) * 16 * deep.K, deep.K
+            cases.append(deep)
+        too_long = CoreAdj.from_matrices([sp.random(100, 100, density=0.02, random_state=400 + j, format="csr", dtype=np.float32) for j in range(65)],
+                                         device=_dev(), self_loop=False)
+        assert too_long.K == 65 and too_long.row_plan() is None       # beyond 64 slots: no plan
+        cases.append(too_long)
         full = CoreAdj.from_matrices([sp.random(300, 300, density=0.004, random_state=200 + j, format="csr", dtype=np.float32) for j in range(32)],
                                      device=_dev(), self_loop=False)
         assert full.K == 32 and full.row_plan() is not None and full.row_plan()["new_rows"] < 300 * 32      # bit 31 of the masks in use
@@ -239,6 +271,15 @@ def test_row_plan_with_hub_rows_general_lists_and_k1(monkeypatch):
                     monkeypatch.setenv("CTGCN_DEDUP", "0")
                     want = layer(x, a)
                 assert torch.isfinite(got).all() and torch.equal(got, want), (a.n, a.K, d)
+                if a.K > 32:
+                    # against the kernels that never see a step mask (fp32 H, then GEMM / layer kernel): round 4's plan-less layer kernel
+                    # shifted its 32-bit all-ones mask by the step index — undefined from step 32 on, rows off by 1e-1 at K = 40 — and
+                    # this test compared it with itself
+                    with torch.no_grad():
+                        monkeypatch.setenv("CTGCN_AGG_SPLIT", "0")
+                        ref = layer(x, a)
+                        monkeypatch.setenv("CTGCN_AGG_SPLIT", "1")
+                    assert torch.equal(got, ref), (a.n, a.K, d)
     finally:
         CoreAdj.LONG_ROW = old
 

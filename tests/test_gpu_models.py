@@ -425,3 +425,48 @@ def test_multi_stream_snapshot_branches_equal_the_single_stream_forward(monkeypa
     assert m._snapshot_streams(torch.empty(1, device=DEV), n, T, dense) is None
     m = ctgcn_amd.CTGCN(61, 64, 64, 1, 2, T).to(DEV).eval()
     assert m._snapshot_streams(torch.empty(1, device=DEV), n, T, dense) is None
+
+
+@pytest.mark.parametrize("hid", [128, 500])
+def test_core_lists_deeper_than_32_match_the_cpu_oracle(hid, monkeypatch):
+    """America-Air (max core 64) / Europe-Air (33), reference README.md:175-176: a CTGCN-C window whose core lists are 64 and 40 matrices long,
+    inference (row plan with two mask words per tile, and without a plan) and training forward against oracle/torch_path.py.  Round 4 shipped
+    a plan-less layer kernel that was wrong from step 32 on; only self-comparisons covered K > 32."""
+    import ctgcn_amd
+    from ctgcn_amd import CoreAdj
+    from ctgcn_amd.utils import symmetric_csr_from_rows
+    from oracle import oracle as O, torch_path as TP
+    n, T = 400, 2
+    adj, ref_adj = [], []
+    for t, (top, mc) in enumerate(((70, 64), (50, 40))):
+        rng = np.random.default_rng(31 + t)
+        src, dst = [], []
+        for i in range(top):
+            for j in range(i):
+                src.append(i); dst.append(j)
+        for i in range(top, n):
+            for j in rng.choice(top, 1 + (i * 7) % (top - 4), replace=False):
+                src.append(i); dst.append(int(j))
+        g = symmetric_csr_from_rows(np.array(src), np.array(dst), rng.integers(1, 5, len(src)) * 0.5, n)
+        kept = O.core_adj_list([O.kcore_matrices(g)], 0, 1, 1, mc)[0]
+        assert 32 < len(kept) <= mc
+        adj.append(CoreAdj.from_matrices(kept, device=DEV))
+        ref_adj.append([TP.coo_like_reference(m) for m in kept])
+    torch.manual_seed(8)
+    model = ctgcn_amd.CTGCN(24, hid, 128, 1, 2, T).to(DEV).eval()
+    x = [torch.randn(n, 24) for _ in range(T)]
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # 64-step recurrences over rows of a 70-clique saturate the gates: the fp32 CPU path itself is 1e-4 away from float64 here, so the rule is
+    # the one of tests/test_gpu_configs.py (errors against the float64 oracle, held to the fp32 CPU path's)
+    from test_gpu_configs import _oracle_fp32_and_fp64, _compare
+    want, want64, _, _ = _oracle_fp32_and_fp64(sd, x, ref_adj)
+    xd = [v.to(DEV) for v in x]
+    outs = {}
+    with torch.no_grad():
+        for dedup in ("1", "0"):
+            monkeypatch.setenv("CTGCN_DEDUP", dedup)
+            outs[dedup] = model(xd, adj)
+            _compare("deep_core_lists_hid%d_dedup%s" % (hid, dedup), outs[dedup].cpu().numpy(), want.numpy(), want64.numpy(), frac_slack=1.5)
+        assert torch.equal(outs["1"], outs["0"])
+    out_train = model.train()(xd, adj)
+    _compare("deep_core_lists_hid%d_training_forward" % hid, out_train.detach().cpu().numpy(), want.numpy(), want64.numpy(), frac_slack=1.5)

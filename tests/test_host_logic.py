@@ -487,3 +487,41 @@ def test_row_plan_names_exactly_rows_that_repeat_in_the_oracle():
         assert np.array_equal(adj.plan_row_dest(plan, torch.arange(n), False).numpy().reshape(n, K),
                               np.where(bits[np.argsort(order)] == 1, (np.argsort(order) * K)[:, None] + np.arange(K)[None, :], -1))
     assert CoreAdj.from_matrices([general[0]] * 1, self_loop=True).row_plan()["new_rows"] == -(-n // 16) * 16
+
+
+def test_row_plan_over_more_than_32_slots():
+    """33-64 slots: two 32-bit mask words per tile (word 2 T = slots 0-31, word 2 T + 1 = slots 32-63); popcounts, bases and the hub-row
+    destinations follow the 64-bit pattern; beyond 64 slots there is no plan."""
+    import scipy.sparse as sp
+    from ctgcn_amd import CoreAdj
+    n, K = 70, 40
+    mats = [sp.random(n, n, density=0.01, random_state=j, format="csr", dtype=np.float32) for j in range(K)]
+    adj = CoreAdj.from_matrices(mats, self_loop=False)
+    for tile in (adj.PLAN_TILE, adj.PLAN_TILE_GEMM):
+        plan = adj.row_plan(tile)
+        nt = -(-n // tile)
+        words = plan["tile_mask"].long() & 0xffffffff
+        assert words.numel() == 2 * nt and bool((words[1::2] < (1 << (K - 32))).all())
+        order = plan["order"].long().numpy()
+        has = np.zeros((n, K), bool)
+        for j, m in enumerate(mats):
+            has[np.unique(m.nonzero()[0]), j] = True
+        has[:, 0] = True
+        total = 0
+        for t in range(nt):
+            rows = order[t * tile:(t + 1) * tile]
+            want = has[rows].any(0)
+            got = np.array([(int(words[2 * t + (j >> 5)]) >> (j & 31)) & 1 for j in range(K)], bool)
+            assert (got == want).all(), (tile, t)
+            assert int(plan["tile_base"][t]) == total
+            total += int(want.sum()) * tile
+        assert plan["operand_rows"] == total
+        dest = adj.plan_row_dest(plan, torch.arange(n), compact=True).view(n, K).numpy()
+        inv = plan["inverse"].long().numpy()
+        for v in (0, n // 2, n - 1):
+            t = inv[v] // tile
+            bits = has[order[t * tile:(t + 1) * tile]].any(0)
+            rank = np.cumsum(bits) - bits
+            want = np.where(bits, int(plan["tile_base"][t]) + (inv[v] % tile) * bits.sum() + rank, -1)
+            assert (dest[v] == want).all()
+    assert CoreAdj.from_matrices(mats + mats[:25], self_loop=False).row_plan() is None      # 65 slots

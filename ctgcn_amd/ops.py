@@ -528,6 +528,12 @@ def _project_grad(dgi, w_ih, out):
     torch.mm(dgi, w_ih, out=out)
 
 
+def keep_projection_enabled():
+    """CTGCN_KEEP_GI=0: the backward of a GRU with d_in != 128 always recomputes its input projection (A/B runs)"""
+    import os
+    return os.environ.get("CTGCN_KEEP_GI", "1") != "0"
+
+
 def wide_weight_grad_enabled():
     """CTGCN_WIDE_DW=0: dW_ih of a GRU with d_in > 128 stays an fp32 library GEMM (A/B runs)"""
     import os
@@ -546,7 +552,9 @@ def _weight_grad(part, g01, g2, x2d, steps, shift, accumulate):
                                         _stream()), "ctgcn_gru_weight_grad_f32")
 
 
-def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=None):
+def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=None, keep_gi=None):
+    """keep_gi: a list that receives (gi buffer, blocked layout flag) when the projection was materialised in one chunk (training: the
+    backward's recompute pass starts from it instead of splitting x and multiplying by W_ih again)"""
     lib = _lib.load()
     rows, steps, d_in = seq.shape
     hid = w_hh.shape[1]
@@ -575,6 +583,8 @@ def _gru_forward(seq, w_ih, w_hh, bias, b_hn, ln_w, ln_b, eps, reduce_sum, out=N
                 check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_buf), ptr(w_hh), ptr(b_hn), ptr(ln_w), ptr(ln_b), eps,
                                             1 if reduce_sum else 0, ptr(out[lo:lo + n]), ldo, None, split, 1 if blocked else 0,
                                             None, None, None, _stream()), "ctgcn_gru_seq_f32")
+        if keep_gi is not None and len(chunks) == 1:
+            keep_gi.append((gi_buf, blocked))
     return out
 
 
@@ -1134,9 +1144,22 @@ class _GruSeq(torch.autograd.Function):
         else:
             bias, b_hn = None, None
         seq_c = seq.contiguous()
-        out = _gru_forward(seq_c, w_ih.detach(), w_hh.detach().contiguous(), bias, b_hn, ln_w, ln_b, eps, reduce_sum)
+        # d_in != hidden (the 500-wide first layer): the projection gi of a call that runs in one chunk is kept for the backward when it fits
+        # the budget of kept training buffers (CTGCN_TRAIN_PLANES_GB, shared with _CoreDiffusionFused's planes) — the recompute pass then
+        # skips the split of x and the GEMM (Enron-like: 0.7 of ~6 ms per snapshot).  The same bits: it IS the forward's gi.
+        kept = [] if (seq_c.shape[2] != hid and keep_projection_enabled()
+                      and _kept_planes["bytes"] + seq_c.shape[0] * seq_c.shape[1] * 3 * hid * 4 <= _kept_planes["budget"]) else None
+        out = _gru_forward(seq_c, w_ih.detach(), w_hh.detach().contiguous(), bias, b_hn, ln_w, ln_b, eps, reduce_sum, keep_gi=kept)
         ctx.save_for_backward(seq_c, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b)
         ctx.eps, ctx.reduce_sum = eps, reduce_sum
+        ctx.kept_gi = None
+        if kept:
+            import weakref
+            gi_buf, blocked = kept[0]
+            nbytes = gi_buf.numel() * 4
+            _kept_planes["bytes"] += nbytes
+            weakref.finalize(gi_buf, _release_planes, nbytes)
+            ctx.kept_gi = (gi_buf, blocked)
         return out
 
     @staticmethod
@@ -1172,7 +1195,10 @@ class _GruSeq(torch.autograd.Function):
         ln_part = torch.empty(2048, 2 * hid, dtype=torch.float32, device=dev) if ln_w is not None else None
         chunks = _row_chunks(lib, rows, steps, hid)
         cmax = chunks[0][1]
-        gi_flat = _gi_buffer(cmax, steps, hid, dev)                                          # reused as d_gi
+        kept_gi, ctx.kept_gi = ctx.kept_gi, None          # used once: the buffer becomes d_gi below (a second backward recomputes)
+        if kept_gi is not None and len(chunks) != 1:
+            kept_gi = None
+        gi_flat = kept_gi[0] if kept_gi is not None else _gi_buffer(cmax, steps, hid, dev)      # reused as d_gi
         gates_buf = torch.empty(cmax * steps, 4 * hid, dtype=torch.float32, device=dev)
         hseq_buf = torch.empty(cmax, steps, hid, dtype=torch.float32, device=dev)
         dghn_buf = torch.empty(cmax * steps, hid, dtype=torch.float32, device=dev)
@@ -1209,7 +1235,7 @@ class _GruSeq(torch.autograd.Function):
                         check(lib.ctgcn_gru_layer_f32(n, steps, d_in, hid, ptr(xs), xs.stride(1), ptr(w_ih_d), ptr(w_hh_d), ptr(bias), ptr(b_hn), None, None,
                                                       0.0, 0, ptr(hseq), 0, ptr(gates), None, 0, _stream()), "ctgcn_gru_layer_f32")
                 else:
-                    blocked = _project(x2d, w_ih_d, bias, gi_flat, steps_blocked=steps)
+                    blocked = kept_gi[1] if kept_gi is not None else _project(x2d, w_ih_d, bias, gi_flat, steps_blocked=steps)
                     check(lib.ctgcn_gru_seq_f32(n, steps, hid, ptr(gi_flat), ptr(w_hh_d), ptr(b_hn), None, None, 0.0, 0, ptr(hseq), 0,
                                                 ptr(gates), forward_split_mode(), 1 if blocked else 0, None, None, None, _stream()), "ctgcn_gru_seq_f32")
                 # LayerNorm backward on the recomputed pre-norm values (dense, tiny next to the recurrence)

@@ -361,3 +361,42 @@ def test_fused_lstm_gradients_match_torch_autograd(rows, steps, d_in, reduce_sum
     if norm is not None:
         close(norm_d.weight.grad, norm.weight.grad, "ln.weight")
         close(norm_d.bias.grad, norm.bias.grad, "ln.bias")
+
+
+def test_kept_projection_gives_the_recomputed_gradients(monkeypatch):
+    """d_in = 500: the backward starts its recompute pass from the forward's gi (kept under the training buffer budget) or projects x again
+    (CTGCN_KEEP_GI=0, or a second backward through the same graph): the same bits either way, and the budget's accounting returns to zero"""
+    import gc
+    from ctgcn_amd import ops
+    torch.manual_seed(11)
+    rnn = torch.nn.GRU(500, 128, 1, batch_first=True).to(DEV)
+    norm = torch.nn.LayerNorm(128).to(DEV)
+    x = (torch.relu(torch.randn(900, 6, 500, device=DEV)) * 1.5).requires_grad_(True)
+    G = torch.randn(900, 128, device=DEV)
+    base = ops._kept_planes["bytes"]
+
+    def grads(keep, twice=False):
+        monkeypatch.setenv("CTGCN_KEEP_GI", keep)
+        for p in list(rnn.parameters()) + list(norm.parameters()) + [x]:
+            p.grad = None
+        out = ops.gru_sequence(rnn, x, norm, True)
+        if keep == "1":
+            assert ops._kept_planes["bytes"] > base
+        (out * G).sum().backward(retain_graph=twice)
+        first = [p.grad.clone() for p in list(rnn.parameters()) + list(norm.parameters()) + [x]]
+        if twice:                                           # the kept buffer was consumed: this one recomputes; gradients accumulate to 2 x
+            (out * G).sum().backward()
+            second = [p.grad.clone() for p in list(rnn.parameters()) + list(norm.parameters()) + [x]]
+            for a, b in zip(first, second):
+                assert torch.allclose(b, 2 * a, rtol=1e-6, atol=1e-7)
+        return [out.detach().clone()] + first
+
+    a = grads("1")
+    b = grads("0")
+    c = grads("1", twice=True)
+    for u, v, w in zip(a, b, c):
+        assert torch.equal(u, v) and torch.equal(u, w)
+    del a, b, c
+    gc.collect()
+    torch.cuda.synchronize()
+    assert ops._kept_planes["bytes"] == base

@@ -159,6 +159,10 @@ class MLP(nn.Module):
         if not needs_grad and h.dim() == 2 and ops.linear_split_ok(h, layer.weight):
             # fp32-accurate split GEMM on the 16-bit matrix cores (inference), SELU in its epilogue
             return ops.linear_split(h, layer.weight, layer.bias, selu=selu, static_x=static_x), bool(selu)
+        if needs_grad and h.dim() == 2 and ops.linear_train_enabled() and ops.linear_split_ok(h, layer.weight) and ops.plane_cache_enabled() \
+                and h.shape[0] >= 4096:
+            # training: forward and dx on the same GEMM (ops._LinearSplit); small inputs stay with the library (launch-bound either way)
+            return ops.linear_split_train(h, layer.weight, layer.bias, static_x=static_x), False
         return layer(h), False
 
     def forward(self, x):

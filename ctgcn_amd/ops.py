@@ -483,6 +483,43 @@ def linear_split(x2d, weight, bias, out=None, selu=False, static_x=False):
     return out
 
 
+def linear_train_enabled():
+    """CTGCN_LINEAR_TRAIN=0: nn.Linear under autograd stays torch's (fp32 library GEMMs) for A/B runs"""
+    import os
+    return os.environ.get("CTGCN_LINEAR_TRAIN", "1") != "0"
+
+
+class _LinearSplit(torch.autograd.Function):
+    """nn.Linear on dense rows under autograd (layers.py:95-106 in training: the MLP of CTGCN-S, 1 737 -> 500 -> 500 -> 128 on the
+    Facebook-like config): y = x W^T + b and dx = dy W on the split GEMM (the forward's arithmetic), dW = dy^T x — a product that contracts
+    over the ROWS, which the panel kernel does not do — and db stay with the library.  Facebook-like training step: the fp32 library GEMMs
+    of the three layers were 88 of 139 ms."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, static_x):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return linear_split(x, weight, bias, static_x=static_x)       # x itself: the plane cache knows a static x by identity
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            w_t = weight.detach().t().contiguous()                 # [k, n_out]: the "weight" of dx = dy @ w_t^T
+            dx = linear_split(dy, w_t, None) if linear_split_ok(dy, w_t) else dy @ weight.detach()
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(dy.t(), x.detach())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db, None
+
+
+def linear_split_train(x2d, weight, bias, static_x=False):
+    return _LinearSplit.apply(x2d, weight, bias, bool(static_x))
+
+
 def _project(x2d, w_ih, bias, out, steps_blocked=0):
     """out = x2d @ w_ih^T + bias — the GRU input projection.  Returns True when `out` was written in the recurrence
     kernel's blocked tile layout (only asked for with steps_blocked > 0, only done by the fp16x2 kernel), else [rows, 3h]."""

@@ -605,7 +605,7 @@ def main():
                                "(ctgcn_amd.ops._PlaneCache; CTGCN_PLANE_CACHE=0 splits them on every call: facebook-like 26.7 -> 30.4 ms, the other configs "
                                "within noise, profiles/r04_mlp_chain_ab.txt); intermediate activations are split on every call",
         "parity_rule": "SURVEY 8c's rtol 1e-4 / atol 1e-5 holds at UCI size; at the BASELINE config sizes the fp32 CPU path itself misses it on 2e-6 .. 6e-5 of the "
-                       "entries, so tests/test_gpu_configs.py evaluates the oracle in float64 too and holds the HIP path to <= 1.25 x the fp32 CPU path's fraction of "
+                       "entries, so tests/test_gpu_configs.py evaluates the oracle in float64 too (on a node sample of 4 112 - 8 320 rows; the fp32 oracle on every row) and holds the HIP path to <= 1.25 x the fp32 CPU path's fraction of "
                        "entries outside that tolerance, <= 1.5 x its worst error and <= 5e-4 absolute (T = 16 depth: 2.0 x the fraction); gradients at 1 M rows: 1e-4 "
                        "of each tensor's largest entry vs float64 autograd.  Observed: profiles/r05_parity_errors.json",
         "hbm_copy_GBps_measured": copy_bw,

@@ -1,13 +1,15 @@
 """BASELINE configs 2, 3, 4 on the GPU (VERDICT r1 "configs untested"): the HIP path on the Enron / Facebook-S / math / AS
 window shapes (synthetic stand-ins with the datasets' published statistics, reference README.md:168-176) against the CPU
 oracle (oracle/torch_path.py: the reference's torch.sparse path, pinned to reference outputs by tests/test_oracle_golden.py)
-on the FULL output, plus the loader-level integers (K per snapshot, core numbers) bit for bit.
+on the FULL output (fp32 oracle) and on a node sample (float64 oracle, see _oracle_fp32_full_fp64_rows), plus the loader-level integers
+(K per snapshot, core numbers) bit for bit.
 
 Tolerance.  SURVEY.md §8c gives rtol 1e-4 / atol 1e-5 after GRU + LayerNorm, probed on UCI (1 899 nodes, degree <= 198).  At
 these sizes (10^8 output values, hub rows that sum hundreds of 500-wide terms, degree features of magnitude 10^2-10^3 through
 three SELU layers, three stacked recurrences) the fp32 CPU path ITSELF is further than that from the exact result on a small
-fraction of the entries (facebook shape: 3.7e-4 worst).  The oracle is therefore also evaluated in float64 and the HIP path is
-held to the fp32 reference path's OWN distance from that exact result:
+fraction of the entries (facebook shape: 3.7e-4 worst).  The oracle is therefore also evaluated in float64 — since round 5 on a node
+sample (4 096 random rows + the 16 highest-degree ones; config 5: 8 192 + 64 + 64 rows without entries), which is what keeps the suite
+inside its time limit — and the HIP path is held to the fp32 reference path's OWN distance from that exact result on those rows:
   (a) the fraction of entries outside rtol 1e-4 / atol 1e-5 of the float64 result is at most FRAC_SLACK x the fp32 CPU path's
       fraction (+ 1e-6), and against the fp32 oracle itself the HIP output is nowhere further than 5e-4;
   (b) the worst HIP error against float64 is at most WORST_SLACK x the fp32 CPU path's worst error (+ 2e-6).
@@ -55,6 +57,20 @@ def _oracle_fp32_and_fp64(sd, xs, ref_adj, *model_args):
     return want, want64, t32, time.time() - t0 - t32
 
 
+def _oracle_fp32_full_fp64_rows(sd, xs, ref_adj, mats, rows, *model_args):
+    """the fp32 CPU oracle on the FULL output (the reference's path) and the float64 one on the node sample `rows` only (oracle/torch_path.py:
+    ctgcn_rows — row-sliced matrices, pinned against the full path by tests/test_oracle_golden.py): the float64 truth of a whole 1 M-node or
+    Enron-sized window was 40 % of this suite's wall-clock (round 5: 928 s of a 1 200 s limit), and the rule below is a statistic that a few
+    thousand rows x 128 columns x T snapshots estimate as well.  Returns (want fp32 [T, n, d], want64 [T, len(rows), d], seconds, seconds)."""
+    from oracle import torch_path as TP
+    t0 = time.time()
+    with torch.no_grad():
+        want = TP.ctgcn(sd, xs, ref_adj, *model_args)                 # model_type 'S': (out, transform outputs)
+        t32 = time.time() - t0
+        want64 = TP.ctgcn_rows({k: v.double() for k, v in sd.items()}, [x.double() for x in xs], mats, rows, *model_args)
+    return want, want64, t32, time.time() - t0 - t32
+
+
 def _compare(case, got, want, want64, extra=None, frac_slack=FRAC_SLACK, worst_slack=WORST_SLACK):
     """the rule of the module docstring on full output arrays; returns the observed numbers"""
     err = np.abs(got - want)
@@ -69,7 +85,11 @@ def _compare(case, got, want, want64, extra=None, frac_slack=FRAC_SLACK, worst_s
     print("%s: vs fp32 oracle max |err| %.3e mean %.3e; vs fp64 oracle: max HIP %.3e / fp32 CPU path %.3e, fraction outside rtol 1e-4 atol 1e-5 "
           "HIP %.2e / fp32 CPU path %.2e" % (case, err.max(), err.mean(), err_hip64, err_cpu64, bad_hip, bad_cpu))
     _record(case, **obs)
-    assert bad_hip <= frac_slack * bad_cpu + 1e-6 and err.max() <= 5e-4, obs
+    # (the counting noise of the two fractions on a node sample: three standard deviations of a count of bad_cpu x size entries — 6e-6 on
+    # 4 M sampled entries at a fraction of 1.6e-5, nothing on the 1e8 entries of a full array)
+    noise = 3.0 * float(np.sqrt(max(bad_cpu, 1.0 / got.size) / got.size))
+    obs["frac_noise_3sigma"] = noise
+    assert bad_hip <= frac_slack * bad_cpu + noise + 1e-6 and err.max() <= 5e-4, obs
     assert err_hip64 <= worst_slack * err_cpu64 + 2e-6, obs
     return obs
 
@@ -104,7 +124,7 @@ def _build(case):
     for a, l in zip(adj, ref_lists):
         assert a.nnz_per_slot == [m.nnz for m in l]
     ref_adj = [[TP.coo_like_reference(m) for m in l] for l in ref_lists]
-    return c, graphs, adj, ref_adj
+    return c, graphs, adj, ref_adj, ref_lists
 
 
 def _features(c, graphs):
@@ -126,7 +146,7 @@ def test_baseline_config_shapes_match_cpu_oracle(case):
     import ctgcn_amd
     from ctgcn_amd import ops
     from oracle import torch_path as TP
-    c, graphs, adj, ref_adj = _build(case)
+    c, graphs, adj, ref_adj, mats = _build(case)
     xs, input_dim = _features(c, graphs)
     torch.manual_seed(0)
     model = ctgcn_amd.CTGCN(input_dim, c["hid"], 128, c["trans"], c["diff"], c["T"], rnn_type="GRU", model_type=c["model"],
@@ -136,16 +156,20 @@ def test_baseline_config_shapes_match_cpu_oracle(case):
     assert ops.gru_fused_ok(model.rnn, torch.zeros(1, 1, 128, device=DEV))     # the HIP GRU kernels are the ones running
     with torch.no_grad():
         got = model([x.to(DEV) for x in xs], adj)
-    want, want64, t32, t64 = _oracle_fp32_and_fp64(sd, xs, ref_adj, "GRU", c["model"], c["act"])
+    # float64 truth on a node sample: 4 096 random rows + the 16 highest-degree rows of the last (largest) snapshot
+    rows, _ = _sample_rows(graphs[-1], 4096, 16, 0, seed=5)
+    want, want64, t32, t64 = _oracle_fp32_full_fp64_rows(sd, xs, ref_adj, mats, rows, "GRU", c["model"], c["act"])
     if c["model"] == "S":
-        (got, got_tr), (want, want_tr), (want64, _) = got, want, want64
+        (got, got_tr), (want, want_tr) = got, want
         for a, b in zip(got_tr, want_tr):
             scale = float(b.abs().max())
             assert float((a.cpu() - b).abs().max()) <= 1e-5 * scale + 1e-6, "transform outputs (dense Linear + SELU)"
+        del want_tr
     got = got.cpu().numpy()
     want, want64 = want.numpy(), want64.numpy()
-    assert got.shape == want.shape == (c["T"], c["n"], 128)
-    _compare(case, got, want, want64, dict(oracle_fp32_s=t32, oracle_fp64_s=t64))
+    assert got.shape == want.shape == (c["T"], c["n"], 128) and want64.shape == (c["T"], len(rows), 128)
+    assert float(np.abs(got - want).max()) <= 5e-4                       # the whole output against the fp32 oracle
+    _compare(case, got[:, rows], want[:, rows], want64, dict(oracle_fp32_s=t32, oracle_fp64_s=t64, rows=int(len(rows))))
 
 
 # ------------------------------------------------------------------------------------------ config 5 at full size
@@ -186,8 +210,10 @@ def config5():
     model = ctgcn_amd.CTGCN(n, 128, 128, 1, 2, len(graphs)).eval()
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(DEV)
-    want, want64, t32, t64 = _oracle_fp32_and_fp64(sd, xs, ref_adj)
-    return dict(model=model, adj=adj, xs=[x.to(DEV) for x in xs], want=want.numpy(), want64=want64.numpy(), mats=mats, graphs=graphs, sd=sd,
+    # float64 truth on 8 192 random rows + the 64 highest-degree rows (hub-row kernels) + 64 rows without entries of the largest snapshot
+    rows, _ = _sample_rows(graphs[-1], 8192, 64, 64, seed=3)
+    want, want64, t32, t64 = _oracle_fp32_full_fp64_rows(sd, xs, ref_adj, mats, rows)
+    return dict(model=model, adj=adj, xs=[x.to(DEV) for x in xs], want=want.numpy(), want64=want64.numpy(), rows=rows, mats=mats, graphs=graphs, sd=sd,
                 times=dict(oracle_fp32_s=t32, oracle_fp64_s=t64), K=[len(a) for a in adj], nnz=[a.nnz for a in adj])
 
 
@@ -222,7 +248,9 @@ def test_config5_full_size_matches_cpu_oracle(config5, path):
         model.eval()
     got = got.cpu().numpy()
     assert got.shape == c["want"].shape == (2, C5["n"], 128) and np.isfinite(got).all()
-    _compare("config5_full_" + path, got, c["want"], c["want64"], extra)
+    assert float(np.abs(got - c["want"]).max()) <= 5e-4                 # all 1 M rows against the fp32 oracle
+    rows = c["rows"]
+    _compare("config5_full_" + path, got[:, rows], c["want"][:, rows], c["want64"], dict(extra, rows=int(len(rows))))
 
 
 # ------------------------------------------------------------------ training at full size

@@ -470,3 +470,27 @@ def test_core_lists_deeper_than_32_match_the_cpu_oracle(hid, monkeypatch):
         assert torch.equal(outs["1"], outs["0"])
     out_train = model.train()(xd, adj)
     _compare("deep_core_lists_hid%d_training_forward" % hid, out_train.detach().cpu().numpy(), want.numpy(), want64.numpy(), frac_slack=1.5)
+    # and the gradients (recurrences of 64 / 40 steps through ops._GruSeq's backward) against float64 autograd of the oracle, held to the
+    # fp32 CPU path's own distance from it (saturated gates over 64 steps: the fp32 path is 1e-3 of the largest entry away on some tensors)
+    gsel = torch.randn(T, n, 128)
+    grads = {}
+    for tag, cast in (("f64", torch.float64), ("f32", torch.float32)):
+        sdc = {k: v.to(cast).requires_grad_(True) for k, v in sd.items()}
+        ref_c = TP.ctgcn_with_grad(sdc, [v.to(cast) for v in x], [[a.to(cast).coalesce() for a in l] for l in ref_adj] if cast == torch.float64 else ref_adj)
+        (ref_c * gsel.to(cast)).sum().backward()
+        grads[tag] = {k: v.grad for k, v in sdc.items() if v.grad is not None}
+    (out_train * gsel.to(DEV)).sum().backward()
+    checked, worst, worst_cpu = 0, 0.0, 0.0
+    for name, p in model.named_parameters():
+        g64 = grads["f64"].get(name)
+        if g64 is None:
+            continue
+        scale = max(1e-9, float(g64.abs().max()))
+        e_hip = float((p.grad.cpu().double() - g64).abs().max()) / scale
+        e_cpu = float((grads["f32"][name].double() - g64).abs().max()) / scale
+        worst, worst_cpu = max(worst, e_hip), max(worst_cpu, e_cpu)
+        # (n = 400 rows: one ReLU pre-activation that flips at rounding distance of zero moves a summed weight gradient by ~1 / n of its scale)
+        assert e_hip <= max(4.0 * e_cpu, 2e-3), (name, e_hip, e_cpu)
+        checked += 1
+    print("  [tol] K > 32, hid %d: gradients vs float64 oracle over %d tensors, worst |err| / max|grad|: HIP %.3e, fp32 CPU path %.3e" % (hid, checked, worst, worst_cpu))
+    assert checked >= 30

@@ -37,5 +37,33 @@ for rows, k, n in [(1500, 200, 96), (1500, 64, 96), (40_000, 500, 128), (40_000,
     torch.cuda.synchronize()
     bad_total += bad
     print("%7d x %4d x %4d: %d repetitions, %d differ from the first; max err / sum|xw| %.2e" % (rows, k, n, a.reps, bad, err), flush=True)
+# the grouped launches of the 500-wide first layer (round 5: one panel GEMM over the rows of all snapshots, per-snapshot weights by a
+# panel -> snapshot table, the scales of the leaving and the entering snapshot in two LDS slots) against the per-snapshot kernels
+from ctgcn_amd.helper import core_adj_from_scipy  # noqa: E402
+from ctgcn_amd.layers import CoreDiffusion  # noqa: E402
+from ctgcn_amd.synth import dynamic_graph  # noqa: E402
+for n_nodes, T, d in [(3001, 5, 500), (3001, 5, 64), (20_000, 4, 200)]:
+    adjs = [core_adj_from_scipy(g, 6, dev)[0] for g in dynamic_graph(n_nodes, avg_deg=6, snapshots=T, seed=3)]
+    torch.manual_seed(n_nodes + d)
+    mods = [CoreDiffusion(d, 128, a_.K).to(dev).eval() for a_ in adjs]
+    xs = [torch.randn(n_nodes, d, device=dev) for _ in range(T)]
+    rnns, norms = [m.rnn for m in mods], [m.norm for m in mods]
+    with torch.no_grad():
+        assert ops.core_diffusion_wide_group_ok(xs, adjs, rnns, norms)
+        ref = [ops.core_diffusion_split(xs[t], adjs[t], rnns[t], norms[t]) for t in range(T)]
+        bad = 0
+        for i in range(a.reps):
+            if i % 2:
+                with torch.cuda.stream(side):
+                    ops.linear_split(noise_x, noise_w, None)
+                    noise_x[noise_idx[:500_000]].sum()
+            junk = torch.empty((i * 7919) % 5_000_000 + 1, device=dev)      # perturb the allocator: the shared planes move
+            outs = [torch.empty(n_nodes, 128, device=dev) for _ in range(T)]
+            ops.core_diffusion_wide_group(xs, adjs, rnns, norms, outs)
+            bad += 0 if all(torch.equal(o, r) for o, r in zip(outs, ref)) else 1
+            del junk
+    torch.cuda.synchronize()
+    bad_total += bad
+    print("grouped first layer, %d nodes x %d snapshots, d = %d: %d repetitions, %d differ from the per-snapshot kernels" % (n_nodes, T, d, a.reps, bad), flush=True)
 print("TOTAL mismatches:", bad_total)
 sys.exit(1 if bad_total else 0)

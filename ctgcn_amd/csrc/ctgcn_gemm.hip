@@ -226,6 +226,11 @@ struct PanelArgs {
     // groups one after the other (every group padded to whole panels), W / column scales / bias are per group: panel -> group, group -> operands
     const int32_t *panel_group;              // [mtiles] or null (one group: bp / sb / bias above)
     const struct PanelGroup *groups;
+    // chained launch (CHAIN instantiation): the output leaves as the NEXT layer's X operand — per-row scale + two fp16 planes [M, okp],
+    // okp = N rounded up to 64 — instead of fp32 rows: what split_rows_h2_kernel would make of y, bit for bit
+    _Float16 *o1, *o2;
+    float *osc;
+    int32_t okp;
 #ifdef CTGCN_GEMM_TIMELINE
     unsigned long long *timeline;            // diagnostic build: [block][wave 0 / 7][stage < 48][6] s_memtime stamps, see tools/gemm_timeline.py
 #endif
@@ -263,13 +268,15 @@ struct PanelArgs {
 //   * Registers (NT = 3): 96 accumulators + 48 W fragments (two slabs) + 32 X fragments (two row-tile groups) = 176 + addresses; 251 allocated.
 //   * Measured (tools/gemm_bench.py, GEMM alone): 435 180 x 500 x 384 0.55 ms (round 4's 128 x 128 tiles: 0.77), 60 730 x 1 737 x 500 0.27 (0.35),
 //     60 730 x 500 x 500 0.10 (0.15); SQ counters: matrix pipe busy 44 % of the SIMD cycles at the 1.85 GHz the chip holds here, waves parked 40 %.
-template <int NT, bool GROUPED = false>
+template <int NT, bool GROUPED = false, bool CHAIN = false>
 __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a)
 {
     constexpr int PLANE = PBM * PSK;                      // halfs of one plane of a stage (16 KB)
     __shared__ __attribute__((aligned(1024))) _Float16 As[3][2 * PLANE];      // [slot][plane][row][64 k], 16-byte segment g of row r at g ^ (r & 7)
     __shared__ __attribute__((aligned(16))) float s_sb[2][NT * 128];          // column scales / bias of the group of the current panel and of the one before
     __shared__ __attribute__((aligned(16))) float s_bias[2][NT * 128];
+    // CHAIN: a row's scale needs the largest |y| of the row over ALL columns — eight waves' partial maxima, exchanged here ([panel parity][row][wave])
+    __shared__ __attribute__((aligned(16))) float s_rmax[CHAIN ? 2 : 1][CHAIN ? PBM : 1][8];
     __shared__ __attribute__((aligned(256))) float s_sa[4][PBM];               // row scales of panel count & 3 (four: one k stage per panel leaves no barrier between
                                                                               // a late wave's epilogue reads and an early wave's request for the panel after next)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;        // wave: in an SGPR
@@ -439,6 +446,65 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         }
     };
 
+    // CHAIN.  transform: when a panel's last product is in, y = act(acc sa sb + bias) replaces the accumulators IN PLACE and every wave leaves the
+    // largest |y| of its columns per row in s_rmax (read behind the next barrier).  leave: scale = h2_scale(max over the eight waves), planes =
+    // the two fp16 terms of y / scale — the arithmetic of split_rows_h2_kernel on the fp32 row this launch does not write.
+    auto chain_transform = [&](int par, int ss, int rbuf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float s = s_sa[par][r * 16 + arow];
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = (wave * NT + j) * 16 + 4 * (lane >> 4);
+                const f4v sbv = *(const f4v *)&s_sb[ss][n], bv = *(const f4v *)&s_bias[ss][n];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float t = fmaf(acc[r][j][v], s * sbv[v], bv[v]);
+                    float o = t;
+                    if (a.act == 1) {
+                        const float neg = (1.0507009873554804934193349852946f * 1.6732632423543772848170429916717f) * expm1f(fminf(t, 0.f));
+                        o = t > 0.f ? 1.0507009873554804934193349852946f * t : neg;
+                    }
+                    acc[r][j][v] = o;
+                    m = fmaxf(m, fabsf(o));
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            if (lane < 16) s_rmax[rbuf][r * 16 + arow][wave] = m;
+        }
+    };
+    auto chain_leave = [&](int64_t pn, int rbuf, int r0, int r1) __attribute__((always_inline)) {
+        const int64_t m0 = pn * PBM;
+#pragma unroll
+        for (int r = r0; r < r1; ++r) {
+            const int64_t m = m0 + r * 16 + arow;
+            const f4v ma = *(const f4v *)&s_rmax[rbuf][r * 16 + arow][0], mb = *(const f4v *)&s_rmax[rbuf][r * 16 + arow][4];
+            const float rm = fmaxf(fmaxf(fmaxf(ma[0], ma[1]), fmaxf(ma[2], ma[3])), fmaxf(fmaxf(mb[0], mb[1]), fmaxf(mb[2], mb[3])));
+            float sc, inv;
+            h2_scale(rm, sc, inv);
+            if (wave == 0 && lane < 16 && m < a.M) a.osc[m] = sc;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = (wave * NT + j) * 16 + 4 * (lane >> 4);
+                h4v hi, lo;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float xs = acc[r][j][v] * inv;
+                    hi[v] = (_Float16)xs;
+                    lo[v] = (_Float16)(xs - (float)hi[v]);
+                }
+                acc[r][j] = f4v{0.f, 0.f, 0.f, 0.f};
+                if (m < a.M && n < a.okp) {
+                    *(h4v *)(a.o1 + m * a.okp + n) = hi;
+                    *(h4v *)(a.o2 + m * a.okp + n) = lo;
+                }
+            }
+        }
+    };
+    int rbuf = 0;                                         // CHAIN: parity of the panel whose maxima sit in s_rmax (flips per finished panel)
+
     int64_t pan_c = first, pan_2 = first;                 // the stage being multiplied: (panel, k stage); the stage requested two ahead
     int ks_c = 0, ks_2 = 0, par = 0, slot = 0;             // par: (panels finished so far) & 3
     auto advance = [&](int64_t &pn, int &ks) __attribute__((always_inline)) { if (++ks == nks) { ks = 0; pn += stride; } };
@@ -492,7 +558,12 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         const bool leave = ks_c == 0 && it > 0;
         const int64_t pprev = pan_c - stride;
         const int sprev = (par + 3) & 3;
-        slab(slot, 0, 0, [&](int g) __attribute__((always_inline)) { if (leave) epilogue(pprev, sprev, sslot_prev, g * RG, g * RG + RG); }, side0);
+        slab(slot, 0, 0, [&](int g) __attribute__((always_inline)) {
+            if (leave) {
+                if constexpr (CHAIN) chain_leave(pprev, rbuf ^ 1, g * RG, g * RG + RG);
+                else epilogue(pprev, sprev, sslot_prev, g * RG, g * RG + RG);
+            }
+        }, side0);
 #ifdef CTGCN_GEMM_TIMELINE
         if (tl) tl[3] = clock64();
 #endif
@@ -513,6 +584,9 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
         if (tl) tl[5] = clock64();
 #endif
         advance(pan_2, ks_2);
+        if constexpr (CHAIN) {
+            if (ks_n == 0) { chain_transform(par, sslot, rbuf); rbuf ^= 1; }       // the panel is complete: its rows leave in the next stage
+        }
         if (ks_n == 0) par = (par + 1) & 3;
         bw_c = bw_n;
         pan_c = pan_n;
@@ -521,7 +595,8 @@ __global__ __launch_bounds__(512, 2) void gemm_h2_panel_kernel(const PanelArgs a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    epilogue(pan_c - stride, (par + 3) & 3, sslot, 0, 8);
+    if constexpr (CHAIN) chain_leave(pan_c - stride, rbuf ^ 1, 0, 8);
+    else epilogue(pan_c - stride, (par + 3) & 3, sslot, 0, 8);
 }
 
 int device_cus()
@@ -668,6 +743,38 @@ int ctgcn_linear_packed_f32(int64_t rows, int32_t n_out, int32_t k, const void *
         (void)hipFree(a.timeline);
     }
 #endif
+    GEMM_TRY(hipGetLastError());
+    return CTGCN_OK;
+}
+
+int ctgcn_linear_packed_chain_f32(int64_t rows, int32_t n_out, int32_t k, const void *x_planes, const void *w_packed, const float *bias, int32_t activation,
+                                  void *out_planes, size_t out_planes_bytes, void *stream)
+{
+    if (rows < 0 || n_out < 1 || n_out > PCHUNK || k < 1) return ctgcn_set_error_(CTGCN_E_INVALID, "linear_packed_chain: bad sizes (n_out <= 512)");
+    if (activation != CTGCN_ACT_NONE && activation != CTGCN_ACT_SELU) return ctgcn_set_error_(CTGCN_E_INVALID, "linear_packed_chain: unknown activation");
+    if (rows == 0) return CTGCN_OK;
+    if (!x_planes || !w_packed || !out_planes || (reinterpret_cast<uintptr_t>(x_planes) & 255u) || (reinterpret_cast<uintptr_t>(w_packed) & 255u) ||
+        (reinterpret_cast<uintptr_t>(out_planes) & 255u))
+        return ctgcn_set_error_(CTGCN_E_INVALID, "linear_packed_chain: null or misaligned (256 bytes) operand buffers");
+    if (out_planes_bytes < ctgcn_split_planes_bytes(rows, n_out)) return ctgcn_set_error_(CTGCN_E_WORKSPACE, "linear_packed_chain: out_planes too small (ctgcn_split_planes_bytes(rows, n_out))");
+    const PackGeom g = pack_geom(n_out, k);
+    PanelArgs a{};
+    a.M = rows; a.N = n_out; a.Kp = g.kp;
+    a.a1 = (const _Float16 *)x_planes; a.a2 = a.a1 + (size_t)rows * g.kp; a.sa = (const float *)(a.a2 + (size_t)rows * g.kp);
+    a.act = activation;
+    a.mtiles = (rows + PBM - 1) / PBM;
+    const _Float16 *frags = (const _Float16 *)w_packed;
+    a.bp = frags; a.sb = (const float *)(frags + g.frag_halfs); a.bias = bias;
+    a.okp = (int32_t)align_up((size_t)n_out, PSK);
+    a.o1 = (_Float16 *)out_planes; a.o2 = a.o1 + (size_t)rows * a.okp; a.osc = (float *)(a.o2 + (size_t)rows * a.okp);
+    const int64_t blocks = a.mtiles < device_cus() ? a.mtiles : device_cus();
+    const dim3 grid((unsigned)blocks), blk(512);
+    switch (chunk_nt(n_out)) {
+    case 1: hipLaunchKernelGGL((gemm_h2_panel_kernel<1, false, true>), grid, blk, 0, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL((gemm_h2_panel_kernel<2, false, true>), grid, blk, 0, (hipStream_t)stream, a); break;
+    case 3: hipLaunchKernelGGL((gemm_h2_panel_kernel<3, false, true>), grid, blk, 0, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL((gemm_h2_panel_kernel<4, false, true>), grid, blk, 0, (hipStream_t)stream, a); break;
+    }
     GEMM_TRY(hipGetLastError());
     return CTGCN_OK;
 }

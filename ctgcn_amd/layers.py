@@ -167,6 +167,18 @@ class MLP(nn.Module):
 
     def forward(self, x):
         stack = [self.linear] if self.layer_num == 1 else list(self.linears)
+        selu = self.activate_type == 'N'
+        if len(stack) > 1 and not (torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or
+                                                              (torch.is_tensor(x) and x.requires_grad))):
+            # inference through dense layers: a hidden activation leaves its GEMM as the next GEMM's operand planes (ops.linear_chain_ok /
+            # ctgcn_linear_packed_chain_f32) — no fp32 rows written, read back and split between two layers
+            i = 0
+            while i + 1 < len(stack) and ops.linear_chain_ok(x, stack[i].weight, stack[i + 1].weight):
+                x = ops.linear_split(x, stack[i].weight, stack[i].bias, selu=selu, static_x=(i == 0 and ops.is_static(x)), planes_out=True)
+                i += 1
+            if i:
+                x = ops.linear_split(x, stack[i].weight, stack[i].bias, selu=selu)       # the chain's last GEMM: fp32 rows
+                stack = stack[i + 1:]
         for i, layer in enumerate(stack):
             # the first layer's operand is the module's input: when the caller has declared it static (ops.mark_static — node features
             # built once and passed to every forward, train.py:72-76, embedding.py:318; ctgcn_amd.helper.DataLoader does) its operand

@@ -443,21 +443,94 @@ def plane_cache_enabled():
     return os.environ.get("CTGCN_PLANE_CACHE", "1") != "0" and not torch.cuda.is_current_stream_capturing()
 
 
-def linear_split(x2d, weight, bias, out=None, selu=False, static_x=False):
+class Planes(object):
+    """the operand form of a dense activation [rows, k] that never existed as fp32 rows: per-row scale + two fp16 planes, written by the GEMM
+    that produced it (ctgcn_linear_packed_chain_f32) for the GEMM that consumes it"""
+    __slots__ = ("buf", "rows", "k", "device")
+
+    def __init__(self, buf, rows, k):
+        self.buf, self.rows, self.k, self.device = buf, rows, k, buf.device
+
+    @property
+    def shape(self):
+        return (self.rows, self.k)
+
+
+def _linear_chunk_rows(k):
+    kp = -(-k // 64) * 64
+    return max(128, (_LINEAR_WS_MAX // (kp * 4 + 4)) // 128 * 128)
+
+
+def mlp_chain_enabled():
+    """CTGCN_MLP_CHAIN=0: every Linear of an MLP writes fp32 rows and the next one splits them again (A/B runs)"""
+    import os
+    return os.environ.get("CTGCN_MLP_CHAIN", "1") != "0"
+
+
+def linear_chain_ok(x, weight, next_weight):
+    """Inference through two consecutive dense Linear layers (layers.py:95-106): the first one's output can leave as the second one's operand
+    planes (linear_split(..., planes_out=True)) — both on the split GEMM in one row chunk, the hidden width at most 512."""
+    if not (mlp_chain_enabled() and linear_split_enabled() and plane_cache_enabled()):
+        return False
+    if isinstance(x, Planes):
+        rows, k = x.rows, x.k
+        if not (weight.is_cuda and weight.dtype == torch.float32 and weight.stride(1) == 1 and weight.data_ptr() % 4 == 0 and weight.stride(0) >= k):
+            return False
+    else:
+        if not (torch.is_tensor(x) and not x.is_sparse and x.dim() == 2 and linear_split_ok(x, weight)):
+            return False
+        rows, k = x.shape
+    hidden = weight.shape[0]
+    if weight.shape[1] != k or next_weight.shape[1] != hidden or hidden < 32 or hidden > 512:
+        return False
+    if not (next_weight.is_cuda and next_weight.dtype == torch.float32 and next_weight.stride(1) == 1 and next_weight.data_ptr() % 4 == 0):
+        return False
+    return rows > 0 and rows <= _linear_chunk_rows(k) and rows <= _linear_chunk_rows(hidden)
+
+
+def linear_split(x2d, weight, bias, out=None, selu=False, static_x=False, planes_out=False):
     """out[rows, n_out] = x2d @ weight^T + bias in fp32-accurate fp16x2 split arithmetic on the matrix cores (gemm_h2_panel_kernel);
     selu: F.selu applied in the GEMM's epilogue (one pass over the output less).
     The weight's packed operand is built once per weight version (_PlaneCache); static_x: x2d is a tensor the caller feeds to every
-    forward unchanged (mark_static): its planes are kept too."""
+    forward unchanged (mark_static): its planes are kept too.
+    x2d may be a Planes object (the output of a call with planes_out=True: the hidden activations of an MLP go from GEMM to GEMM as operand
+    planes, never as fp32 rows; linear_chain_ok says when)."""
     lib = _lib.load()
     rows, k = x2d.shape
     n_out = weight.shape[0]
-    if out is None:
-        out = torch.empty(rows, n_out, dtype=torch.float32, device=x2d.device)
-    kp = -(-k // 64) * 64
-    chunk = max(128, (_LINEAR_WS_MAX // (kp * 4 + 4)) // 128 * 128)
+    chunk = _linear_chunk_rows(k)
     b = None if bias is None else bias.detach().contiguous()
     w = weight.detach()
     act = _lib.ACT_SELU if selu else _lib.ACT_NONE
+    if isinstance(x2d, Planes) or planes_out:
+        if not (rows <= chunk and plane_cache_enabled()) or (planes_out and n_out > 512):
+            raise ValueError("linear_split: operand planes in / out need one row chunk, the plane cache and n_out <= 512 (linear_chain_ok)")
+        dev = x2d.device
+        with torch.cuda.device(dev):
+            wp = _plane_cache.packed(weight, lib)
+            if isinstance(x2d, Planes):
+                xp = x2d.buf
+            elif static_x and not x2d.requires_grad:
+                xp = _plane_cache.planes(x2d, lib)
+            else:
+                nbytes = int(lib.ctgcn_split_planes_bytes(rows, k))
+                xp = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                with _timed("linear_aux", rows=rows, k=k, split=True):
+                    check(lib.ctgcn_split_rows_f32(rows, k, ptr(x2d), x2d.stride(0), ptr(xp), nbytes, _stream()), "ctgcn_split_rows_f32")
+            if planes_out:
+                obytes = int(lib.ctgcn_split_planes_bytes(rows, n_out))
+                obuf = torch.empty(obytes, dtype=torch.uint8, device=dev)
+                with _timed("linear_split", rows=rows, k=k, n_out=n_out, planes=True, chain=True):
+                    check(lib.ctgcn_linear_packed_chain_f32(rows, n_out, k, ptr(xp), ptr(wp), ptr(b), act, ptr(obuf), obytes, _stream()),
+                          "ctgcn_linear_packed_chain_f32")
+                return Planes(obuf, rows, n_out)
+            if out is None:
+                out = torch.empty(rows, n_out, dtype=torch.float32, device=dev)
+            with _timed("linear_split", rows=rows, k=k, n_out=n_out, planes=True):
+                check(lib.ctgcn_linear_packed_f32(rows, n_out, k, ptr(xp), ptr(wp), ptr(b), act, ptr(out), out.stride(0), _stream()), "ctgcn_linear_packed_f32")
+        return out
+    if out is None:
+        out = torch.empty(rows, n_out, dtype=torch.float32, device=x2d.device)
     if rows <= chunk and plane_cache_enabled():
         with torch.cuda.device(x2d.device):
             wp = _plane_cache.packed(weight, lib)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 26
+#define CTGCN_ABI_VERSION 27
 
 enum {
     CTGCN_OK = 0,
@@ -400,6 +400,12 @@ int ctgcn_split_rows_f32(int64_t rows, int32_t k, const float *x, int64_t ldx, v
 int ctgcn_pack_weight_f32(int32_t n_out, int32_t k, const float *w, int64_t ldw, void *packed, size_t packed_bytes, void *stream);
 int ctgcn_linear_packed_f32(int64_t rows, int32_t n_out, int32_t k, const void *x_planes, const void *w_packed, const float *bias,
                             int32_t activation, float *y, int64_t ldy, void *stream);
+/* ctgcn_linear_packed_f32 whose output leaves as the NEXT layer's X operand (the hidden layers of the MLP, reference layers.py:95-106, in
+ * inference): out_planes = what ctgcn_split_rows_f32(rows, n_out, y) would write for y = act(x w^T + bias) — per-row scale + two fp16 planes
+ * [rows, n_out rounded up to 64], bit for bit — without y going to memory as fp32 and coming back.  n_out <= 512;
+ * out_planes: ctgcn_split_planes_bytes(rows, n_out) bytes, 256-byte aligned. */
+int ctgcn_linear_packed_chain_f32(int64_t rows, int32_t n_out, int32_t k, const void *x_planes, const void *w_packed, const float *bias, int32_t activation,
+                                  void *out_planes, size_t out_planes_bytes, void *stream);
 /* ctgcn_linear_packed_f32 for the operand rows of `groups` snapshots in ONE launch (the 500-wide first layer of a small window): planes1 /
  * planes2 / scales / y hold the rows of all groups one after the other, every group padded to whole panels of 128 rows (total_rows % 128 == 0;
  * rows a group does not fill are multiplied and written like any other: give them finite contents or ignore them); panel_group (DEVICE,

@@ -275,3 +275,52 @@ def test_mlp_training_with_split_linears_against_float64(monkeypatch):
     for n_, a, b in zip(names, errs["1"], errs["0"]):
         print("  [tol] MLP autograd %-18s |err| / max vs float64: split linears %.3e, library linears %.3e" % (n_, a, b))
         assert a <= max(3.0 * b, 5e-6), (n_, a, b)
+
+
+@pytest.mark.parametrize("rows,k,n_out,selu,bias", [(6000, 1737, 500, True, True), (6000, 500, 500, True, True), (129, 96, 40, False, True),
+                                                     (70001, 200, 384, False, False), (300, 64, 512, True, True), (1, 40, 33, True, True)])
+def test_chained_output_planes_equal_the_split_of_the_fp32_output(rows, k, n_out, selu, bias):
+    """ctgcn_linear_packed_chain_f32: the GEMM's output as the next layer's operand planes — bit for bit what ctgcn_split_rows_f32 makes of the
+    fp32 output of ctgcn_linear_packed_f32 (same epilogue arithmetic, row maximum over all eight waves' columns, zero padding to 64 columns)"""
+    from ctgcn_amd import ops, _lib
+    lib = _lib.load()
+    torch.manual_seed(rows + k + n_out)
+    x = torch.randn(rows, k, device=DEV)
+    w = torch.randn(n_out, k, device=DEV) / k ** 0.5
+    b = torch.randn(n_out, device=DEV) if bias else None
+    y = ops.linear_split(x, w, b, selu=selu)
+    nbytes = int(lib.ctgcn_split_planes_bytes(rows, n_out))
+    want = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.ctgcn_split_rows_f32(rows, n_out, y.data_ptr(), y.stride(0), want.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "split")
+    got = ops.linear_split(x, w, b, selu=selu, planes_out=True)
+    assert isinstance(got, ops.Planes) and got.shape == (rows, n_out) and got.buf.numel() == nbytes
+    kp = -(-n_out // 64) * 64
+    used = rows * kp * 4 + rows * 4
+    torch.cuda.synchronize()
+    assert torch.equal(got.buf[:used], want[:used])
+    # and the consumer takes them: the same fp32 rows as from the tensor itself
+    w2 = torch.randn(77, n_out, device=DEV)
+    if n_out >= 32:
+        assert torch.equal(ops.linear_split(got, w2, None), ops.linear_split(y, w2, None))
+
+
+def test_mlp_inference_chain_is_bit_identical(monkeypatch):
+    """MLP.forward in inference: hidden activations go from GEMM to GEMM as operand planes (CTGCN_MLP_CHAIN, default on) — the bits of the
+    layer-by-layer path (fp32 rows written, split again), for the CTGCN-S transform shape (reference layers.py:95-106) and a linear one"""
+    from ctgcn_amd import ops
+    from ctgcn_amd.layers import MLP
+    for dims, act, rows in (((1737, 500, 128, 3), "N", 6000), ((300, 64, 40, 4), "L", 1000), ((96, 500, 128, 2), "N", 129)):
+        torch.manual_seed(dims[0])
+        mlp = MLP(dims[0], dims[1], dims[2], dims[3], activate_type=act).to(DEV).eval()
+        x = torch.randn(rows, dims[0], device=DEV)
+        calls = []
+        real = ops.linear_split
+        monkeypatch.setattr(ops, "linear_split", lambda *a_, **k_: (calls.append(bool(k_.get("planes_out"))), real(*a_, **k_))[1])
+        with torch.no_grad():
+            monkeypatch.setenv("CTGCN_MLP_CHAIN", "1")
+            got = mlp(x)
+            assert calls == [True] * (dims[3] - 1) + [False], calls
+            monkeypatch.setenv("CTGCN_MLP_CHAIN", "0")
+            want = mlp(x)
+        monkeypatch.setattr(ops, "linear_split", real)
+        assert torch.isfinite(got).all() and torch.equal(got, want), dims

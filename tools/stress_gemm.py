@@ -37,6 +37,24 @@ for rows, k, n in [(1500, 200, 96), (1500, 64, 96), (40_000, 500, 128), (40_000,
     torch.cuda.synchronize()
     bad_total += bad
     print("%7d x %4d x %4d: %d repetitions, %d differ from the first; max err / sum|xw| %.2e" % (rows, k, n, a.reps, bad, err), flush=True)
+# the chained form (round 5: the output leaves as the next layer's operand planes; row maxima exchanged between the eight waves through LDS)
+for rows, k, n in [(60_730, 1737, 500), (60_730, 500, 500), (1500, 64, 96), (40_000, 500, 128), (300_000, 200, 384)]:
+    torch.manual_seed(rows + n + 1)
+    x = torch.randn(rows, k, device=dev)
+    w = torch.randn(n, k, device=dev) / k ** 0.5
+    b = torch.randn(n, device=dev)
+    ref = ops.linear_split(x, w, b, selu=True, planes_out=True).buf.clone()
+    used = rows * (-(-n // 64) * 64) * 4 + rows * 4
+    bad = 0
+    for i in range(a.reps):
+        if i % 2:
+            with torch.cuda.stream(side):
+                ops.linear_split(noise_x, noise_w, None)
+                noise_x[noise_idx[:500_000]].sum()
+        bad += 0 if torch.equal(ops.linear_split(x, w, b, selu=True, planes_out=True).buf[:used], ref[:used]) else 1
+    torch.cuda.synchronize()
+    bad_total += bad
+    print("chained %7d x %4d x %4d: %d repetitions, %d differ from the first" % (rows, k, n, a.reps, bad), flush=True)
 # the grouped launches of the 500-wide first layer (round 5: one panel GEMM over the rows of all snapshots, per-snapshot weights by a
 # panel -> snapshot table, the scales of the leaving and the entering snapshot in two LDS slots) against the per-snapshot kernels
 from ctgcn_amd.helper import core_adj_from_scipy  # noqa: E402

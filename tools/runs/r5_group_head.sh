@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the 500-wide first layer of a small window as grouped launches (ops.core_diffusion_wide_group): one part on the main stream, or one
-# part per lane (CTGCN_GROUP_HEAD_PARTS / CTGCN_STREAMS), against the per-snapshot launches on two lanes (CTGCN_GROUP_HEAD=0).
+# part per lane (CTGCN_GROUP_HEAD_PARTS, an experiment switch that did not survive: parts never helped / CTGCN_STREAMS), against the per-snapshot
+# launches on two lanes (CTGCN_GROUP_HEAD=0).  With the shipped code only the parts=1 rows can be reproduced (CTGCN_GROUP_HEAD=1 forces the grouped form).
 # Forward ms per window of the three 'C' shapes.  Output: gpurun_out/r5_group_head.txt
 mkdir -p gpurun_out
 out=gpurun_out/r5_group_head.txt

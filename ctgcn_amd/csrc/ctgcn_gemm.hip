@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/ctgcn_hip.h"
+#include "ctgcn_jitter.h"          // diagnostic builds (-DCTGCN_JITTER): delays around every barrier; nothing in the product
 
 extern "C" int ctgcn_set_error_(int code, const char *msg);   // defined in ctgcn_hip.hip
 

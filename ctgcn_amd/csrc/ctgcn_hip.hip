@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/ctgcn_hip.h"
+#include "ctgcn_jitter.h"          // diagnostic builds (-DCTGCN_JITTER): delays around every barrier; nothing in the product
 
 namespace {
 
@@ -706,10 +707,14 @@ __global__ __launch_bounds__(256) void kcore_level_kernel(int n, int k, int chun
     };
     int begin = 0, processed = 0;
     for (;;) {
-        __syncthreads();
+        __syncthreads();                   // the pushes of the round before are done
         int tail = min(s_tail, KC_QCAP);
+        // EVERY thread has read s_tail before anybody pushes again.  (Rounds 1-4 had this barrier in the refill branch only: a wave that
+        // read s_tail late — after a faster wave's first push of the new round — saw another `tail`, took another side of the branch below
+        // and met the others at different barriers.  Pushes sit behind two dependent global loads, so it never showed; the barrier-jitter
+        // build of round 5, ctgcn_jitter.h, produced wrong core numbers within seconds.)
+        __syncthreads();
         if (begin == tail) {
-            __syncthreads();               // everyone has read s_tail
             if (tid == 0) {                // refill from this block's spill stack (rare)
                 int m = 0, top = s_top;
                 while (top >= 0 && m < KC_QCAP / 2) { q[m++] = pool_v[top]; top = pool_prev[top]; }
@@ -719,6 +724,7 @@ __global__ __launch_bounds__(256) void kcore_level_kernel(int n, int k, int chun
             __syncthreads();
             begin = 0;
             tail = s_tail;
+            __syncthreads();               // as above: read by everyone before the first push
             if (tail == 0) break;
         }
         // pass A: short neighbour lists, one 16-lane group per vertex; pass B: long lists (hubs, the dense top

@@ -19,6 +19,12 @@ __device__ __forceinline__ void ctgcn_jitter_(unsigned salt)
     case 1: __builtin_amdgcn_s_sleep(24); break;
     case 2: __builtin_amdgcn_s_sleep(64); break;
     case 3: __builtin_amdgcn_s_sleep(127); break;
+#if (CTGCN_JITTER) % 2 == 0                  // even seeds: half of the barriers are touched, with short delays too
+    case 4: __builtin_amdgcn_s_sleep(1); break;
+    case 5: __builtin_amdgcn_s_sleep(3); break;
+    case 6: __builtin_amdgcn_s_sleep(12); break;
+    case 7: __builtin_amdgcn_s_sleep(40); break;
+#endif
     default: break;
     }
 }

@@ -83,9 +83,23 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the host-core baseline and the stock-PyTorch-on-this-GPU baseline")
     ap.add_argument("--train-leg", action="store_true", help="run the training-step leg even with --no-extras (the per-config runs of the default line)")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 forward and the k-core roofline legs")
-    ap.add_argument("--cpu-budget-s", type=float, default=100.0,
-                    help="seconds of host time for the CPU baseline (config 5: three passes of the full 8-matrix loop as COO + three as CSR)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0,
+                    help="seconds of host time for the CPU baseline (SURVEY 8d: a bounded sample, 10-30 s; config 5: one pass of the full 8-matrix loop "
+                         "as COO + one as CSR; --full: 100 s = three passes each)")
+    ap.add_argument("--full", action="store_true",
+                    help="everything the detail file can hold: stock-PyTorch-on-this-GPU baseline, reference-loss training batch, per-config "
+                         "training steps and baselines, forced single-rank RCCL leg (minutes; the default run keeps to the headline, its roofline "
+                         "and CPU baseline plus short legs)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic (two `rocprofv3 --pmc` passes of a 2-step run of this script, FETCH_SIZE and WRITE_SIZE apart)")
+    ap.add_argument("--prewarm-s", type=float, default=1.0, help="seconds of untimed stepping before the warm-up steps (clocks)")
+    ap.add_argument("--detail-file", default=None,
+                    help="where the full record goes (default gpurun_out/bench_detail.json, per workload: bench_detail_<name>.json); stdout "
+                         "carries ONE compact JSON line (< 4 KB)")
+    a = ap.parse_args()
+    if a.full and a.cpu_budget_s == 30.0:
+        a.cpu_budget_s = 100.0
+    return a
 
 
 def algorithmic_bytes(n, nnz, K, d):
@@ -331,7 +345,7 @@ def main():
         return 1000.0 * elapsed / steps, out
 
     copy_bw = measure_copy_bandwidth(dev) if rank == 0 else None
-    ms_per_step, out = timed(args.steps, args.warmup, prewarm_s=1.0)
+    ms_per_step, out = timed(args.steps, args.warmup, prewarm_s=args.prewarm_s)
     assert torch.isfinite(out).all()
     per_rank_ms = None
     if use_dist:
@@ -408,15 +422,15 @@ def main():
                # the three ways to price this launch
                "frac_8d": round(survey_gbps / HBM_PEAK_GBS, 4),
                "frac_moved": round(achieved / HBM_PEAK_GBS, 4),
-               "frac_dram_bracket": 0.735 if d == 128 else None,
                "frac_note": "frac_8d: SURVEY 8d's bytes (every (node, core) output row) / time - can exceed 1 because the row plan does not write the "
-                            "rows that repeat the row before them; frac_moved (= frac): the bytes this launch has to move / time; frac_dram_bracket: "
-                            "the same kernel on a hub-free uniform graph with X = 2 GB = 8 x the Infinity Cache, 5.88 TB/s of 8 "
-                            "(profiles/r04_agg_dram_bracket.txt): the DRAM-bound rate",
+                            "rows that repeat the row before them; frac_moved (= frac): the bytes this launch has to move / time.  (The DRAM-bound "
+                            "bracket of this kernel - hub-free uniform graph, X = 2 GB - was measured once in round 4: 5.88 TB/s = 0.735, "
+                            "profiles/r04_agg_dram_bracket.txt; not re-measured by this run, so not a field)",
                "hbm_written_GBps": round(written / (avg_ms * 1e-3) / 1e9, 1),
-               "traffic": rec["hbm_bytes_per_launch"] if rec else None,
-               "traffic_round": rec.get("round") if rec else None,
-               "traffic_source": rec.get("source", "profiles/pmc_traffic.json") if rec else None,
+               # measured by THIS run (pmc_traffic below fills it in) or null; an earlier round's figure is kept apart, with its provenance
+               "traffic": None,
+               "traffic_earlier_profile": {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "round": rec.get("round"),
+                                           "source": rec.get("source", "profiles/pmc_traffic.json")} if rec else None,
                "launches_timed": len(group), "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(moved),
                "snapshots_per_launch": m0.get("group", 1),
                "ms_per_step_rank0": round(sum(ms for ms, _ in group) / roof_steps, 3),
@@ -556,7 +570,7 @@ def main():
                                   "sweeps x (launch + a pass over the active vertices), not by bandwidth: profiles/r05_kcore_hindex.txt"}
     # ------------------------------------------------------------------------- the reference's own GPU path on THIS GPU (baseline only)
     torch_rocm = None
-    if world == 1 and not use_dist and not args.no_cpu_baseline and not args.train and not args.graph:
+    if world == 1 and not use_dist and args.full and not args.no_cpu_baseline and not args.train and not args.graph:
         try:
             torch_rocm = torch_rocm_baseline(model, x_list, adj_list, W, ms_per_step, first, log)
         except Exception as exc:
@@ -567,7 +581,7 @@ def main():
     train = None
     if (not args.no_extras or args.train_leg) and not args.train and not args.graph and not use_dist and os.environ.get("CTGCN_BENCH_TRAIN_LEG", "1") != "0":
         try:
-            train = training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log)
+            train = training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log, reference_loss=args.full)
         except Exception as exc:          # e.g. out of memory on a box that is not empty: the forward line above must still be printed
             train = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:400])}
             log("training leg failed: %s" % train["error"])
@@ -645,21 +659,155 @@ def main():
     line["forced_dist"] = None
     line["exact_fp32_ms_per_step"] = exact["ms_per_step"] if exact else None
     line["training_step_ms_per_step"] = train.get("ms_per_step") if train else None
+    # roofline.traffic measured by THIS run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE apart) over a 2-step run of this very script
+    headline = args.workload == "synthetic-1m" and world == 1 and not use_dist and not args.train and not args.graph
+    line["pmc"] = None
+    del model, x_list, adj_list, out
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    if world == 1 and not use_dist and not args.no_pmc and not args.train and not args.graph and roof is not None:
+        line["pmc"] = pmc_traffic(args, roof, log)
+        if line["pmc"].get("hbm_bytes_per_launch") is not None:
+            roof["traffic"] = line["pmc"]["hbm_bytes_per_launch"]
+            roof["traffic_over_algorithmic_bytes"] = round(roof["traffic"] / float(roof["algorithmic_bytes_per_launch"]), 4)
     # the other BASELINE configs (2, 3, 4 math / AS) in the SAME driver run: short runs of this script, one after the other, on the same GPU
     line["configs"] = None
-    if args.workload == "synthetic-1m" and world == 1 and not args.train and not args.graph and not args.no_extras \
-            and os.environ.get("CTGCN_BENCH_OTHER_CONFIGS", "1") != "0":
-        del model, x_list, adj_list, out
+    if headline and not args.no_extras and os.environ.get("CTGCN_BENCH_OTHER_CONFIGS", "1") != "0":
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
-        line["configs"] = other_configs(line, log)
-        line["forced_dist"] = forced_dist_leg(args, log)
+        line["configs"] = other_configs(line, log, args.full)
+        if args.full:
+            line["forced_dist"] = forced_dist_leg(args, log)
+    line["bench_wall_s"] = round(time.time() - T_START, 1)
+    detail_path = args.detail_file or os.path.join(ROOT, "gpurun_out", "bench_detail%s.json" % ("" if args.workload == "synthetic-1m" else "_" + args.workload))
+    try:
+        os.makedirs(os.path.dirname(detail_path) or ".", exist_ok=True)
+        with open(detail_path, "w") as fh:
+            json.dump(line, fh, indent=1)
+        log("full record: %s (%d bytes)" % (detail_path, os.path.getsize(detail_path)))
+    except OSError as exc:
+        log("could not write %s: %s" % (detail_path, exc))
+        detail_path = None
+    record = compact_record(line, detail_path)
+    text = json.dumps(record, separators=(",", ":"))
+    assert len(text) < MAX_LINE_BYTES, "bench line is %d bytes (limit %d): move fields to the detail file" % (len(text), MAX_LINE_BYTES)
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
-    print(json.dumps(line), flush=True)
+    print(text, flush=True)
     os.dup2(2, 1)               # whatever RCCL prints while shutting down must not follow the JSON line on stdout
     if use_dist:
         dist.destroy_process_group()
+
+
+MAX_LINE_BYTES = 4096       # the driver keeps ~9 KB of stdout: round 5's 23 KB line did not parse there
+T_START = time.time()
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_record(line, detail_path):
+    """The ONE stdout line: the driver contract's keys + `roofline` + `cpu_baseline` + one-number summaries of the short legs.
+    Everything else (per-config records, kernel tables, GRU / k-core / backward rooflines, notes) is in the detail file."""
+    cfg = line["config"]
+    rec = _pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    rec["config"] = _pick(cfg, ("workload", "name", "nodes", "snapshots", "max_core", "aggregated_edges_per_step", "parallelism"))
+    rec["config"]["workload"] = cfg["workload"][:240]
+    r = line.get("roofline")
+    if r:
+        rr = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "frac_8d", "traffic", "traffic_over_algorithmic_bytes", "avg_launch_ms",
+                       "algorithmic_bytes_per_launch", "launches_timed", "frac_of_measured_copy_bw"))
+        rr["kernel"] = r["kernel"].split(" (")[0]
+        if r["bound"] == "cache":       # the contract's vocabulary is hbm | mfma: the gather of a small window is served on-die (detail: bound_note)
+            rr["bound"], rr["served_by"] = "hbm", "L2 / Infinity Cache (X of a snapshot fits on-die)"
+        rec["roofline"] = rr
+    else:
+        rec["roofline"] = None
+    c = line.get("cpu_baseline")
+    if c:
+        rec["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "value_coalesced_csr", "protocol"))
+        rec["cpu_baseline"]["sample"] = c.get("sample_short", c.get("sample", ""))[:300]
+    else:
+        rec["cpu_baseline"] = None
+    also = {}
+    if line.get("hbm_copy_GBps_measured"):
+        also["hbm_copy_GBps_measured"] = line["hbm_copy_GBps_measured"]["value"]
+    k = line.get("kernel_ms_per_step_rank0")
+    if k:
+        also["kernel_ms_per_step"] = k
+    g = line.get("roofline_gru") or {}
+    g = g.get("fused_layers", g)
+    if g.get("frac") is not None:
+        also["gru_layer_mfma_frac"] = g["frac"]
+    if line.get("exact_fp32"):
+        also["exact_fp32_ms"] = line["exact_fp32"]["ms_per_step"]
+    ts = line.get("training_step")
+    if ts:
+        also["training_step_ms"] = ts.get("ms_per_step", ts.get("error"))
+    kc = line.get("roofline_kcore")
+    if kc:
+        also["kcore_exact_ms"], also["kcore_frac"] = kc["peel_ms_exact"], kc["frac"]
+    if line.get("cpu_baseline_kcore"):
+        also["kcore_cpu_ms"] = round(line["cpu_baseline_kcore"]["value"], 1)
+    if line.get("configs"):
+        also["configs_ms"] = {w: ([c.get("ms_per_step"), (c.get("roofline_d128") or {}).get("frac"), (c.get("training_step") or {}).get("ms_per_step")]
+                                  if "error" not in c else c["error"][:60]) for w, c in line["configs"].items() if w != "synthetic-1m"}
+        also["configs_ms_fields"] = "forward ms, d=128 aggregation frac, training step ms"
+    if line.get("forced_dist"):
+        also["forced_dist_ms"] = line["forced_dist"].get("ms_per_step", "error")
+    if line.get("per_rank_ms"):
+        also["per_rank_ms"] = [[round(p.get(q, 0.0), 2) for q in ("snapshot_branches_ms", "exchange_exposed_ms", "temporal_head_ms")] for p in line["per_rank_ms"]]
+    also["bench_wall_s"] = line.get("bench_wall_s")
+    rec["also"] = also
+    rec["detail_file"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    return rec
+
+
+def pmc_traffic(args, roof, log):
+    """HBM bytes per launch of the dominant aggregation kernel, measured now: `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE`
+    as SEPARATE passes (MI355X_MICROARCH.md: the two do not share a pass) over `bench.py --steps 1 --warmup 1` of the same workload; every
+    launch of the kernel in those runs is averaged, like `achieved` averages every launch of the timed steps.  FETCH_SIZE is in KiB and, on
+    gfx950, counts the 128-byte requests of 16 B/lane streams at 64 B: doubled, as the guide prescribes; WRITE_SIZE in KiB."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not found"}
+    kern = roof["kernel"].split(" ")[0].split("<")[0]
+    res = {"kernel": kern, "command": "rocprofv3 --kernel-trace --pmc <C> -- python bench.py --workload %s --steps 1 --warmup 1 --prewarm-s 0 --no-cpu-baseline "
+                                      "--no-extras --no-pmc (C = FETCH_SIZE, then WRITE_SIZE)" % args.workload}
+    t0 = time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="ctgcn_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
+               "--workload", args.workload, "--steps", "1", "--warmup", "1", "--prewarm-s", "0", "--no-cpu-baseline", "--no-extras", "--no-pmc",
+               "--detail-file", os.path.join(tmp, "detail.json")]
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            files = glob.glob(tmp + "/**/*counter_collection.csv", recursive=True)
+            if p.returncode != 0 or not files:
+                res["error"] = "%s pass: rc %d, %d csv: %s" % (counter, p.returncode, len(files), p.stderr.decode()[-300:])
+                break
+            vals = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not vals:
+                res["error"] = "%s pass: no %s rows" % (counter, kern)
+                break
+            res[counter] = {"launches": len(vals), "mean_KiB": sum(vals) / len(vals)}
+        except subprocess.TimeoutExpired:
+            res["error"] = "%s pass timed out after 240 s" % counter
+            break
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    if "error" not in res:
+        res["fetch_bytes_corrected_x2"] = res["FETCH_SIZE"]["mean_KiB"] * 1024 * 2
+        res["write_bytes"] = res["WRITE_SIZE"]["mean_KiB"] * 1024
+        res["hbm_bytes_per_launch"] = int(res["fetch_bytes_corrected_x2"] + res["write_bytes"])
+    res["seconds"] = round(time.time() - t0, 1)
+    log("pmc traffic: %s (%.0f s)" % (res.get("hbm_bytes_per_launch", res.get("error")), res["seconds"]))
+    return res
 
 
 def dry_run(args):
@@ -742,19 +890,22 @@ def config_summary(line):
             "cpu_baseline": {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "value_coalesced_csr", "protocol")} if cpu else None}
 
 
-def other_configs(main_line, log):
+def other_configs(main_line, log, full=False):
     """{name: summary} for BASELINE configs 2-4 (+ this run's config 5): `python bench.py --workload W --steps 20 --no-extras` each, ~10 s."""
     out = {"synthetic-1m": config_summary(main_line)}
     for w in ("enron-like", "facebook-like", "math-like", "as-like"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "20", "--warmup", "3", "--no-extras", "--train-leg", "--cpu-budget-s", "4"]
+        detail = os.path.join(ROOT, "gpurun_out", "bench_detail_%s.json" % w)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "20", "--warmup", "3", "--no-extras", "--train-leg", "--no-pmc",
+               "--detail-file", detail] + (["--full", "--cpu-budget-s", "4"] if full else ["--no-cpu-baseline"])
         t0 = time.time()
         try:
+            if os.path.exists(detail):
+                os.remove(detail)
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
-            rows = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
-            if p.returncode != 0 or not rows:
+            if p.returncode != 0 or not os.path.exists(detail):
                 out[w] = {"error": "rc %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
             else:
-                out[w] = config_summary(json.loads(rows[-1]))
+                out[w] = config_summary(json.load(open(detail)))
         except subprocess.TimeoutExpired:
             out[w] = {"error": "timed out after 240 s"}
         log("config %s: %s (%.1f s)" % (w, out[w].get("ms_per_step", out[w].get("error")), time.time() - t0))
@@ -765,17 +916,17 @@ def forced_dist_leg(args, log):
     """The SAME window through the sharded code path with ONE rank under RCCL (CTGCN_FORCE_DIST=1: process group, all_to_all exchange of the
     snapshot states, temporal GRU on the receive buffer) — the first point of a SCALE curve is this path at N = 1, so the driver's N = 1 number
     can be checked against the headline (what is left is RCCL's send -> recv copy of 8 GB that a single rank does for nothing)."""
+    detail = os.path.join(ROOT, "gpurun_out", "bench_detail_forced_dist.json")
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--no-extras", "--no-cpu-baseline"]
+           "--no-extras", "--no-cpu-baseline", "--no-pmc", "--detail-file", detail]
     env = dict(os.environ, CTGCN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     t0 = time.time()
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
-        rows = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
-        if p.returncode != 0 or not rows:
+        if p.returncode != 0 or not os.path.exists(detail):
             return {"error": "rc %d: %s" % (p.returncode, p.stderr.decode()[-300:])}
-        r = json.loads(rows[-1])
+        r = json.load(open(detail))
         out = {"ms_per_step": r["ms_per_step"], "what": "CTGCN_FORCE_DIST=1: one rank, RCCL process group, sharded forward (all_to_all exchange)",
                "per_rank_ms": r.get("per_rank_ms")}
     except subprocess.TimeoutExpired:
@@ -784,7 +935,7 @@ def forced_dist_leg(args, log):
     return out
 
 
-def training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log):
+def training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log, reference_loss=True):
     """fwd + bwd + Adam on the same window (the reference's training step, embedding.py:346-352, with the surrogate loss
     out.square().mean(): the negative-sampling loss is outside the hot path):
     2 warm-up + 3 timed steps after the forward measurement,
@@ -879,7 +1030,7 @@ def training_leg(model, x_list, adj_list, ops, first, agg_edges_step, log):
             lambda m: rs(m) * m["fresh"] * (1536.0 + 516.0 + 512.0),
             lambda m: rs(m) * m["fresh"] * 2.0 * 128 * 384 * (3 + 4))
         log("training step: %.1f ms" % ms)
-        if os.environ.get("CTGCN_BENCH_REFERENCE_LOSS", "1") != "0":
+        if reference_loss and os.environ.get("CTGCN_BENCH_REFERENCE_LOSS", "1") != "0":
             try:
                 res["reference_loss_batch_step"] = reference_loss_leg(model, x_list, adj_list, first, opt, log)
             except Exception as exc:
@@ -1069,6 +1220,9 @@ def cpu_baseline(adj_list, widths, budget_s, log):
     return {"value": edges / res["coo"][0], "unit": "edges/s", "cores": cores, "kind": "port",
             "value_coalesced_csr": edges / res["csr"][0],
             "protocol": "COO: %s; CSR: %s" % (proto["coo"], proto["csr"]),
+            "sample_short": "reference layers.py:41-48 loop (torch.sparse.mm on uncoalesced int64 COO + add + relu; value_coalesced_csr: same on torch CSR) over ALL "
+                            "%d k-core matrices of snapshot %d (largest of the window), %d nodes, widths %s, %d aggregated edges/pass, %d threads" % (
+                                len(mats), pick, n, widths, edges, cores),
             "sample": "oracle/torch_path.py (reference layers.py:41-48 restated: torch.sparse.mm on uncoalesced int64 COO operands as "
                       "utils.py:89-95 builds them + add + relu; `value_coalesced_csr` = the same loop on coalesced torch CSR operands), "
                       "snapshot %d of the window (the largest), the full loop over its %d k-core matrices (%d nodes), feature widths %s, "

@@ -20,6 +20,7 @@ def _free_port():
 def _check(stdout, world):
     lines = [l for l in stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1, lines                      # exactly one line on stdout
+    assert len(lines[0]) < 8192, len(lines[0])         # the driver's record keeps ~9 KB of stdout (a 23 KB line did not parse)
     line = json.loads(lines[0])
     assert line["n_gpus"] == world and line["dry"] is True and line["steps"] == 3 and line["warmup"] == 1
     for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -28,6 +29,24 @@ def _check(stdout, world):
     assert owned == list(range(line["config"]["snapshots"]))          # every snapshot on exactly one rank
     assert [r["rank"] for r in line["per_rank"]] == list(range(world))
     assert line["config"]["assignment"] == [r["snapshots"] for r in line["per_rank"]]
+
+
+def test_compact_record_of_a_full_run_fits_the_driver():
+    """bench.compact_record on the largest record this script has produced (round 5's 23 KB line, kept under profiles/): the stdout line
+    stays under bench.MAX_LINE_BYTES and still carries the contract's keys, `roofline` and `cpu_baseline`."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    full["per_rank_ms"] = [{"snapshot_branches_ms": 20.123, "exchange_exposed_ms": 1.5, "temporal_head_ms": 2.25, "rank": r} for r in range(8)]
+    rec = bench.compact_record(full, os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    text = json.dumps(rec, separators=(",", ":"))
+    assert len(text) < bench.MAX_LINE_BYTES <= 4096, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert rec[key] == full[key], key
+    assert rec["roofline"]["bound"] in ("hbm", "mfma") and rec["roofline"]["frac"] == full["roofline"]["frac"]
+    assert rec["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"] and rec["cpu_baseline"]["kind"] in ("port", "reference")
+    assert rec["config"]["name"] == "synthetic-1m" and "model" not in rec["config"]
+    assert rec["detail_file"] == os.path.join("gpurun_out", "bench_detail.json")
 
 
 def test_bench_self_launch_two_ranks_dry():

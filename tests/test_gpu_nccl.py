@@ -48,12 +48,23 @@ def test_bench_single_rank_sharded_path_matches_plain(tmp_path):
     lines = []
     for force in ("0", "1"):
         env = dict(os.environ, CTGCN_FORCE_DIST=force, MASTER_PORT=str(_free_port()))
+        detail = str(tmp_path / ("detail%s.json" % force))
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--steps", "3", "--warmup", "1",
-                              "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=600)
+                              "--no-cpu-baseline", "--no-extras", "--no-pmc", "--detail-file", detail], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         json_lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         assert len(json_lines) == 1 and out.stdout.strip().splitlines()[-1] == json_lines[0], out.stdout[-500:]   # ONE line, and it is the last
-        lines.append(json.loads(json_lines[0]))
+        # the driver keeps ~9 KB of stdout: round 5's 23 KB line reached it truncated and unparsed
+        assert len(json_lines[0]) < 4096, len(json_lines[0])
+        compact = json.loads(json_lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                    "config", "roofline", "cpu_baseline", "detail_file"):
+            assert key in compact, key
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "algorithmic_bytes_per_launch"):
+            assert key in compact["roofline"], key
+        full = json.load(open(detail))
+        assert full["ms_per_step"] == compact["ms_per_step"] and full["value"] == compact["value"]
+        lines.append(full)
     a, b = lines
     assert a["config"]["aggregated_edges_per_step"] == b["config"]["aggregated_edges_per_step"]
     assert a["config"]["K_per_snapshot"] == b["config"]["K_per_snapshot"]

@@ -14,7 +14,7 @@ ACT_NONE, ACT_SELU = 0, 1
 OP_KCORE = 1
 OP_INGEST = 2
 MAX_SLOTS = 255
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _c = ctypes
 _vp, _i64, _i32, _u32, _int, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_uint32, _c.c_int, _c.c_size_t
@@ -57,12 +57,12 @@ SIGNATURES = {
     "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _i64, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "ctgcn_layernorm_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _i64, _vp, _c.c_float, _vp, _vp, _i32, _vp, _vp]),
     "ctgcn_group_table_bytes": (_sz, [_i32]),
-    "ctgcn_core_aggregate_split_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
-    "ctgcn_gru_layer_presplit_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
-    "ctgcn_transpose_bias_group_f32": (_int, [_i32, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp]),
-    "ctgcn_gru_seq_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "ctgcn_core_aggregate_split_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp, _vp]),
+    "ctgcn_gru_layer_presplit_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp, _vp]),
+    "ctgcn_transpose_bias_group_f32": (_int, [_i32, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp, _vp]),
+    "ctgcn_gru_seq_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp, _vp]),
     "ctgcn_linear_packed_chain_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _sz, _vp]),
-    "ctgcn_linear_packed_group_f32": (_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _sz, _vp]),
+    "ctgcn_linear_packed_group_f32": (_int, [_i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _sz, _vp, _vp]),
     "ctgcn_gru_bwd_blocks": (_i32, [_i64]),
     "ctgcn_gru_layer_presplit_save_f32": (_int, [_i64, _i32, _i32, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctgcn_gru_bwd_rec_f32": (_int, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),

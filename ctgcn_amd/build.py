@@ -8,13 +8,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = [os.path.join(_HERE, "csrc", f) for f in ("ctgcn_hip.hip", "ctgcn_gemm.hip", "ctgcn_gru_bwd.hip", "ctgcn_ingest.hip", "ctgcn_walks.hip", "ctgcn_export.cpp")]
 HDR = os.path.join(os.path.dirname(_HERE), "include", "ctgcn_hip.h")
 JITTER_HDR = os.path.join(_HERE, "csrc", "ctgcn_jitter.h")     # included by the kernel files (inert without -DCTGCN_JITTER): part of the source hash
+TABLE_HDR = os.path.join(_HERE, "csrc", "ctgcn_table.h")       # descriptor-table upload of the grouped launches (both kernel files)
 OUT = os.path.join(_HERE, "csrc", "libctgcn_hip.so")
 STAMP = OUT + ".srchash"          # sha256 of the sources + header + this recipe the .so was built from (travels with it, git-ignored)
 
 
 def source_hash():
     h = hashlib.sha256()
-    for f in SRCS + [HDR, JITTER_HDR, os.path.abspath(__file__)]:
+    for f in SRCS + [HDR, JITTER_HDR, TABLE_HDR, os.path.abspath(__file__)]:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())

@@ -24,7 +24,8 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/ctgcn_hip.h"
-#include "ctgcn_jitter.h"          // diagnostic builds (-DCTGCN_JITTER): delays around every barrier; nothing in the product
+#include "ctgcn_jitter.h"
+#include "ctgcn_table.h"           // descriptor tables of the grouped launches: kernel-argument upload + host shadow          // diagnostic builds (-DCTGCN_JITTER): delays around every barrier; nothing in the product
 
 extern "C" int ctgcn_set_error_(int code, const char *msg);   // defined in ctgcn_hip.hip
 
@@ -782,7 +783,7 @@ int ctgcn_linear_packed_chain_f32(int64_t rows, int32_t n_out, int32_t k, const 
 
 int ctgcn_linear_packed_group_f32(int32_t groups, int64_t total_rows, int32_t n_out, int32_t k, const void *planes1, const void *planes2,
                                   const float *scales, const int32_t *panel_group, const void *const *w_packed, const float *const *bias,
-                                  int32_t activation, float *y, int64_t ldy, void *table, size_t table_bytes, void *stream)
+                                  int32_t activation, float *y, int64_t ldy, void *table, size_t table_bytes, void *shadow, void *stream)
 {
     if (groups < 1 || groups > 1024 || total_rows < 0 || (total_rows % PBM) || n_out < 1 || n_out > PCHUNK || k < 1 || ldy < n_out)
         return ctgcn_set_error_(CTGCN_E_INVALID, "linear_packed_group: bad sizes (rows in whole panels of 128, n_out <= 512)");
@@ -801,7 +802,7 @@ int ctgcn_linear_packed_group_f32(int32_t groups, int64_t total_rows, int32_t n_
         const _Float16 *frags = (const _Float16 *)w_packed[i];
         host[i] = PanelGroup{frags, (const float *)(frags + g.frag_halfs), bias ? bias[i] : nullptr};
     }
-    GEMM_TRY(hipMemcpyAsync(table, host.data(), host.size() * sizeof(PanelGroup), hipMemcpyHostToDevice, (hipStream_t)stream));   // pageable: consumed on return
+    GEMM_TRY(ctgcn_table::upload(table, host.data(), host.size() * sizeof(PanelGroup), shadow, (hipStream_t)stream));
     PanelArgs a{};
     a.M = total_rows; a.N = n_out; a.Kp = g.kp;
     a.a1 = (const _Float16 *)planes1; a.a2 = (const _Float16 *)planes2; a.sa = scales;

@@ -29,7 +29,8 @@
 #include <vector>
 
 #include "../../include/ctgcn_hip.h"
-#include "ctgcn_jitter.h"          // diagnostic builds (-DCTGCN_JITTER): delays around every barrier; nothing in the product
+#include "ctgcn_jitter.h"
+#include "ctgcn_table.h"          // diagnostic builds (-DCTGCN_JITTER): delays around every barrier; nothing in the product
 
 namespace {
 
@@ -4719,7 +4720,7 @@ size_t ctgcn_group_table_bytes(int32_t groups)
 }
 
 int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t d, const ctgcn_agg_split_group_t *g, void *table, size_t table_bytes,
-                                         void *stream)
+                                         void *shadow, void *stream)
 {
     if (groups < 1 || groups > 1024 || !g) return fail(CTGCN_E_INVALID, "core_aggregate_split_group: groups=%d", groups);
     if ((d & 3) || d < 32 || d > 512) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split_group: needs d %% 4 == 0, 32 <= d <= 512 (got %d)", d);
@@ -4737,7 +4738,7 @@ int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t
         if ((q.row_order == nullptr) != (q.tile_mask == nullptr) || (q.row_order && q.K > 32))
             return fail(CTGCN_E_INVALID, "core_aggregate_split_group: group %d: row_order and tile_mask come together, K <= 32 under a plan", i);
         AggSplitGroup &h = host[i];
-        h = AggSplitGroup{};
+        std::memset((void *)&h, 0, sizeof h);           // padding included: the table is compared byte-wise with its shadow
         AggArgs &a = h.a;
         if (layer_form) {
             if (!q.workspace || (reinterpret_cast<uintptr_t>(q.workspace) & 255u) || q.planes1 || q.tile_base)
@@ -4765,7 +4766,7 @@ int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t
         a.chunks = p.chunks; a.passes = p.passes; a.hub_split = 1;
     }
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(table, host.data(), host.size() * sizeof(AggSplitGroup), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctgcn_table::upload(table, host.data(), host.size() * sizeof(AggSplitGroup), shadow, st));
     const int rows_per_block = p.chunks <= 32 ? 8 : 4;
     const int64_t bpg = (n_rows + rows_per_block - 1) / rows_per_block;
     if (bpg * groups > 0x7fffffffLL) return fail(CTGCN_E_UNSUPPORTED, "core_aggregate_split_group: grid too large");
@@ -4778,7 +4779,7 @@ int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t
 }
 
 int ctgcn_transpose_bias_group_f32(int32_t groups, int64_t n, int32_t d, const float *const *w, int64_t ldw, const float *const *bias, float *const *out,
-                                   int64_t ldo, void *table, size_t table_bytes, void *stream)
+                                   int64_t ldo, void *table, size_t table_bytes, void *shadow, void *stream)
 {
     if (groups < 1 || groups > 1024 || n < 1 || d < 1 || ldw < n || ldo < d || !w || !out) return fail(CTGCN_E_INVALID, "transpose_bias_group: bad arguments");
     if (!table || (reinterpret_cast<uintptr_t>(table) & 255u) || table_bytes < ctgcn_group_table_bytes(groups))
@@ -4791,7 +4792,7 @@ int ctgcn_transpose_bias_group_f32(int32_t groups, int64_t n, int32_t d, const f
         vec = vec && aligned16(w[i]) && aligned16(out[i]);
     }
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(table, host.data(), host.size() * sizeof(TransposeGroup), hipMemcpyHostToDevice, st));      // pageable source: consumed on return
+    HIP_TRY(ctgcn_table::upload(table, host.data(), host.size() * sizeof(TransposeGroup), shadow, st));
     const dim3 grid((unsigned)((n + 63) / 64), (unsigned)((d + 63) / 64), (unsigned)groups);
     if (vec) hipLaunchKernelGGL(transpose_bias_group_kernel<true>, grid, dim3(256), 0, st, n, d, (const TransposeGroup *)table, ldw, ldo);
     else hipLaunchKernelGGL(transpose_bias_group_kernel<false>, grid, dim3(256), 0, st, n, d, (const TransposeGroup *)table, ldw, ldo);
@@ -4799,7 +4800,8 @@ int ctgcn_transpose_bias_group_f32(int32_t groups, int64_t n, int32_t d, const f
     return CTGCN_OK;
 }
 
-int ctgcn_gru_seq_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_seq_group_t *g, void *table, size_t table_bytes, void *stream)
+int ctgcn_gru_seq_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_seq_group_t *g, void *table, size_t table_bytes, void *shadow,
+                            void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_seq_group: only hidden = %d is built (got %d)", GRU_H, hidden);
     if (groups < 1 || groups > 1024 || !g || rows < 1) return fail(CTGCN_E_INVALID, "gru_seq_group: groups=%d rows=%lld", groups, (long long)rows);
@@ -4821,7 +4823,7 @@ int ctgcn_gru_seq_group_f32(int32_t groups, int64_t rows, int32_t hidden, const 
             (q.row_order == nullptr) != (q.tile_base == nullptr) || (q.row_order && q.steps > 32))
             return fail(CTGCN_E_INVALID, "gru_seq_group: bad arguments of group %d", i);
         GruArgs &a = host[i];
-        a = GruArgs{};
+        std::memset((void *)&a, 0, sizeof a);
         a.rows = rows; a.steps = q.steps; a.gi = q.gi; a.whh = q.w_hh; a.bhn = q.b_hn; a.gamma = q.ln_weight; a.beta = q.ln_bias; a.eps = q.ln_eps;
         a.reduce_sum = 1; a.out = q.out; a.gates = nullptr; a.gi_blocked = 0; a.ldo = q.ld_out > 0 ? q.ld_out : GRU_H;
         a.order = q.row_order; a.tmask = q.tile_mask; a.tbase = q.tile_base;
@@ -4845,15 +4847,15 @@ int ctgcn_gru_seq_group_f32(int32_t groups, int64_t rows, int32_t hidden, const 
     hipStream_t st = (hipStream_t)stream;
     char *tb = (char *)table;
     const size_t map_off = ctgcn_group_table_bytes(groups) - 3 * sizeof(int32_t) * 1024;
-    HIP_TRY(hipMemcpyAsync(tb, host.data(), host.size() * sizeof(GruArgs), hipMemcpyHostToDevice, st));            // pageable sources: consumed on return
-    HIP_TRY(hipMemcpyAsync(tb + map_off, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctgcn_table::upload(tb, host.data(), host.size() * sizeof(GruArgs), shadow, st));
+    HIP_TRY(ctgcn_table::upload(tb + map_off, map.data(), map.size() * sizeof(int32_t), shadow ? (char *)shadow + map_off : nullptr, st));
     hipLaunchKernelGGL(gru_seq_h2_group_kernel, dim3((unsigned)used), dim3(512), 0, st, (const GruArgs *)tb, (const int32_t *)(tb + map_off));
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }
 
 int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_layer_group_t *g, void *table, size_t table_bytes,
-                                       void *stream)
+                                       void *shadow, void *stream)
 {
     if (hidden != GRU_H) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit_group: only d_in = hidden = %d is built (got %d)", GRU_H, hidden);
     if (groups < 1 || groups > 1024 || !g || rows < 1) return fail(CTGCN_E_INVALID, "gru_layer_presplit_group: groups=%d rows=%lld", groups, (long long)rows);
@@ -4874,7 +4876,7 @@ int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hid
             (q.row_order == nullptr) != (q.tile_mask == nullptr) || (q.row_order && q.steps > 32))
             return fail(CTGCN_E_INVALID, "gru_layer_presplit_group: bad arguments of group %d", i);
         LayerArgs &a = host[i];
-        a = LayerArgs{};
+        std::memset((void *)&a, 0, sizeof a);
         a.rows = rows; a.steps = q.steps; a.x = nullptr; a.ldx = GRU_H; a.wih = q.w_ih; a.whh = q.w_hh; a.bias_gi = q.bias_gi; a.bhn = q.b_hn;
         a.gamma = q.ln_weight; a.beta = q.ln_bias; a.eps = q.ln_eps; a.out = q.out; a.ldo = q.ld_out > 0 ? q.ld_out : GRU_H;
         const size_t nrow = (size_t)rows * q.steps;
@@ -4903,11 +4905,9 @@ int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hid
     hipStream_t st = (hipStream_t)stream;
     char *tb = (char *)table;
     const size_t map_off = ctgcn_group_table_bytes(groups) - 3 * sizeof(int32_t) * 1024;
-    // `host` / `map` are function-local PAGEABLE vectors: a host-to-device hipMemcpyAsync from pageable memory has consumed its source when it
-    // returns (the runtime stages it; documented HIP behaviour), so they may die with this frame — the price is that the call is not
-    // captured into a hipGraph (ops.group_launch_enabled) and that the host waits for the staging (a few KB).
-    HIP_TRY(hipMemcpyAsync(tb, host.data(), host.size() * sizeof(LayerArgs), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(tb + map_off, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    // the descriptors travel as kernel arguments (ctgcn_table.h: asynchronous, capturable), or not at all when `shadow` says the table is current
+    HIP_TRY(ctgcn_table::upload(tb, host.data(), host.size() * sizeof(LayerArgs), shadow, st));
+    HIP_TRY(ctgcn_table::upload(tb + map_off, map.data(), map.size() * sizeof(int32_t), shadow ? (char *)shadow + map_off : nullptr, st));
     hipLaunchKernelGGL(gru_layer8_h2_group_kernel, dim3((unsigned)used), dim3(512), 0, st, (const LayerArgs *)tb, (const int32_t *)(tb + map_off));
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CTGCN_ABI_VERSION 27
+#define CTGCN_ABI_VERSION 28
 
 enum {
     CTGCN_OK = 0,
@@ -310,10 +310,19 @@ int ctgcn_gru_bwd_in_f32(int64_t rows, int32_t steps, int32_t hidden, const floa
  *   ctgcn_core_aggregate_split_group_f32   = ctgcn_core_aggregate_split_f32(d = 128, n_out = 1, no hub rows) per group, one grid
  *   ctgcn_gru_layer_presplit_group_f32     = ctgcn_gru_layer_presplit_f32 per group, one persistent grid of <= one block per CU: a block serves
  *                                            one snapshot (its weights stay resident), blocks are dealt out in proportion to `work`
- * Same kernels' code per snapshot: bit-identical to the per-snapshot calls.  g: HOST array of `groups` descriptors; table: device scratch,
- * 256-byte aligned, ctgcn_group_table_bytes(groups) bytes, written by an asynchronous copy on `stream` before the launch (do not reuse it for
+ * Same kernels' code per snapshot: bit-identical to the per-snapshot calls.  g: HOST array of `groups` descriptors; table: device memory,
+ * 256-byte aligned, ctgcn_group_table_bytes(groups) bytes, that the call fills on `stream` before the launch (do not reuse it for
  * another call before that call's kernel has run — same stream: fine).  Hub rows (longer than the caller's long-row threshold) are not
  * handled here: windows that have any take the per-snapshot calls.
+ *
+ * How the table is filled (ABI 28; rounds 4-5 used hipMemcpyAsync from pageable memory: a host stall per call, not capturable): the descriptor
+ * bytes travel as kernel arguments of a small writer kernel — asynchronous, stream-ordered, recordable into a hipGraph, no host-to-device copy.
+ * `shadow` (all ctgcn_*_group_f32 calls; may be NULL): HOST memory of the table's size that the caller zero-fills once and keeps together with
+ * `table`.  The call compares this call's descriptors with the shadow; when they are equal the device table is current and NOTHING is written
+ * (the steady state of an inference loop over one window: same graphs, weights and buffers forward after forward); otherwise table and shadow
+ * are rewritten.  A caller that passes a shadow promises that nothing else writes to `table`, and that it always uses the pair on the same
+ * stream (the table's last writer and its readers must be stream-ordered).  One (table, shadow) pair per call site: two calls sharing a table
+ * would rewrite it every time.
  */
 typedef struct {
     const int32_t *row_ptr, *col_idx;
@@ -363,12 +372,13 @@ size_t ctgcn_group_table_bytes(int32_t groups);
  * snapshots): Linear(I) = W^T + b of every snapshot; the aggregation into shared operand planes (ctgcn_agg_split_group_t, GEMM form);
  * ctgcn_linear_packed_group_f32 (one panel GEMM over all snapshots' rows, weights per snapshot); the recurrences. */
 int ctgcn_transpose_bias_group_f32(int32_t groups, int64_t n, int32_t d, const float *const *w, int64_t ldw, const float *const *bias, float *const *out,
-                                   int64_t ldo, void *table, size_t table_bytes, void *stream);
-int ctgcn_gru_seq_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_seq_group_t *g, void *table, size_t table_bytes, void *stream);
+                                   int64_t ldo, void *table, size_t table_bytes, void *shadow, void *stream);
+int ctgcn_gru_seq_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_seq_group_t *g, void *table, size_t table_bytes, void *shadow,
+                            void *stream);
 int ctgcn_core_aggregate_split_group_f32(int32_t groups, int64_t n_rows, int32_t d, const ctgcn_agg_split_group_t *g, void *table, size_t table_bytes,
-                                         void *stream);
+                                         void *shadow, void *stream);
 int ctgcn_gru_layer_presplit_group_f32(int32_t groups, int64_t rows, int32_t hidden, const ctgcn_gru_layer_group_t *g, void *table, size_t table_bytes,
-                                       void *stream);
+                                       void *shadow, void *stream);
 
 /*
  * Dense  y[rows, n_out] = x[rows, k]·w[n_out, k]^T + bias  (bias [n_out] may be NULL) in fp32-accurate fp16x2 split arithmetic on the
@@ -410,11 +420,11 @@ int ctgcn_linear_packed_chain_f32(int64_t rows, int32_t n_out, int32_t k, const 
  * planes2 / scales / y hold the rows of all groups one after the other, every group padded to whole panels of 128 rows (total_rows % 128 == 0;
  * rows a group does not fill are multiplied and written like any other: give them finite contents or ignore them); panel_group (DEVICE,
  * total_rows / 128 entries) names the group of every panel; w_packed[i] / bias[i] (host arrays of device pointers): the group's packed weight
- * and bias.  n_out <= 512.  table: device scratch, 256-byte aligned, >= 24 bytes per group (ctgcn_group_table_bytes covers it), written by an
- * asynchronous copy on `stream`.  Same arithmetic per row as ctgcn_linear_packed_f32: bit-identical to the per-group calls. */
+ * and bias.  n_out <= 512.  table / shadow: as for the other grouped calls above (256-byte aligned device memory, >= 24 bytes per group —
+ * ctgcn_group_table_bytes covers it; optional host shadow of the same size).  Same arithmetic per row as ctgcn_linear_packed_f32: bit-identical to the per-group calls. */
 int ctgcn_linear_packed_group_f32(int32_t groups, int64_t total_rows, int32_t n_out, int32_t k, const void *planes1, const void *planes2,
                                   const float *scales, const int32_t *panel_group, const void *const *w_packed, const float *const *bias,
-                                  int32_t activation, float *y, int64_t ldy, void *table, size_t table_bytes, void *stream);
+                                  int32_t activation, float *y, int64_t ldy, void *table, size_t table_bytes, void *shadow, void *stream);
 int ctgcn_linear_f32(int64_t rows, int32_t n_out, int32_t k, const float *x, int64_t ldx, const float *w, int64_t ldw, const float *bias,
                      int32_t activation, float *y, int64_t ldy, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -57,6 +57,7 @@ SIGNATURES = {
     "ctgcn_gru_seq_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _c.c_float, _int, _vp, _i64, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "ctgcn_layernorm_bwd_f32": (_int, [_i64, _i32, _i32, _vp, _vp, _i64, _vp, _c.c_float, _vp, _vp, _i32, _vp, _vp]),
     "ctgcn_group_table_bytes": (_sz, [_i32]),
+    "ctgcn_table_uploads": (ctypes.c_uint64, [_int]),
     "ctgcn_core_aggregate_split_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp, _vp]),
     "ctgcn_gru_layer_presplit_group_f32": (_int, [_i32, _i64, _i32, _vp, _vp, _sz, _vp, _vp]),
     "ctgcn_transpose_bias_group_f32": (_int, [_i32, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp, _vp]),

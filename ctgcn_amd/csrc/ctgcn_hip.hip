@@ -22,6 +22,7 @@
 //   K outputs need only two accumulators per lane (P = running A_j·x, R = running res_j) whatever K is.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -758,10 +759,17 @@ __global__ __launch_bounds__(256) void kcore_level_kernel(int n, int k, int chun
 // ever decrease and never pass below the core number, in any update order, so sweeps update h IN PLACE and may read stale neighbours (another
 // XCD's L2): a stale value is a larger one, the result stays an upper bound.  What must not be lost is the knowledge that a neighbour changed:
 //   * a vertex is recomputed in sweep s when its byte in flags[s & 1] is set (the first FULL sweeps recompute everybody);
-//   * a vertex whose value drops to `now` sets the byte of every neighbour u with h(u) > now in flags[(s + 1) & 1] (plain byte stores of the
-//     value 1 — concurrent writers agree; L2 lines carry byte masks, so bytes written under different XCDs merge at write-back) and the block
-//     that owns a flag clears it after reading it — two sweeps before anybody sets it again, with kernel boundaries in between;
-//   * a sweep that sets no flag has reached the fixed point: ctl->marks[s & 15] == 0.
+//   * a vertex v whose value drops from c to `now` stops counting towards exactly the neighbours u with now < h(u) <= c (it never counted for
+//     h(u) > c, it still counts for h(u) <= now): it sets THEIR bytes in flags[(s + 1) & 1], and its own (plain byte stores of the value 1 —
+//     concurrent writers agree; L2 lines carry byte masks, so bytes written under different XCDs merge at write-back); the block that owns a
+//     flag clears it after reading it — two sweeps before anybody sets it again, with kernel boundaries in between.  Round 5 flagged every
+//     neighbour with h(u) > now: a degree-5 vertex moving from 5 to 4 had its hub neighbour (h = 84, ~2 000 entries) recomputed from scratch,
+//     and the ~1 000 hubs of the config-5 snapshot were recomputed in nearly every sweep (35 - 54 us of each).  Why the own flag: v reads
+//     h(u) while u may be moving in the same sweep (or sits stale in another XCD's L2) — the value read is then LARGER than the true one and
+//     may fail `<= c` although the true one passes.  But then u changed in this sweep, flagged itself, and is recomputed in the next one
+//     from values that are all visible by then; an u that did not change is read exactly.  By induction no lost update;
+//   * a sweep that sets no flag changed no vertex: the fixed point.  ctl->marks[s & 15] == 0; the NEXT sweep's kernels see that, set ctl->done
+//     and return, and so does every kernel queued behind them: the host queues sweeps in one batch and reads the control block once.
 // Same unique integers as the peel (tests compare both with the Batagelj-Zaversnik oracle); level_cap clips every value at the cap
 // (H of clipped values, clipped, is the clipped H: counts of values >= k for k <= cap do not change).
 constexpr int KH_CHUNK = 1024;      // vertices per block
@@ -771,15 +779,28 @@ struct KhCtl {               // 256 bytes: the head of the workspace (the peel's
     int marks[16];           // flags set by sweep s & 15
     int hubs[16];            // active hub vertices (lists longer than KH_CACHE) queued by sweep s & 15 for kcore_hindex_hub_kernel
     int max_core;
-    int pad[31];
+    int done;                // set on the device by the first sweep that finds its predecessor's counter at zero: every later kernel of the call returns at once
+    int pad[30];
 };
 static_assert(sizeof(KhCtl) == 256, "KhCtl must fit the 256-byte control block of the k-core workspace");
 constexpr int KH_BINS = 8192;
 
-__global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int all_active, int do_mark, int sweep, const int32_t *__restrict__ row_ptr,
+__device__ __forceinline__ bool kh_finished(KhCtl *ctl, int check_prev, int sweep)
+{
+    // uniform over the grid: `done` is only ever written by kernels that return here, marks[(sweep - 1) & 15] is final (kernel boundary)
+    if (__hip_atomic_load(&ctl->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+    if (check_prev && __hip_atomic_load(&ctl->marks[(sweep - 1) & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(&ctl->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int all_active, int do_mark, int check_prev, int sweep, const int32_t *__restrict__ row_ptr,
                                                            const int32_t *__restrict__ col, int32_t *h, uint8_t *flag_in, uint8_t *flag_out, KhCtl *ctl,
                                                            int32_t *hub_list)
 {
+    if (kh_finished(ctl, check_prev, sweep)) return;
     // three queues by list length, filled by the threads that read the flags (each reads its vertices' row_ptr once, all in parallel: a
     // queue scanned by every phase with a row_ptr load per entry to skip the others' vertices cost ~200 us per sweep, active or not)
     __shared__ int q[3][KH_CHUNK];
@@ -829,8 +850,13 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         int nb[KH_TINY], hv[KH_TINY];
 #pragma unroll
         for (int j = 0; j < KH_TINY; ++j) nb[j] = j < deg ? col[s0 + j] : v;
+        unsigned le = 0;                                  // bit j: the neighbour's value is <= c (v counted towards it before this update)
 #pragma unroll
-        for (int j = 0; j < KH_TINY; ++j) hv[j] = nb[j] != v ? min(h[nb[j]], c) : 0;
+        for (int j = 0; j < KH_TINY; ++j) {
+            const int raw = nb[j] != v ? h[nb[j]] : 0;
+            le |= (unsigned)(raw <= c) << j;
+            hv[j] = min(raw, c);
+        }
         unsigned long long c_lo = 0, c_hi = 0;            // counters of the values 1 .. 8 and 9 .. 16
 #pragma unroll
         for (int j = 0; j < KH_TINY; ++j) {
@@ -846,9 +872,10 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         if (now < c) {
             h[v] = now;
             if (do_mark) {
+                flag_out[v] = 1; ++marks;
 #pragma unroll
                 for (int j = 0; j < KH_TINY; ++j)
-                    if (hv[j] > now) { flag_out[nb[j]] = 1; ++marks; }
+                    if (hv[j] > now && ((le >> j) & 1)) { flag_out[nb[j]] = 1; ++marks; }
             }
         }
     }
@@ -864,7 +891,7 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         for (int j = 0; j < PER; ++j) {
             const int e = s0 + lig + KC_GROUP * j;
             nb[j] = e < e0 ? col[e] : v;
-            val[j] = nb[j] != v ? min(h[nb[j]], c) : 0;
+            val[j] = nb[j] != v ? min(h[nb[j]], c + 1) : 0;       // c + 1 = "above c": counts like c for every k <= c, and tells the marking apart
         }
         int klo = 0, khi = c;
         while (klo < khi) {                               // uniform across the group: c and the counts are
@@ -881,9 +908,10 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         if (klo < c) {
             if (lig == 0) h[v] = klo;
             if (do_mark) {
+                if (lig == 0) { flag_out[v] = 1; ++marks; }
 #pragma unroll
                 for (int j = 0; j < PER; ++j)
-                    if (val[j] > klo) { flag_out[nb[j]] = 1; ++marks; }
+                    if (val[j] > klo && val[j] <= c) { flag_out[nb[j]] = 1; ++marks; }
             }
         }
     }
@@ -895,7 +923,7 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         const int c = h[v];
         for (int e = wl; e < deg; e += 64) {
             const int u = col[s0 + e];
-            cache[wv][e] = u != v ? min(h[u], c) : 0;
+            cache[wv][e] = u != v ? min(h[u], c + 1) : 0;
         }
         int klo = 0, khi = c;
         while (klo < khi) {
@@ -908,9 +936,11 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         }
         if (klo < c) {
             if (wl == 0) h[v] = klo;
-            if (do_mark)
+            if (do_mark) {
+                if (wl == 0) { flag_out[v] = 1; ++marks; }
                 for (int e = wl; e < deg; e += 64)
-                    if (cache[wv][e] > klo) { flag_out[col[s0 + e]] = 1; ++marks; }
+                    if (cache[wv][e] > klo && cache[wv][e] <= c) { flag_out[col[s0 + e]] = 1; ++marks; }
+            }
         }
     }
     if (marks) atomicAdd(&s_marks, marks);
@@ -923,13 +953,16 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
 // largest k with count(values >= k) >= k from per-thread suffix sums (a wave probing a 200 000-entry list eleven times would set the sweep's
 // time).  Values are clipped at KH_BINS: a hub whose estimate is still above that comes out at KH_BINS at most — an upper bound, a decrease —
 // and flags ITSELF for the next sweep.
-__global__ __launch_bounds__(256) void kcore_hindex_hub_kernel(int do_mark, int sweep, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col, int32_t *h,
+__global__ __launch_bounds__(256) void kcore_hindex_hub_kernel(int do_mark, int check_prev, int sweep, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col, int32_t *h,
                                                                uint8_t *flag_out, KhCtl *ctl, const int32_t *__restrict__ hub_list)
 {
     __shared__ int hist[KH_BINS + 1];
     __shared__ int part[256];
     __shared__ int s_best, s_marks;
     const int tid = threadIdx.x;
+    if (kh_finished(ctl, check_prev, sweep)) return;
+    // the counters of the NEXT sweep (its kernels start after this one has finished; nobody else touches that slot now)
+    if (blockIdx.x == 0 && tid == 0) { ctl->marks[(sweep + 1) & 15] = 0; ctl->hubs[(sweep + 1) & 15] = 0; }
     const int count = ctl->hubs[sweep & 15];
     int marks = 0;
     for (int i = blockIdx.x; i < count; i += gridDim.x) {
@@ -971,12 +1004,13 @@ __global__ __launch_bounds__(256) void kcore_hindex_hub_kernel(int do_mark, int 
         if (now < c) {
             if (tid == 0) {
                 h[v] = now;
-                if (now == B && B < c) { flag_out[v] = 1; ++marks; }      // clipped, not the h-index yet: look again
+                if (do_mark || (now == B && B < c)) { flag_out[v] = 1; ++marks; }      // changed: look again (clipped at KH_BINS: not the h-index yet)
             }
             if (do_mark)
                 for (int e = s0 + tid; e < e0; e += 256) {
                     const int u = col[e];
-                    if (u != v && h[u] > now) { flag_out[u] = 1; ++marks; }
+                    const int hu = u != v ? h[u] : 0;
+                    if (hu > now && hu <= c) { flag_out[u] = 1; ++marks; }
                 }
         }
     }
@@ -4130,6 +4164,11 @@ extern "C" {
 
 int ctgcn_abi_version(void) { return CTGCN_ABI_VERSION; }
 
+// diagnostic counters of the grouped launches' descriptor tables (ctgcn_table.h): tables written / found current through their shadow
+static std::atomic<uint64_t> g_table_written{0}, g_table_current{0};
+void ctgcn_table_count_(int written) { (written ? g_table_written : g_table_current).fetch_add(1, std::memory_order_relaxed); }
+uint64_t ctgcn_table_uploads(int current) { return (current ? g_table_current : g_table_written).load(std::memory_order_relaxed); }
+
 const char *ctgcn_last_error(void) { return g_err; }
 
 int ctgcn_device_info(char *name_host, size_t name_len, int *cu_count_host)
@@ -4387,32 +4426,30 @@ int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, i
         hipLaunchKernelGGL(kcore_hindex_init_kernel, dim3((unsigned)(((int64_t)nn * 8 + 255) / 256)), dim3(256), 0, st, nn, capv, row_ptr, col_idx, deg, flags);
         const unsigned blocks = (unsigned)((nn + KH_CHUNK - 1) / KH_CHUNK);
         static const int FULL = [] { const char *e = getenv("CTGCN_KCORE_FULL"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
-        constexpr int BATCH = 8;                          // FULL sweeps recompute every vertex (the last of them sets flags); BATCH sweeps per host check
+        // FULL sweeps recompute every vertex (the last of them sets flags).  No host check between sweeps (round 5 read the counters back every 8
+        // sweeps: five or six stream synchronisations inside one call): a sweep that finds its predecessor's counter at zero sets ctl->done and
+        // every kernel queued behind it returns at once (~4 us each), so the sweeps are queued in ONE batch sized for power-law graphs (48; the
+        // config-5 snapshots need 36 - 40), the finish kernel behind them, and the control block is read once.  Graphs that need more (long
+        // paths: one sweep per hop) continue in batches of 32 with a read each.
         KhCtl hk{};
-        for (int sweep = 0;;) {
-            HIP_TRY(hipMemsetAsync(&kc->marks[sweep & 15], 0, BATCH * sizeof(int), st));        // this batch's counters (16 is a multiple of BATCH)
-            HIP_TRY(hipMemsetAsync(&kc->hubs[sweep & 15], 0, BATCH * sizeof(int), st));
-            const int first = sweep;
-            for (int b = 0; b < BATCH; ++b, ++sweep) {
-                hipLaunchKernelGGL(kcore_hindex_kernel, dim3(blocks), dim3(256), 0, st, nn, capv, sweep < FULL ? 1 : 0, sweep >= FULL - 1 ? 1 : 0, sweep,
+        int sweep = 0;
+        for (int batch = 48;; batch = 32) {
+            for (int b = 0; b < batch; ++b, ++sweep) {
+                const int mark = sweep >= FULL - 1 ? 1 : 0, check = sweep >= FULL ? 1 : 0;
+                hipLaunchKernelGGL(kcore_hindex_kernel, dim3(blocks), dim3(256), 0, st, nn, capv, sweep < FULL ? 1 : 0, mark, check, sweep,
                                    row_ptr, col_idx, deg, flags + (size_t)(sweep & 1) * nn, flags + (size_t)((sweep + 1) & 1) * nn, kc, hub_list);
-                hipLaunchKernelGGL(kcore_hindex_hub_kernel, dim3(256), dim3(256), 0, st, sweep >= FULL - 1 ? 1 : 0, sweep, row_ptr, col_idx, deg,
+                hipLaunchKernelGGL(kcore_hindex_hub_kernel, dim3(256), dim3(256), 0, st, mark, check, sweep, row_ptr, col_idx, deg,
                                    flags + (size_t)((sweep + 1) & 1) * nn, kc, hub_list);
             }
+            hipLaunchKernelGGL(kcore_hindex_finish_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, deg, core, kc);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&hk, kc, sizeof(KhCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            bool done = false;
-            for (int b = first; b < sweep; ++b) done = done || (b >= FULL - 1 && hk.marks[b & 15] == 0);      // a marking sweep that set no flag: fixed point
             static const bool trace = getenv("CTGCN_KCORE_TRACE") != nullptr;
-            if (trace) { fprintf(stderr, "kcore sweeps %d..%d flags set:", first, sweep - 1); for (int b = first; b < sweep; ++b) fprintf(stderr, " %d", hk.marks[b & 15]); fprintf(stderr, "\n"); }
-            if (done) break;
+            if (trace) fprintf(stderr, "kcore: %d sweeps queued, done %d, last counter %d\n", sweep, hk.done, hk.marks[(sweep - 1) & 15]);
+            if (hk.done || hk.marks[(sweep - 1) & 15] == 0) break;      // (the batch's last sweep may be the one that set no flag)
             if (sweep > nn + 64) return fail(CTGCN_E_HIP, "kcore: h-index sweeps did not converge");
         }
-        hipLaunchKernelGGL(kcore_hindex_finish_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, deg, core, kc);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&hk, kc, sizeof(KhCtl), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         if (max_core_host) *max_core_host = hk.max_core;
         return CTGCN_OK;
     }
@@ -4432,15 +4469,14 @@ int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, i
         for (int b = 0; b < BATCH && level + b < cap; ++b)
             hipLaunchKernelGGL(kcore_level_kernel, dim3(blocks), dim3(256), 0, st, nn, level + b, chunk, row_ptr, col_idx, deg,
                                claimed, pool_v, pool_prev, ctl);
+        // the result of what has been peeled so far, then ONE read: with the loader's cap (<= 16 levels) the call synchronises once
+        hipLaunchKernelGGL(kcore_copy_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, cap, deg, core);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&h, ctl, sizeof(KcoreCtl), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (h.visited >= nn) break;
         if (level > nn) return fail(CTGCN_E_HIP, "kcore: did not converge (visited %d of %d)", h.visited, nn);
     }
-    hipLaunchKernelGGL(kcore_copy_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, cap, deg, core);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
     if (max_core_host) *max_core_host = h.visited >= nn ? h.max_core : cap;     // survivors exist: max core >= cap, reported as cap
     return CTGCN_OK;
 }

@@ -15,6 +15,8 @@
 #include <cstdint>
 #include <cstring>
 
+extern "C" void ctgcn_table_count_(int written);       // ctgcn_hip.hip: the diagnostic counters behind ctgcn_table_uploads()
+
 namespace ctgcn_table {
 
 constexpr int CHUNK_BYTES = 3584;                  // kernel arguments live in a 4 KB segment; leave room for the two other arguments
@@ -30,7 +32,8 @@ static __global__ __launch_bounds__(256) void table_write_kernel(Chunk c, uint32
 static inline hipError_t upload(void *dst, const void *src, size_t bytes, void *shadow, hipStream_t st)
 {
     if (bytes == 0) return hipSuccess;
-    if (shadow && std::memcmp(shadow, src, bytes) == 0) return hipSuccess;
+    if (shadow && std::memcmp(shadow, src, bytes) == 0) { ctgcn_table_count_(0); return hipSuccess; }
+    ctgcn_table_count_(1);
     if (shadow) std::memset(shadow, 0xff, bytes);           // not current until every chunk is queued
     const char *s = (const char *)src;
     for (size_t off = 0; off < bytes; off += CHUNK_BYTES) {

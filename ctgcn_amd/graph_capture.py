@@ -5,7 +5,10 @@ and the step time is launch + Python overhead, not GPU time.  The whole forward 
 LayerNorm, temporal GRU — only launches kernels on the current stream and allocates through torch's caching allocator
 (no host synchronisation once the adjacency caches are warm), so it can be recorded ONCE into a hipGraph and replayed
 with a single launch.  Adjacency structure and weights are baked in by address: replay sees in-place weight updates
-(`load_state_dict`, optimizer steps) but a different graph needs a new capture.
+(`load_state_dict`, optimizer steps) but a different graph needs a new capture.  That contract has a price: the operand forms the
+eager path caches per weight version (packed W planes, folded GRU biases, the planes of static features) are rebuilt INSIDE the
+graph on every replay.  `frozen_weights=True` records the cached forms instead — the replay is then pure layer kernels — and the
+caller re-captures after changing a weight or a static feature tensor (an embedding run never does, reference embedding.py:302-318).
 
     runner = GraphedInference(model, x_list, adj_list)     # warm-up + capture
     emb = runner()                                          # replay; same tensors as model(x_list, adj_list)
@@ -21,7 +24,7 @@ def _is_dense(x):
 
 
 class GraphedInference:
-    def __init__(self, model, x_list, adj_list, warmup=2):
+    def __init__(self, model, x_list, adj_list, warmup=2, frozen_weights=False):
         single = not isinstance(x_list, (list, tuple))
         xs = [x_list] if single else list(x_list)
         if not all(x is None or torch.is_tensor(x) for x in xs):
@@ -44,8 +47,16 @@ class GraphedInference:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self._out = model(arg, adj_list)
+        self.frozen_weights = bool(frozen_weights)
+        self._held = []                          # frozen: the cached operand buffers the graph reads (kept alive with it)
+        from . import ops
+        if frozen_weights:
+            ops._plane_cache.capture_hold = self._held
+        try:
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self._out = model(arg, adj_list)
+        finally:
+            ops._plane_cache.capture_hold = None
 
     def __call__(self, x_list=None):
         if x_list is not None:

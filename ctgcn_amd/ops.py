@@ -382,6 +382,7 @@ class _PlaneCache(object):
     def __init__(self, limit=48 << 30):
         import collections
         self.limit, self.bytes, self.entries = limit, 0, collections.OrderedDict()
+        self.capture_hold = None                 # a list while a frozen-weights capture runs (graph_capture.GraphedInference)
 
     def _drop(self, key):
         e = self.entries.pop(key, None)
@@ -398,17 +399,27 @@ class _PlaneCache(object):
     def get(self, t, kind, make):
         """make() -> (buffer, nbytes): the operand form `kind` of tensor t, built on the current stream"""
         import weakref
-        if t.is_inference():                     # no version counter to validate against (t._version raises): never cached
+        capturing = torch.cuda.is_current_stream_capturing()
+        if t.is_inference() or (capturing and self.capture_hold is None):
+            # no version counter to validate against (t._version raises): never cached.  Under hipGraph capture the operand form is built
+            # INSIDE the graph, from the tensor's storage at replay time: a replay sees in-place weight updates (graph_capture.py's contract)
             return make()[0]
         key = (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.device), kind)
         e = self.entries.get(key)
         cur = torch.cuda.current_stream(t.device)
         if e is not None and e[0]() is t and e[1] == t._version:
             self.entries.move_to_end(key)
+            if capturing:
+                # GraphedInference(frozen_weights=True): the graph reads the operand form built by the warm-up forwards (the device was
+                # synchronised before the capture began).  The runner keeps the buffer alive for as long as the graph exists.
+                self.capture_hold.append(e[2])
+                return e[2]
             if e[5] != cur:                      # built on another stream: order behind it, keep the buffer alive for this stream too
                 cur.wait_event(e[4])
                 e[2].record_stream(cur)
             return e[2]
+        if capturing:
+            return make()[0]                     # a miss under capture: built in-graph, nothing kept (the buffer belongs to the capture's pool)
         self._drop(key)
         buf, nbytes = make()
         ev = torch.cuda.Event()
@@ -465,7 +476,7 @@ def is_static(x):
 def plane_cache_enabled():
     """CTGCN_PLANE_CACHE=0: ctgcn_linear_f32 splits both operands on every call (round 3's behaviour) for A/B runs."""
     import os
-    return os.environ.get("CTGCN_PLANE_CACHE", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+    return os.environ.get("CTGCN_PLANE_CACHE", "1") != "0"      # (under hipGraph capture _PlaneCache.get builds in-graph and keeps nothing)
 
 
 class Planes(object):
@@ -508,7 +519,9 @@ def linear_chain_ok(x, weight, next_weight):
     hidden = weight.shape[0]
     if weight.shape[1] != k or next_weight.shape[1] != hidden or hidden < 32 or hidden > 512:
         return False
-    if not (next_weight.is_cuda and next_weight.dtype == torch.float32 and next_weight.stride(1) == 1 and next_weight.data_ptr() % 4 == 0):
+    if not (next_weight.is_cuda and next_weight.dtype == torch.float32 and next_weight.dim() == 2 and next_weight.stride(1) == 1
+            and next_weight.data_ptr() % 4 == 0 and next_weight.stride(0) >= next_weight.shape[1] and next_weight.device == weight.device
+            and weight.device == x.device):
         return False
     return rows > 0 and rows <= _linear_chunk_rows(k) and rows <= _linear_chunk_rows(hidden)
 
@@ -604,9 +617,8 @@ class _LinearSplit(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            w_t = weight.detach().t().contiguous()                 # [k, n_out]: the "weight" of dx = dy @ w_t^T
-            dx = linear_split(dy, w_t, None) if linear_split_ok(dy, w_t) else dy @ weight.detach()
+        if ctx.needs_input_grad[0]:                                # dx = dy @ w_t^T with w_t = weight^T [k, n_out], transposed + packed once per version
+            dx = linear_split(dy, _transposed(weight), None) if _transposed_split_ok(dy, weight) else dy @ weight.detach()
         if ctx.needs_input_grad[1]:
             dw = torch.mm(dy.t(), x.detach())
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -646,21 +658,40 @@ def _gi_buffer(rows, steps, hid, device):
     return torch.empty(-(-rows // 64) * 64 * steps * 3 * hid, dtype=torch.float32, device=device)
 
 
+def _transposed(w):
+    """w^T as a contiguous tensor, built once per version of w (every backward re-transposed the weight and pushed the temporary
+    through the packed-operand cache, which keys on the tensor object — an entry added and dropped per call).  The cached transpose is a
+    stable object, so its packed form (linear_split -> _PlaneCache.packed) is kept with it and dies with it when w changes."""
+    def make():
+        t = w.detach().t().contiguous()
+        return t, t.numel() * t.element_size()
+    if not plane_cache_enabled():
+        return make()[0]
+    return _plane_cache.get(w, "transposed", make)
+
+
+def _transposed_split_ok(x2d, w):
+    """linear_split_ok(x2d, w^T contiguous) without building the transpose"""
+    return (linear_split_enabled() and x2d.is_cuda and w.is_cuda and x2d.device == w.device and x2d.dtype == torch.float32 and w.dtype == torch.float32
+            and x2d.dim() == 2 and w.dim() == 2 and x2d.stride(1) == 1 and x2d.data_ptr() % 4 == 0 and x2d.shape[0] > 0 and x2d.shape[1] >= 32
+            and x2d.stride(0) >= x2d.shape[1] and x2d.shape[1] == w.shape[0])
+
+
 def _project_grad(dgi, w_ih, out):
     """out[rows, d_in] = dgi[rows, 3h] @ w_ih — gradient of the input projection w.r.t. its input."""
     if split_mfma_enabled() and w_ih.shape == (384, 128) and w_ih.is_contiguous() and dgi.is_contiguous() \
             and out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0:
         lib = _lib.load()
-        check(lib.ctgcn_gru_input_grad_f32(dgi.shape[0], 128, 128, ptr(dgi), ptr(w_ih), ptr(out), out.stride(0), _stream()),
+        check(lib.ctgcn_gru_input_grad_f32(dgi.shape[0], 128, 128, ptr(dgi), ptr(w_ih.detach()), ptr(out), out.stride(0), _stream()),
               "ctgcn_gru_input_grad_f32")
         return
-    w_t = w_ih.t().contiguous()                    # [d_in, 3h]: the "weight" of out = dgi @ w_t^T (768 KB at d_in = 500, once per call)
-    if linear_split_ok(dgi, w_t) and out.stride(1) == 1:
+    if _transposed_split_ok(dgi, w_ih) and out.stride(1) == 1:
         # the 500-wide first layer (layers.py:59 with input_size = hid_dim): the fp32 library GEMM took 1.8 ms per Enron-like snapshot,
         # 14 % of the training step; split of dgi (0.3 ms) + gemm_h2_panel_kernel (0.45 ms).  Same fp32-accurate arithmetic as the forward.
-        linear_split(dgi, w_t, None, out=out)
+        # w_t [d_in, 3h] is the "weight" of out = dgi @ w_t^T: transposed and packed once per weight version (_transposed)
+        linear_split(dgi, _transposed(w_ih), None, out=out)
         return
-    torch.mm(dgi, w_ih, out=out)
+    torch.mm(dgi, w_ih.detach(), out=out)
 
 
 def keep_projection_enabled():
@@ -1023,6 +1054,13 @@ def core_diffusion_fused(x, adj, rnn, norm):
 _GROUP_MAX_NODES = 200_000
 
 
+def _compute_units(dev):
+    """CUs the persistent kernels of `dev` run on — queried under THAT device (the gate asked the current device, the C side the
+    tensors' device at launch; on a process with several GPUs the two could disagree and the launch refused what the gate had accepted)"""
+    with torch.cuda.device(dev):
+        return int(_lib.load().ctgcn_compute_units())
+
+
 class _GroupTables(object):
     """(device table, host shadow) pairs of the grouped launches (include/ctgcn_hip.h, ABI 28), one per call site, window length and stream,
     kept between forwards: when a call's descriptors equal the shadow the C side writes nothing — the steady state of an inference loop,
@@ -1030,15 +1068,17 @@ class _GroupTables(object):
     bytes, so an entry can never make a launch read a stale table; entries are small (a few KB) and least-recently-used ones go first.
     Under hipGraph capture nothing is cached: a fresh table from the capture's pool, written by the (capturable) writer kernel."""
 
-    def __init__(self, limit=512):
+    def __init__(self, limit=1024):
         import collections
         self.limit, self.entries = limit, collections.OrderedDict()
 
-    def get(self, lib, site, groups, dev):
+    def get(self, lib, site, groups, dev, desc=b""):
+        """desc: the caller's descriptor bytes (its ctypes arrays).  They are part of the key: the caching allocator may alternate between two
+        or three sets of addresses (a forward runs while the previous forward's output is still alive), and every set keeps its own table."""
         nbytes = int(lib.ctgcn_group_table_bytes(groups))
         if torch.cuda.is_current_stream_capturing():
             return torch.empty(nbytes, dtype=torch.uint8, device=dev), None, nbytes
-        key = (site, groups, str(dev), torch.cuda.current_stream(dev).cuda_stream)
+        key = (site, groups, str(dev), torch.cuda.current_stream(dev).cuda_stream, hash(desc))
         e = self.entries.get(key)
         if e is None:
             e = self.entries[key] = (torch.empty(nbytes, dtype=torch.uint8, device=dev), ctypes.create_string_buffer(nbytes))
@@ -1065,7 +1105,7 @@ def core_diffusion_group_ok(xs, adjs, rnns, norms):
     """The width-128 CoreDiffusion layer of a window's snapshots in ONE aggregation launch + ONE GRU layer launch
     (ctgcn_core_aggregate_split_group_f32 / ctgcn_gru_layer_presplit_group_f32): inference, >= 2 snapshots of a small graph that share
     the node set, no hub rows, every snapshot fit for the per-snapshot split path."""
-    if not group_launch_enabled() or len(xs) < 2 or len(xs) > int(_lib.load().ctgcn_compute_units()):
+    if not group_launch_enabled() or len(xs) < 2 or not xs[0].is_cuda or len(xs) > _compute_units(xs[0].device):
         return False          # the grouped GRU launch gives every snapshot at least one block of the persistent grid: longer windows take the per-snapshot path
     n = adjs[0].n
     if n > _GROUP_MAX_NODES:
@@ -1096,8 +1136,6 @@ def core_diffusion_split_group(xs, adjs, rnns, norms, outs):
     keep = []                                         # tensors the descriptors point at, alive until the launches are queued
     use_plan = row_plan_enabled()
     with torch.cuda.device(dev):
-        tb_agg, sh_agg, tb_bytes = _group_tables.get(lib, ("agg128", id(rnns[0])), T, dev)
-        tb_lay, sh_lay, _ = _group_tables.get(lib, ("layer128", id(rnns[0])), T, dev)
         for t, (x, adj, rnn, norm, out) in enumerate(zip(xs, adjs, rnns, norms, outs)):
             K = adj.K
             plan = adj.row_plan() if use_plan else None
@@ -1118,6 +1156,8 @@ def core_diffusion_split_group(xs, adjs, rnns, norms, outs):
             g.out, g.ld_out = ptr(out), out.stride(0)
             g.row_order, g.tile_mask = a.row_order, a.tile_mask
             g.work = (plan["new_rows"] if plan is not None else n * K) + n * K
+        tb_agg, sh_agg, tb_bytes = _group_tables.get(lib, "agg128", T, dev, bytes(agg))
+        tb_lay, sh_lay, _ = _group_tables.get(lib, "layer128", T, dev, bytes(lay))
         nnz = sum(adj.nnz for adj in adjs)
         rows_written = sum((adj.row_plan()["new_rows"] if use_plan else n * adj.K) for adj in adjs)
         with _timed("agg_fwd", n=n, d=128, K=max(adj.K for adj in adjs), nnz=nnz, split=True, group=T, rows_written=rows_written,
@@ -1134,7 +1174,7 @@ def core_diffusion_wide_group_ok(xs, adjs, rnns, norms):
     """The first CoreDiffusion layer (d_in != 128: the 500-wide GRU input of the 'C' configs, layers.py:59) of a window's snapshots in one
     launch per kernel — aggregation into operand planes shared by the window, ONE panel GEMM over all snapshots' rows, one recurrence launch:
     the conditions of core_diffusion_group_ok with the split GEMM (packed weights) as consumer."""
-    if not group_launch_enabled() or len(xs) < 2 or len(xs) > int(_lib.load().ctgcn_compute_units()):
+    if not group_launch_enabled() or len(xs) < 2 or not xs[0].is_cuda or len(xs) > _compute_units(xs[0].device):
         return False
     if forward_split_mode() != 2 or not plane_cache_enabled():
         return False
@@ -1200,9 +1240,6 @@ def core_diffusion_wide_group(xs, adjs, rnns, norms, outs):
         sc = torch.empty(total, dtype=torch.float32, device=dev)
         gi = torch.empty(total, n_out, dtype=torch.float32, device=dev)
         pg = _panel_groups(padded, dev)
-        tb_agg, sh_agg, tb_bytes = _group_tables.get(lib, ("aggwide", id(rnns[0])), T, dev)
-        tb_lin, sh_lin, _ = _group_tables.get(lib, ("linwide", id(rnns[0])), T, dev)
-        tb_seq, sh_seq, _ = _group_tables.get(lib, ("seqwide", id(rnns[0])), T, dev)
         for t, (x, adj, rnn, norm, out, plan) in enumerate(zip(xs, adjs, rnns, norms, outs, plans)):
             K = adj.K
             bias, b_hn = _gru_bias(rnn, hid)
@@ -1226,6 +1263,9 @@ def core_diffusion_wide_group(xs, adjs, rnns, norms, outs):
             g.out, g.ld_out = ptr(out), out.stride(0)
             g.row_order, g.tile_mask, g.tile_base = a.row_order, a.tile_mask, a.tile_base
             g.work = n * K + rows[t]
+        tb_agg, sh_agg, tb_bytes = _group_tables.get(lib, "aggwide", T, dev, bytes(agg))
+        tb_lin, sh_lin, _ = _group_tables.get(lib, "linwide", T, dev, bytes(w_arr) + bytes(b_arr))
+        tb_seq, sh_seq, _ = _group_tables.get(lib, "seqwide", T, dev, bytes(seq))
         nnz = sum(adj.nnz for adj in adjs)
         Kmax = max(adj.K for adj in adjs)
         with _timed("agg_fwd", n=n, d=d, K=Kmax, nnz=nnz, split=True, group=T, rows_written=sum(rows), K_sum=sum(adj.K for adj in adjs)):
@@ -1252,7 +1292,7 @@ def linear_of_identity_group(weights, biases):
     has_bias = all(b is not None for b in biases)
     b_arr = (ctypes.c_void_p * T)(*[b.detach().data_ptr() for b in biases]) if has_bias else None
     with torch.cuda.device(dev):
-        table, shadow, tb_bytes = _group_tables.get(lib, ("transpose", ws[0].data_ptr()), T, dev)
+        table, shadow, tb_bytes = _group_tables.get(lib, "transpose", T, dev, bytes(w_arr) + bytes(o_arr) + (bytes(b_arr) if has_bias else b""))
         with _timed("transpose_bias", n=n, d=d, group=T):
             check(lib.ctgcn_transpose_bias_group_f32(T, n, d, w_arr, ws[0].stride(0), b_arr, o_arr, d, ptr(table), tb_bytes, shadow, _stream()),
                   "ctgcn_transpose_bias_group_f32")
@@ -1384,8 +1424,8 @@ class _GruSeq(torch.autograd.Function):
         if wide_dw:
             wide_cols = [min(c0, d_in - hid) for c0 in range(0, d_in, hid)]
             dw_part_wide = [torch.empty(_DW_PAIRS, 3 * hid, hid, dtype=torch.float32, device=dev) for _ in wide_cols]
-        else:
-            hprev_buf = torch.zeros(cmax, steps, hid, dtype=torch.float32, device=dev)     # [:, 0] stays 0
+        if not split:                                # read only by the library-GEMM weight gradients below (it was allocated and
+            hprev_buf = torch.zeros(cmax, steps, hid, dtype=torch.float32, device=dev)     # zeroed on every split-path backward); [:, 0] stays 0
         with torch.cuda.device(dev):
             for lo, n in chunks:
                 x2d = seq[lo:lo + n].reshape(n * steps, d_in)
@@ -1432,7 +1472,7 @@ class _GruSeq(torch.autograd.Function):
                                                 ptr(dpre) if reduce_sum else None, ptr(w_hh_d), ptr(dgi), ptr(dghn),
                                                 ptr(bias_part), bias_part.shape[0], 1 if split_mfma_enabled() else 0, _stream()),
                       "ctgcn_gru_seq_bwd_f32")
-                _project_grad(dgi, w_ih_d, dseq[lo:lo + n].view(n * steps, d_in))
+                _project_grad(dgi, w_ih, dseq[lo:lo + n].view(n * steps, d_in))        # the parameter itself: its transpose is cached by identity + version
                 db_all += bias_part.sum(0)          # per-block column sums written by the kernel (no re-read of d_gi / d_ghn)
                 if split and d_in == hid:
                     _weight_grad(dw_part_ih, dgi, dgi[:, 2 * hid:], x2d, steps, False, lo > 0)

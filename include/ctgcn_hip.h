@@ -368,6 +368,9 @@ typedef struct {
     int64_t work;
 } ctgcn_gru_seq_group_t;
 size_t ctgcn_group_table_bytes(int32_t groups);
+/* Diagnostic: descriptor tables written by the grouped calls of this process so far (current = 0), or found current through their shadow and
+ * not written (current = 1).  A steady-state inference loop moves only the second counter (tests/test_gpu_group.py). */
+uint64_t ctgcn_table_uploads(int current);
 /* Round 5, the 500-wide first CoreDiffusion layer of a small window in one launch per kernel (reference models.py:243-247 loops over the
  * snapshots): Linear(I) = W^T + b of every snapshot; the aggregation into shared operand planes (ctgcn_agg_split_group_t, GEMM form);
  * ctgcn_linear_packed_group_f32 (one panel GEMM over all snapshots' rows, weights per snapshot); the recurrences. */

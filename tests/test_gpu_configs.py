@@ -12,9 +12,19 @@ sample (4 096 random rows + the 16 highest-degree ones; config 5: 8 192 + 64 + 6
 inside its time limit — and the HIP path is held to the fp32 reference path's OWN distance from that exact result on those rows:
   (a) the fraction of entries outside rtol 1e-4 / atol 1e-5 of the float64 result is at most FRAC_SLACK x the fp32 CPU path's
       fraction (+ 1e-6), and against the fp32 oracle itself the HIP output is nowhere further than 5e-4;
-  (b) the worst HIP error against float64 is at most WORST_SLACK x the fp32 CPU path's worst error (+ 2e-6).
-Observed errors are printed per case and written to gpurun_out/parity_errors/<case>.json (committed copy of a full run:
-profiles/r03_parity_errors.json).
+  (b) the worst HIP error against float64 is at most WORST_SLACK x the fp32 CPU path's worst error (+ 2e-6);
+  (c) (round 6) the RMS error against float64 is at most RMS_SLACK x the fp32 CPU path's — every sampled entry contributes, so unlike (a)
+      this statistic has no sampling noise to speak of: a systematic loss of precision shows here first.
+Observed errors are printed per case and written to gpurun_out/parity_errors/<case>.json.
+
+Where rule (a) is pinned.  Outliers are rare (2e-6 .. 7e-5 of the entries), so on a node sample (a) compares two counts of a few dozen:
+round 5's samples showed HIP / CPU ratios of 1.05 .. 1.71 and needed a counting-noise allowance to pass, which VERDICT r5 rightly
+questioned ("systematic, not noise?").  tools/parity_full.py settles it outside the suite, once per round, on EVERY row of every config in
+float64 (profiles/r06_parity_full.json): ratio 1.03 (config 5; 95 % interval 0.88 - 1.22 from a bootstrap over nodes), 1.09 (math-like),
+1.10 (Enron-like), 1.14 (Facebook-like, 1.08 - 1.20), 0 / 0 (AS-like) — the plain 1.25 x rule holds on the full arrays with no allowance,
+and the build WITHOUT any 16-bit operand (CTGCN_FP32_MFMA_ONLY=1) sits at 1.06: the small excess is accumulation order and the
+1-ulp exp / rcp of the gate math, not the fp16 x 2 split.  The tool fails when a full array breaks 1.25 x / 1.5 x.  In the suite (a) stays a
+consistency check of the sample against that pin: the allowance below is three standard deviations of the sample's own outlier count.
 
 Config 5 (1 M nodes) is held to the same rule at FULL size (test_config5_full_size_matches_cpu_oracle): snapshots 3 and 15 of the
 16-snapshot window, max_core 8, through the inference path (aggregation -> fp16 planes -> register-resident GRU layer kernel), the
@@ -31,6 +41,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 FRAC_SLACK = 1.25       # observed <= 1.16 (profiles/r03_parity_errors.json)
 WORST_SLACK = 1.5       # observed <= 1.40: the single worst of up to 2e8 entries is an extreme-value statistic; round 2 allowed 2.0
+RMS_SLACK = 1.6         # observed on the full arrays (profiles/r06_parity_full.json): 1.07 (Facebook-like) .. 1.48 (Enron-like); both sides ~4e-7
 
 
 def _record(case, **numbers):
@@ -78,19 +89,22 @@ def _compare(case, got, want, want64, extra=None, frac_slack=FRAC_SLACK, worst_s
     d_hip, d_cpu = np.abs(got - want64), np.abs(want - want64)
     bad_hip, bad_cpu = float((d_hip > tol64).mean()), float((d_cpu > tol64).mean())
     err_hip64, err_cpu64 = float(d_hip.max()), float(d_cpu.max())
+    rms_hip, rms_cpu = float(np.sqrt(np.mean(d_hip.astype(np.float64) ** 2))), float(np.sqrt(np.mean(d_cpu.astype(np.float64) ** 2)))
     obs = dict(max_err_vs_fp32_oracle=float(err.max()), mean_err_vs_fp32_oracle=float(err.mean()), max_err_hip_vs_fp64=err_hip64,
                max_err_cpu_fp32_vs_fp64=err_cpu64, frac_outside_hip=bad_hip, frac_outside_cpu_fp32=bad_cpu,
+               outside_hip=int((d_hip > tol64).sum()), outside_cpu_fp32=int((d_cpu > tol64).sum()), rms_err_hip_vs_fp64=rms_hip, rms_err_cpu_fp32_vs_fp64=rms_cpu,
                rule="rtol 1e-4 atol 1e-5 vs fp64; slack %.2f / %.2f" % (frac_slack, worst_slack), shape=list(got.shape))
     obs.update(extra or {})
     print("%s: vs fp32 oracle max |err| %.3e mean %.3e; vs fp64 oracle: max HIP %.3e / fp32 CPU path %.3e, fraction outside rtol 1e-4 atol 1e-5 "
           "HIP %.2e / fp32 CPU path %.2e" % (case, err.max(), err.mean(), err_hip64, err_cpu64, bad_hip, bad_cpu))
     _record(case, **obs)
-    # (the counting noise of the two fractions on a node sample: three standard deviations of a count of bad_cpu x size entries — 6e-6 on
-    # 4 M sampled entries at a fraction of 1.6e-5, nothing on the 1e8 entries of a full array)
+    # (a) on a node sample is a comparison of two small counts: the allowance is three standard deviations of a count of bad_cpu x size
+    # entries (6e-6 on 4 M sampled entries at a fraction of 1.6e-5; nothing on a full array, where tools/parity_full.py applies the plain rule)
     noise = 3.0 * float(np.sqrt(max(bad_cpu, 1.0 / got.size) / got.size))
     obs["frac_noise_3sigma"] = noise
     assert bad_hip <= frac_slack * bad_cpu + noise + 1e-6 and err.max() <= 5e-4, obs
     assert err_hip64 <= worst_slack * err_cpu64 + 2e-6, obs
+    assert rms_hip <= RMS_SLACK * rms_cpu + 1e-9, obs
     return obs
 
 CASES = {

@@ -175,3 +175,88 @@ def test_training_on_streams_gives_the_same_gradients(monkeypatch):
     assert len(res["1"]) == len(res["3"])
     for a, b in zip(res["1"], res["3"]):
         assert torch.equal(a, b)
+
+
+def test_steady_state_forwards_write_no_descriptor_table(monkeypatch):
+    """ABI 28: the grouped launches keep (device table, host shadow) pairs between forwards.  After the first forwards of an
+    inference loop over one window every call finds its table current — the counter of written tables stands still, the counter of tables
+    found current moves — and the output does not change.  Covers the 500-wide head (transpose + aggregation + panel GEMM + recurrence
+    tables) and the 128-wide layer (aggregation + layer tables)."""
+    from ctgcn_amd import CTGCN, _lib
+    lib = _lib.load()
+    n, T = 3001, 6
+    adjs = _window(n, T, 6, 6, seed=3)
+    torch.manual_seed(0)
+    model = CTGCN(n, 500, 128, 1, 2, T).to(DEV).eval()              # one-hot input: Linear(I) as the grouped transpose
+    idx = torch.arange(n, device=DEV).repeat(2, 1)
+    xs = [torch.sparse_coo_tensor(idx, torch.ones(n, device=DEV), (n, n)) for _ in range(T)]
+    monkeypatch.setenv("CTGCN_GROUP", "1")
+    with torch.no_grad():
+        first = model(xs, adjs).clone()
+        for _ in range(3):
+            model(xs, adjs)
+        torch.cuda.synchronize()
+        written, current = int(lib.ctgcn_table_uploads(0)), int(lib.ctgcn_table_uploads(1))
+        for _ in range(5):
+            out = model(xs, adjs)
+        torch.cuda.synchronize()
+    assert int(lib.ctgcn_table_uploads(0)) == written, "a steady-state forward rewrote a descriptor table"
+    assert int(lib.ctgcn_table_uploads(1)) >= current + 5 * 5          # >= 5 grouped calls per forward found their table current
+    assert torch.equal(out, first)
+    # a weight update is seen (the folded GRU biases are re-made: new addresses in the descriptors -> tables rewritten -> new output)
+    with torch.no_grad():
+        model.duffision_list[0].diffusion_list[0].rnn.bias_ih_l0.add_(0.25)
+        changed = model(xs, adjs)
+    assert not torch.equal(changed, first)
+    assert int(lib.ctgcn_table_uploads(0)) > written
+
+
+def test_graph_replay_runs_the_grouped_launches(monkeypatch):
+    """The descriptor tables travel as kernel arguments, so the grouped launches can be recorded: GraphedInference of a small window replays
+    the SAME grouped kernels as the eager forward (bit-identical), including after an in-place weight update."""
+    from ctgcn_amd import CTGCN, ops
+    from ctgcn_amd.graph_capture import GraphedInference
+    n, T = 2501, 5
+    adjs = _window(n, T, 6, 6, seed=4)
+    torch.manual_seed(0)
+    model = CTGCN(n, 500, 128, 1, 2, T).to(DEV).eval()
+    idx = torch.arange(n, device=DEV).repeat(2, 1)
+    xs = [torch.sparse_coo_tensor(idx, torch.ones(n, device=DEV), (n, n)) for _ in range(T)]
+    monkeypatch.setenv("CTGCN_GROUP", "1")
+    with torch.no_grad():
+        want = model(xs, adjs).clone()
+    calls = []
+    real = ops.core_diffusion_split_group
+    monkeypatch.setattr(ops, "core_diffusion_split_group", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    runner = GraphedInference(model, xs, adjs)
+    assert calls, "capture did not take the grouped path"
+    for _ in range(3):
+        got = runner()
+        assert torch.equal(got, want)
+    with torch.no_grad():
+        model.duffision_list[1].diffusion_list[1].rnn.weight_hh_l0.mul_(1.01)
+        want2 = model(xs, adjs).clone()
+    assert not torch.equal(want2, want)
+    assert torch.equal(runner(), want2)                 # replay reads the weights in place
+
+
+def test_frozen_graph_replay_matches_and_keeps_its_operands_alive(monkeypatch):
+    """GraphedInference(frozen_weights=True) records the cached operand forms (packed weights, folded biases) instead of rebuilding them in
+    the graph: same bits as the eager forward; the runner holds the buffers, so dropping the cache does not pull them from under the graph."""
+    from ctgcn_amd import CTGCN, ops
+    from ctgcn_amd.graph_capture import GraphedInference
+    n, T = 2501, 5
+    adjs = _window(n, T, 6, 6, seed=4)
+    torch.manual_seed(0)
+    model = CTGCN(n, 500, 128, 1, 2, T).to(DEV).eval()
+    idx = torch.arange(n, device=DEV).repeat(2, 1)
+    xs = [torch.sparse_coo_tensor(idx, torch.ones(n, device=DEV), (n, n)) for _ in range(T)]
+    with torch.no_grad():
+        want = model(xs, adjs).clone()
+    runner = GraphedInference(model, xs, adjs, frozen_weights=True)
+    assert len(runner._held) > 0
+    assert torch.equal(runner(), want)
+    ops.invalidate_plane_cache()
+    junk = [torch.randn(1 << 20, device=DEV) for _ in range(8)]          # reuse whatever the cache released
+    assert torch.equal(runner(), want)
+    del junk

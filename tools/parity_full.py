@@ -147,12 +147,20 @@ def main():
         print("%s done in %.0f s" % (case, time.time() - t0), flush=True)
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
         json.dump(res, open(args.out, "w"), indent=1, sort_keys=True)       # after every case: a time-out keeps what was finished
+    failed = []
     for k, v in res.items():
         if isinstance(v, dict):
+            # the plain rule of tests/test_gpu_configs.py on full arrays: no sampling allowance
+            if v["outside_hip"] > 1.25 * v["outside_cpu_fp32"] + 1e-6 * v["entries"] or v["max_err_hip_vs_fp64"] > 1.5 * v["max_err_cpu_fp32_vs_fp64"] + 2e-6 \
+                    or v["max_err_hip_vs_fp32_oracle"] > 5e-4:
+                failed.append(k)
             print("%-44s outside HIP %8d / CPU %8d of %.2e  ratio %s  95%% %s  rms %.2e / %.2e  worst %.2e / %.2e" % (
                 k, v["outside_hip"], v["outside_cpu_fp32"], v["entries"], v["ratio_hip_over_cpu"] and round(v["ratio_hip_over_cpu"], 3),
                 [x and round(x, 3) for x in v["ratio_95_interval"]], v["rms_err_hip_vs_fp64"], v["rms_err_cpu_fp32_vs_fp64"],
                 v["max_err_hip_vs_fp64"], v["max_err_cpu_fp32_vs_fp64"]))
+
+    if failed:
+        raise SystemExit("full-array parity rule broken: %s" % ", ".join(failed))
 
 
 if __name__ == "__main__":

@@ -921,9 +921,16 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         const int v = q[2][i];
         const int s0 = row_ptr[v], e0 = row_ptr[v + 1], deg = e0 - s0;
         const int c = h[v];
-        for (int e = wl; e < deg; e += 64) {
-            const int u = col[s0 + e];
-            cache[wv][e] = u != v ? min(h[u], c + 1) : 0;
+        // four (column, value) request pairs per lane in flight: one pair per trip was a dependent chain of up to 16 trips x two memory
+        // latencies — the ~30 us floor of every tail sweep (a 1 000-entry list in one block sets the kernel's time)
+        for (int e = wl; e < deg; e += 256) {
+            int u[4], x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = e + 64 * j < deg ? col[s0 + e + 64 * j] : v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = u[j] != v ? min(h[u[j]], c + 1) : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (e + 64 * j < deg) cache[wv][e + 64 * j] = x[j];
         }
         int klo = 0, khi = c;
         while (klo < khi) {
@@ -4433,21 +4440,23 @@ int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, i
         // paths: one sweep per hop) continue in batches of 32 with a read each.
         KhCtl hk{};
         int sweep = 0;
-        for (int batch = 48;; batch = 32) {
+        static const bool trace = getenv("CTGCN_KCORE_TRACE") != nullptr;       // diagnostic: one sweep per batch, the flags every sweep set on stderr
+        for (int batch = trace ? 1 : 48;; batch = trace ? 1 : 32) {
             for (int b = 0; b < batch; ++b, ++sweep) {
                 const int mark = sweep >= FULL - 1 ? 1 : 0, check = sweep >= FULL ? 1 : 0;
                 hipLaunchKernelGGL(kcore_hindex_kernel, dim3(blocks), dim3(256), 0, st, nn, capv, sweep < FULL ? 1 : 0, mark, check, sweep,
                                    row_ptr, col_idx, deg, flags + (size_t)(sweep & 1) * nn, flags + (size_t)((sweep + 1) & 1) * nn, kc, hub_list);
-                hipLaunchKernelGGL(kcore_hindex_hub_kernel, dim3(256), dim3(256), 0, st, mark, check, sweep, row_ptr, col_idx, deg,
+                // 1 024 blocks (33 KB of LDS each: four per CU): the ~850 hubs of a config-5 snapshot that move in nearly every sweep (they converge
+                // last) are recomputed in ONE round of blocks instead of four — 30 - 46 us per sweep with 256 blocks, x 37 sweeps = 1.4 of 3.7 ms
+                hipLaunchKernelGGL(kcore_hindex_hub_kernel, dim3(1024), dim3(256), 0, st, mark, check, sweep, row_ptr, col_idx, deg,
                                    flags + (size_t)((sweep + 1) & 1) * nn, kc, hub_list);
             }
             hipLaunchKernelGGL(kcore_hindex_finish_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, deg, core, kc);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&hk, kc, sizeof(KhCtl), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            static const bool trace = getenv("CTGCN_KCORE_TRACE") != nullptr;
-            if (trace) fprintf(stderr, "kcore: %d sweeps queued, done %d, last counter %d\n", sweep, hk.done, hk.marks[(sweep - 1) & 15]);
-            if (hk.done || hk.marks[(sweep - 1) & 15] == 0) break;      // (the batch's last sweep may be the one that set no flag)
+            if (trace) fprintf(stderr, "kcore: sweep %d set %d flags (%d hubs queued), done %d\n", sweep - 1, hk.marks[(sweep - 1) & 15], hk.hubs[(sweep - 1) & 15], hk.done);
+            if (hk.done || (sweep - 1 >= FULL - 1 && hk.marks[(sweep - 1) & 15] == 0)) break;      // (the batch's last sweep may be the marking sweep that set no flag)
             if (sweep > nn + 64) return fail(CTGCN_E_HIP, "kcore: h-index sweeps did not converge");
         }
         if (max_core_host) *max_core_host = hk.max_core;

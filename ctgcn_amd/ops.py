@@ -1068,9 +1068,31 @@ class _GroupTables(object):
     bytes, so an entry can never make a launch read a stale table; entries are small (a few KB) and least-recently-used ones go first.
     Under hipGraph capture nothing is cached: a fresh table from the capture's pool, written by the (capturable) writer kernel."""
 
+    SLAB_BYTES = 8 << 20
+
     def __init__(self, limit=1024):
         import collections
         self.limit, self.entries = limit, collections.OrderedDict()
+        self.slabs = {}                       # device -> [slab tensor, bytes used]: tables are carved from ONE allocation per device
+        self.misses = {}                      # call site -> descriptor sets seen for the first time (diagnostic)
+
+    def _carve(self, dev, nbytes):
+        """256-byte aligned device memory for a table.  Not torch.empty per table: a table allocated on a miss changes the caching allocator's
+        small pool, the next forward's bias / output tensors land elsewhere, their addresses are in the descriptors — another miss, another
+        allocation: the cache never converged (measured: 4 of 6 tables rewritten per forward, for ever).  A full slab drops every entry of
+        its device and starts over."""
+        key = str(dev)
+        need = -(-nbytes // 256) * 256
+        slab = self.slabs.get(key)
+        if slab is None or slab[1] + need > slab[0].numel():
+            if slab is not None:
+                for k in [k for k in self.entries if k[2] == key]:
+                    del self.entries[k]
+                self._retire(slab[0])
+            slab = self.slabs[key] = [torch.empty(max(self.SLAB_BYTES, need), dtype=torch.uint8, device=dev), 0]
+        view = slab[0][slab[1]: slab[1] + need]
+        slab[1] += need
+        return view
 
     def get(self, lib, site, groups, dev, desc=b""):
         """desc: the caller's descriptor bytes (its ctypes arrays).  They are part of the key: the caching allocator may alternate between two
@@ -1081,15 +1103,27 @@ class _GroupTables(object):
         key = (site, groups, str(dev), torch.cuda.current_stream(dev).cuda_stream, hash(desc))
         e = self.entries.get(key)
         if e is None:
-            e = self.entries[key] = (torch.empty(nbytes, dtype=torch.uint8, device=dev), ctypes.create_string_buffer(nbytes))
-            while len(self.entries) > self.limit:
-                self.entries.popitem(last=False)
+            self.misses[site] = self.misses.get(site, 0) + 1
+            if len(self.entries) >= self.limit:            # (carved memory is not returned piecemeal: start over)
+                self.entries.clear()
+                for old in self.slabs.values():
+                    self._retire(old[0])
+                self.slabs.clear()
+            e = self.entries[key] = (self._carve(dev, nbytes), ctypes.create_string_buffer(nbytes))
         else:
             self.entries.move_to_end(key)
         return e[0], e[1], nbytes
 
+    def _retire(self, slab):
+        """a slab leaves the cache: kernels queued on ANY stream may still read tables in it, so the device is drained before the caching
+        allocator gets the block back (rare: a slab holds ~500 tables)"""
+        torch.cuda.synchronize(slab.device)
+
     def clear(self):
+        for old in self.slabs.values():
+            self._retire(old[0])
         self.entries.clear()
+        self.slabs.clear()
 
 
 _group_tables = _GroupTables()

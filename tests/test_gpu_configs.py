@@ -170,8 +170,11 @@ def test_baseline_config_shapes_match_cpu_oracle(case):
     assert ops.gru_fused_ok(model.rnn, torch.zeros(1, 1, 128, device=DEV))     # the HIP GRU kernels are the ones running
     with torch.no_grad():
         got = model([x.to(DEV) for x in xs], adj)
-    # float64 truth on a node sample: 4 096 random rows + the 16 highest-degree rows of the last (largest) snapshot
-    rows, _ = _sample_rows(graphs[-1], 4096, 16, 0, seed=5)
+    # float64 truth on a node sample: 4 096 random rows + the 16 highest-degree rows of the last (largest) snapshot; the two windows whose
+    # float64 pass is the most expensive (Enron-like 40 s, Facebook-like 24 s at that size) take 1 024 + 8 — the full arrays of every
+    # config are compared in float64 once per round by tools/parity_full.py (profiles/r06_parity_full.json), this is the suite's spot check
+    n_rand, n_hub = (1024, 8) if case in ("enron_c2", "facebook_s_c3") else (4096, 16)
+    rows, _ = _sample_rows(graphs[-1], n_rand, n_hub, 0, seed=5)
     want, want64, t32, t64 = _oracle_fp32_full_fp64_rows(sd, xs, ref_adj, mats, rows, "GRU", c["model"], c["act"])
     if c["model"] == "S":
         (got, got_tr), (want, want_tr) = got, want
@@ -432,10 +435,9 @@ def test_full_depth_window_matches_cpu_oracle_on_sampled_rows():
     """(c) a T = 16 window at 200 000 nodes (config 5's generator and depth: cumulative snapshots, max_core 8, CTGCN-C 128 / 128, two
     CoreDiffusion layers per snapshot) through the inference path — 16 grouped-or-single snapshot branches and the per-step temporal GRU
     kernel at depth 16 — against the CPU oracle on 2 048 random rows + the 8 highest-degree nodes, in float32 (the reference's arithmetic)
-    and float64, under the module's rule with the slack this depth needs: sixteen recurrent steps on top of two CoreDiffusion layers carry
-    the operands' 22 mantissa bits (fp16 x 2 split) against the fp32 path's 24 through more products than the 2-step windows above —
-    observed: 2.6e-5 of the entries outside rtol 1e-4 / atol 1e-5 against the fp32 CPU path's 1.5e-5 (ratio 1.7), worst error 1.6e-4
-    against 1.2e-4 (1.34).  Bounds: 2.0 x the fraction, 1.5 x the worst error."""
+    and float64, under the module's rule.  (Round 5 gave this test a slack of 2.0 x on the outlier fraction and blamed the fp16 x 2 operands
+    for an observed ratio of 1.7; that was 47 against 27 sampled entries.  On the full array — tools/parity_full.py, case window_T16_n200k,
+    profiles/r06_parity_full.json — the ratio is what the other configs show, and the module's 1.25 x (+ the sample's counting allowance) holds here too.)"""
     import ctgcn_amd
     from ctgcn_amd.helper import core_adj_from_scipy
     from ctgcn_amd.synth import window_graph
@@ -469,4 +471,4 @@ def test_full_depth_window_matches_cpu_oracle_on_sampled_rows():
         xs64 = [torch.sparse_coo_tensor(idx, torch.ones(n, dtype=torch.float64), (n, n)) for _ in range(T)]
         want64 = TP.ctgcn_rows({k: v.double() for k, v in sd.items()}, xs64, mats, rows).numpy()
     _compare("window_T16_n200k_sampled_rows", got, want, want64, dict(oracle_fp32_s=t32, oracle_fp64_s=time.time() - t0 - t32, rows=int(len(rows)),
-                                                                     K=[len(a) for a in adj]), frac_slack=2.0)
+                                                                     K=[len(a) for a in adj]))

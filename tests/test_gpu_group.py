@@ -182,7 +182,7 @@ def test_steady_state_forwards_write_no_descriptor_table(monkeypatch):
     inference loop over one window every call finds its table current — the counter of written tables stands still, the counter of tables
     found current moves — and the output does not change.  Covers the 500-wide head (transpose + aggregation + panel GEMM + recurrence
     tables) and the 128-wide layer (aggregation + layer tables)."""
-    from ctgcn_amd import CTGCN, _lib
+    from ctgcn_amd import CTGCN, _lib, ops
     lib = _lib.load()
     n, T = 3001, 6
     adjs = _window(n, T, 6, 6, seed=3)
@@ -193,8 +193,17 @@ def test_steady_state_forwards_write_no_descriptor_table(monkeypatch):
     monkeypatch.setenv("CTGCN_GROUP", "1")
     with torch.no_grad():
         first = model(xs, adjs).clone()
-        for _ in range(3):
+        # the caching allocator settles into a cycle of a few address sets (observed: four, reached in five forwards of a fresh process);
+        # every set gets its own table (ops._GroupTables keys on the descriptor bytes).  Warm up until three forwards in a row wrote nothing.
+        quiet, last = 0, int(lib.ctgcn_table_uploads(0))
+        for _ in range(60):
             model(xs, adjs)
+            now = int(lib.ctgcn_table_uploads(0))
+            quiet = quiet + 1 if now == last else 0
+            last = now
+            if quiet >= 3:
+                break
+        assert quiet >= 3, "the descriptor tables never settled: %s" % dict(ops._group_tables.misses)
         torch.cuda.synchronize()
         written, current = int(lib.ctgcn_table_uploads(0)), int(lib.ctgcn_table_uploads(1))
         for _ in range(5):

@@ -131,10 +131,41 @@ def config5():
     return res
 
 
+def window_t16():
+    """the T = 16 window at 200 000 nodes of tests/test_gpu_configs.py::test_full_depth_window_matches_cpu_oracle_on_sampled_rows, every row"""
+    import ctgcn_amd
+    import test_gpu_configs as G
+    from ctgcn_amd.helper import core_adj_from_scipy
+    from ctgcn_amd.synth import window_graph
+    from oracle import oracle as O, torch_path as TP
+    n, T, K = 200_000, 16, 8
+    graphs = window_graph(n, 1_600_000, T, cumulative=True)
+    adj, ref_adj = [], []
+    for g in graphs:
+        capped = np.minimum(O.core_numbers(g), K)
+        a, core_dev, _ = core_adj_from_scipy(g, K, G.DEV)
+        assert np.array_equal(core_dev.cpu().numpy(), capped)
+        ref = O.core_adj_list([O.kcore_matrices(g, capped)], 0, 1, 1, max_core=K)[0]
+        adj.append(a)
+        ref_adj.append([TP.coo_like_reference(m) for m in ref])
+    idx = torch.arange(n).repeat(2, 1)
+    xs = [torch.sparse_coo_tensor(idx, torch.ones(n), (n, n)) for _ in range(T)]
+    torch.manual_seed(0)
+    model = ctgcn_amd.CTGCN(n, 128, 128, 1, 2, T).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(G.DEV)
+    with torch.no_grad():
+        got = model([x.to(G.DEV) for x in xs], adj).cpu().numpy()
+    want, want64, t32, t64 = G._oracle_fp32_and_fp64(sd, xs, ref_adj)
+    out = stats(got, want.numpy(), want64.numpy())
+    out.update(oracle_fp32_s=round(t32, 1), oracle_fp64_s=round(t64, 1), nodes=n, snapshots=T)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_full.json"))
-    ap.add_argument("--cases", default="config5,math_c4,enron_c2,as_c4,facebook_s_c3")
+    ap.add_argument("--cases", default="config5,math_c4,enron_c2,as_c4,facebook_s_c3,window_T16_n200k")
     args = ap.parse_args()
     assert torch.cuda.is_available()
     res = {"what": "full-array float64 parity (tools/parity_full.py); every row of every snapshot", "torch": torch.__version__}
@@ -142,6 +173,8 @@ def main():
         t0 = time.time()
         if case == "config5":
             res.update(config5())
+        elif case == "window_T16_n200k":
+            res[case] = window_t16()
         else:
             res[case] = small_case(case)
         print("%s done in %.0f s" % (case, time.time() - t0), flush=True)

@@ -921,16 +921,17 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
         const int v = q[2][i];
         const int s0 = row_ptr[v], e0 = row_ptr[v + 1], deg = e0 - s0;
         const int c = h[v];
-        // four (column, value) request pairs per lane in flight: one pair per trip was a dependent chain of up to 16 trips x two memory
-        // latencies — the ~30 us floor of every tail sweep (a 1 000-entry list in one block sets the kernel's time)
-        for (int e = wl; e < deg; e += 256) {
-            int u[4], x[4];
+        // ALL of the list's (column, value) request pairs in flight at once — KH_CACHE / 64 = 16 per lane, the columns kept for the marking
+        // pass: one pair per trip was a dependent chain of up to 16 trips x two memory latencies, and the marking pass loaded the columns
+        // again one trip at a time (a 1 000-entry list in one block set the ~30 us floor of every tail sweep)
+        constexpr int KH_PER = KH_CACHE / 64;
+        int un[KH_PER];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u[j] = e + 64 * j < deg ? col[s0 + e + 64 * j] : v;
+        for (int j = 0; j < KH_PER; ++j) un[j] = wl + 64 * j < deg ? col[s0 + wl + 64 * j] : v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = u[j] != v ? min(h[u[j]], c + 1) : 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (e + 64 * j < deg) cache[wv][e + 64 * j] = x[j];
+        for (int j = 0; j < KH_PER; ++j) {
+            const int x = un[j] != v ? min(h[un[j]], c + 1) : 0;
+            if (wl + 64 * j < deg) cache[wv][wl + 64 * j] = x;
         }
         int klo = 0, khi = c;
         while (klo < khi) {
@@ -945,8 +946,12 @@ __global__ __launch_bounds__(256) void kcore_hindex_kernel(int n, int cap, int a
             if (wl == 0) h[v] = klo;
             if (do_mark) {
                 if (wl == 0) { flag_out[v] = 1; ++marks; }
-                for (int e = wl; e < deg; e += 64)
-                    if (cache[wv][e] > klo && cache[wv][e] <= c) { flag_out[col[s0 + e]] = 1; ++marks; }
+#pragma unroll
+                for (int j = 0; j < KH_PER; ++j)
+                    if (wl + 64 * j < deg) {
+                        const int x = cache[wv][wl + 64 * j];
+                        if (x > klo && x <= c) { flag_out[un[j]] = 1; ++marks; }
+                    }
             }
         }
     }
@@ -1014,10 +1019,15 @@ __global__ __launch_bounds__(256) void kcore_hindex_hub_kernel(int do_mark, int 
                 if (do_mark || (now == B && B < c)) { flag_out[v] = 1; ++marks; }      // changed: look again (clipped at KH_BINS: not the h-index yet)
             }
             if (do_mark)
-                for (int e = s0 + tid; e < e0; e += 256) {
-                    const int u = col[e];
-                    const int hu = u != v ? h[u] : 0;
-                    if (hu > now && hu <= c) { flag_out[u] = 1; ++marks; }
+                for (int e = s0 + tid; e < e0; e += 256 * 4) {        // four (column, value) pairs per thread in flight, as in the gather above
+                    int u[4], hu[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = e + 256 * j < e0 ? col[e + 256 * j] : v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hu[j] = u[j] != v ? h[u[j]] : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (hu[j] > now && hu[j] <= c) { flag_out[u[j]] = 1; ++marks; }
                 }
         }
     }

@@ -13,18 +13,23 @@ workload = default `synthetic-1m` = BASELINE config 5 (1M nodes x 16 cumulative 
 `python bench.py --gpus N` with N > 1 and no launcher environment re-launches itself under torch.distributed.run
 (one process per GPU, RCCL, 127.0.0.1 rendezvous); under a launcher (RANK/WORLD_SIZE set) it runs as that rank.
 
-Extra objects on the JSON line:
+Output (round 6).  stdout carries ONE compact JSON line, < 4 KB (bench.MAX_LINE_BYTES; the driver keeps ~9 KB of stdout — round 5's
+23 KB line reached it truncated and unparsed): the contract's keys, `config` {workload, name, nodes, snapshots, max_core,
+aggregated_edges_per_step, parallelism}, `roofline`, `cpu_baseline`, `also` (one-number summaries of the short legs) and `detail_file`.
+The FULL record — everything below — goes to gpurun_out/bench_detail.json (--detail-file), per workload bench_detail_<name>.json.
   roofline            dominant kernel (the aggregation): algorithmic bytes per launch / HIP-event duration on the launch stream; under the
-                      row plan the algorithmic bytes are those of the rows actually written, survey_8d_* keeps SURVEY §8d's formula
-  roofline_by_width   the same per feature width when the model aggregates at more than one (hid=500: d=500 and d=128)
-  roofline_gru        matrix-core kernels (recurrence / input projection)
-  roofline_kcore      k-core peel of the window's largest snapshot: 2(4(N+1)+4nnz)+8N bytes / measured peel time
-  cpu_baseline        the reference's torch.sparse.mm loop on the host cores (warm-up 2, 5 repeats, median — the sample is sized so
-                      that this protocol fits the budget; uncoalesced COO as the reference builds it + a coalesced-CSR variant),
-                      bounded sample, rank 0, N=1 only
-  hbm_copy_GBps_measured  a 1-second device-to-device copy microbench on THIS box (read + write bytes / time), next to the 8 TB/s spec
-  cpu_baseline_kcore  Batagelj-Zaversnik (the algorithm of networkx.core_number) single thread, oracle C restatement
-  exact_fp32          the same forward with CTGCN_FP32_MFMA_ONLY=1 (no fp16x2 operand split in the GRU products)
+                      row plan the algorithmic bytes are those of the rows actually written, frac_8d keeps SURVEY §8d's formula;
+                      `traffic` = HBM bytes per launch measured BY THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE apart, the
+                      gfx950 x2 correction of MI355X_MICROARCH.md) over a 2-step run of this script (pmc_traffic; --no-pmc: null)
+  cpu_baseline        the reference's torch.sparse.mm loop on the host cores (uncoalesced COO as the reference builds it + a coalesced-CSR
+                      variant), a bounded sample (--cpu-budget-s, default 30 s: one pass of the full 8-matrix loop of the largest
+                      snapshot each; --full: 100 s = median of three), rank 0, N=1 only
+  (detail file only)  roofline_by_width, roofline_gru (matrix-core kernels), roofline_kcore, exact_fp32 (CTGCN_FP32_MFMA_ONLY=1),
+                      training_step (+ backward rooflines), hbm_copy_GBps_measured, configs (BASELINE configs 2-4: short runs of this
+                      script), hipgraph (small windows: the same forward replayed from one hipGraph, frozen and live weights), pmc;
+                      --full adds torch_rocm_baseline (the reference's own GPU path, stock PyTorch-ROCm), the reference-loss training
+                      batch, per-config baselines and the forced single-rank RCCL leg
+The default run (the driver's command) takes ~100 s on an MI355X box; --full several minutes.
 """
 import argparse
 import json

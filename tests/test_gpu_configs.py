@@ -25,6 +25,7 @@ float64 (profiles/r06_parity_full.json): ratio 1.03 (config 5; 95 % interval 0.8
 and the build WITHOUT any 16-bit operand (CTGCN_FP32_MFMA_ONLY=1) sits at 1.06: the small excess is accumulation order and the
 1-ulp exp / rcp of the gate math, not the fp16 x 2 split.  The tool fails when a full array breaks 1.25 x / 1.5 x.  In the suite (a) stays a
 consistency check of the sample against that pin: the allowance below is three standard deviations of the sample's own outlier count.
+Depth matters: the 16-step window (test_full_depth_window...) sits at 1.35 on its full array (interval 1.21 - 1.53) and carries its own slack.
 
 Config 5 (1 M nodes) is held to the same rule at FULL size (test_config5_full_size_matches_cpu_oracle): snapshots 3 and 15 of the
 16-snapshot window, max_core 8, through the inference path (aggregation -> fp16 planes -> register-resident GRU layer kernel), the
@@ -173,8 +174,28 @@ def test_baseline_config_shapes_match_cpu_oracle(case):
     # float64 truth on a node sample: 4 096 random rows + the 16 highest-degree rows of the last (largest) snapshot; the two windows whose
     # float64 pass is the most expensive (Enron-like 40 s, Facebook-like 24 s at that size) take 1 024 + 8 — the full arrays of every
     # config are compared in float64 once per round by tools/parity_full.py (profiles/r06_parity_full.json), this is the suite's spot check
-    n_rand, n_hub = (1024, 8) if case in ("enron_c2", "facebook_s_c3") else (4096, 16)
+    sampled_only = case in ("enron_c2", "facebook_s_c3")
+    n_rand, n_hub = (1024, 8) if sampled_only else (4096, 16)
     rows, _ = _sample_rows(graphs[-1], n_rand, n_hub, 0, seed=5)
+    if sampled_only:
+        # these two also take the fp32 oracle on the sampled rows only (the full fp32 pass was ~35 s each of a suite that has to stay well
+        # inside its time limit): every row of the smaller windows and of the 1 M-node one is compared in the tests around this one, and every
+        # row of THESE in float64 by tools/parity_full.py once per round
+        t0 = time.time()
+        with torch.no_grad():
+            want = TP.ctgcn_rows(sd, xs, mats, rows, "GRU", c["model"], c["act"])
+            t32 = time.time() - t0
+            want64 = TP.ctgcn_rows({k: v.double() for k, v in sd.items()}, [x.double() for x in xs], mats, rows, "GRU", c["model"], c["act"])
+            t64 = time.time() - t0 - t32
+            if c["model"] == "S":
+                got, got_tr = got
+                for t, a in enumerate(got_tr):
+                    b = TP.mlp(sd, "mlp_list.%d." % t, xs[t], c["act"])
+                    assert float((a.cpu() - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6, "transform outputs (dense Linear + SELU)"
+        got = got.cpu().numpy()
+        assert got.shape == (c["T"], c["n"], 128) and np.isfinite(got).all()
+        _compare(case, got[:, rows], want.numpy(), want64.numpy(), dict(oracle_fp32_s=t32, oracle_fp64_s=t64, rows=int(len(rows)), fp32_oracle="sampled rows"))
+        return
     want, want64, t32, t64 = _oracle_fp32_full_fp64_rows(sd, xs, ref_adj, mats, rows, "GRU", c["model"], c["act"])
     if c["model"] == "S":
         (got, got_tr), (want, want_tr) = got, want
@@ -290,12 +311,12 @@ def _rel_max(a, b):
 def test_config5_training_layer_gradients_at_full_size(config5):
     """(a) ONE CoreDiffusion(128, 128) on snapshot 15 of the config-5 window — 1 M rows, K = 8, 17 M entries, row plan on, the backward in
     four row chunks at the shipped _GI_MAX_ELEMS — forward + backward through ops._CoreDiffusionFused against float64 autograd of the
-    reference's path (layers.py:38-63 via oracle/torch_path.py).  The loss reads 131 072 random rows + the 256 highest-degree rows + 4 096
+    reference's path (layers.py:38-63 via oracle/torch_path.py).  The loss reads 32 768 random rows + the 256 highest-degree rows + 2 048
     rows without entries (the reference's batch loss reads a node subset too, embedding.py:346-352); the float64 side evaluates exactly
     those rows (TP.core_diffusion on row-sliced matrices, pinned by tests/test_oracle_golden.py::test_row_subset_path_equals_the_full_path).
     Rows with a pre-ReLU value within 1e-5 (relative) of zero are kept out of the loss (their G is zero): there the derivative of ReLU is
     decided by the last bit of the sum — found with this very test: one such entry moved 47 neighbours' dX by 2.7e-2 with every dH
-    correct to 5e-6 (tools/diag_c5_layer2.py).  Compared IN FULL: all seven parameter gradients, and dX on all 1 M rows (rows the loss
+    correct to 5e-6 (round 5, a one-off diagnostic since removed).  Compared IN FULL: all seven parameter gradients, and dX on all 1 M rows (rows the loss
     does not reach must come out exactly zero, so garbage from any row of any chunk would show).  Tolerances: gradients 1e-4 of each
     tensor's largest entry (tests/test_gpu_train_fused.py); forward rows: this module's rule against the fp32 CPU path on the same rows
     (x is unit normal here: hub rows sum ~1 900 of them, |H| up to 1e3 — the fp32 CPU path itself is 1.1e-4 from float64 there)."""
@@ -304,7 +325,7 @@ def test_config5_training_layer_gradients_at_full_size(config5):
     from oracle import torch_path as TP
     n = C5["n"]
     adj, mats, graph = config5["adj"][1], config5["mats"][1], config5["graphs"][1]
-    rows, deg = _sample_rows(graph, 131072, 256, 4096, seed=11)
+    rows, deg = _sample_rows(graph, 32768, 256, 2048, seed=11)
     assert deg[rows].max() == deg.max() and (deg[rows] == 0).sum() >= 1000
     torch.manual_seed(5)
     layer = CoreDiffusion(128, 128)
@@ -363,16 +384,16 @@ def test_config5_training_layer_gradients_at_full_size(config5):
 
 def test_config5_training_window_gradients_at_full_size(config5):
     """(b) the 2-snapshot CTGCN-C of the fixture (1 M nodes, snapshots 3 and 15, two CoreDiffusion layers each) in training mode with
-    .backward() through the temporal GRU's backward kernels: loss = <out[:, rows], G>, rows = 8 192 random + the 16 highest-degree nodes
-    of snapshot 15.  float64 side: TP.ctgcn_rows(with_grad) — models.py:240-253 on those rows, layer 1 evaluated on the columns layer 2
-    touches (~170 000 rows on snapshot 15).  Sample rows whose value depends on a ReLU at a kink (their own layer-2 pre-activations, or
+    .backward() through the temporal GRU's backward kernels: loss = <out[:, rows], G>, rows = 2 048 random + the 16 highest-degree nodes
+    of snapshot 15 (round 5: 8 192; the float64 side was 80 s of the suite).  float64 side: TP.ctgcn_rows(with_grad) — models.py:240-253 on those
+    rows, layer 1 evaluated on the columns layer 2 touches.  Sample rows whose value depends on a ReLU at a kink (their own layer-2 pre-activations, or
     layer-1 pre-activations of a node they aggregate: within 1e-5 of zero) get G = 0 — see test (a).  Every parameter gradient is compared
     in full — the one-hot MLP's weight gradient [128, 1 M] is the first layer's dX, transposed."""
     from oracle import torch_path as TP
     import scipy.sparse as sp
     c = config5
     model, n = c["model"], C5["n"]
-    rows, _ = _sample_rows(c["graphs"][1], 8192, 16, 0, seed=12)
+    rows, _ = _sample_rows(c["graphs"][1], 2048, 16, 0, seed=12)
     torch.manual_seed(6)
     G = torch.randn(2, len(rows), 128)
     t0 = time.time()
@@ -434,10 +455,15 @@ def test_config5_training_window_gradients_at_full_size(config5):
 def test_full_depth_window_matches_cpu_oracle_on_sampled_rows():
     """(c) a T = 16 window at 200 000 nodes (config 5's generator and depth: cumulative snapshots, max_core 8, CTGCN-C 128 / 128, two
     CoreDiffusion layers per snapshot) through the inference path — 16 grouped-or-single snapshot branches and the per-step temporal GRU
-    kernel at depth 16 — against the CPU oracle on 2 048 random rows + the 8 highest-degree nodes, in float32 (the reference's arithmetic)
-    and float64, under the module's rule.  (Round 5 gave this test a slack of 2.0 x on the outlier fraction and blamed the fp16 x 2 operands
-    for an observed ratio of 1.7; that was 47 against 27 sampled entries.  On the full array — tools/parity_full.py, case window_T16_n200k,
-    profiles/r06_parity_full.json — the ratio is what the other configs show, and the module's 1.25 x (+ the sample's counting allowance) holds here too.)"""
+    kernel at depth 16 — against the CPU oracle on 1 024 random rows + the 8 highest-degree nodes, in float32 (the reference's arithmetic)
+    and float64, under the module's rule with the slack this depth needs, SET FROM THE FULL ARRAY: tools/parity_full.py, case
+    window_T16_n200k (profiles/r06_parity_full.json: all 200 000 rows x 16 steps in float64) counts 1 937 entries outside rtol 1e-4 /
+    atol 1e-5 for the HIP path against 1 433 for the fp32 CPU path of 4.1e8 — ratio 1.35, 95 % interval 1.21 - 1.53 (bootstrap over
+    nodes); worst error 1.58e-4 against 1.18e-4, RMS 4.9e-7 against 3.6e-7.  So at depth 16 the excess IS systematic (the 2-step windows above
+    sit at 1.03 - 1.14), and it is not the fp16 x 2 operand split (round 5's guess): the build without any 16-bit operand shows the same
+    excess on config 5.  It is the gate math — v_exp_f32 / v_rcp_f32 (1 ulp each) and tanh as 1 - 2 / (1 + e^2x), whose absolute error near
+    zero is an ulp of 1.0 where the CPU's tanhf keeps a relative ulp — carried through 8 + 8 + 16 recurrent steps.  Both paths stay
+    4e-6 of the entries away from the tolerance; the slack here is 1.6 x = the interval's upper end, plus the sample's counting allowance."""
     import ctgcn_amd
     from ctgcn_amd.helper import core_adj_from_scipy
     from ctgcn_amd.synth import window_graph
@@ -453,7 +479,7 @@ def test_full_depth_window_matches_cpu_oracle_on_sampled_rows():
         assert a.nnz_per_slot == [m.nnz for m in ref]
         adj.append(a)
         mats.append(ref)
-    rows, _ = _sample_rows(graphs[-1], 2048, 8, 0, seed=13)
+    rows, _ = _sample_rows(graphs[-1], 1024, 8, 0, seed=13)
     idx = torch.arange(n).repeat(2, 1)
     xs = [torch.sparse_coo_tensor(idx, torch.ones(n), (n, n)) for _ in range(T)]
     torch.manual_seed(0)
@@ -471,4 +497,4 @@ def test_full_depth_window_matches_cpu_oracle_on_sampled_rows():
         xs64 = [torch.sparse_coo_tensor(idx, torch.ones(n, dtype=torch.float64), (n, n)) for _ in range(T)]
         want64 = TP.ctgcn_rows({k: v.double() for k, v in sd.items()}, xs64, mats, rows).numpy()
     _compare("window_T16_n200k_sampled_rows", got, want, want64, dict(oracle_fp32_s=t32, oracle_fp64_s=time.time() - t0 - t32, rows=int(len(rows)),
-                                                                     K=[len(a) for a in adj]))
+                                                                     K=[len(a) for a in adj]), frac_slack=1.6)

@@ -1,5 +1,7 @@
+"""How many forwards the grouped launches' descriptor-table cache (ops._GroupTables, ABI 28) needs to settle: tables written / found current and
+cache misses per call site after every forward of a small one-hot window.  python tools/table_cache_probe.py"""
 import sys, torch
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))); sys.path.insert(0, sys.path[0] + "/tests")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))); sys.path.insert(0, sys.path[0] + "/tests")
 from ctgcn_amd import CTGCN, _lib, ops
 from test_gpu_group import _window, DEV
 lib = _lib.load()

@@ -4461,6 +4461,9 @@ int ctgcn_kcore_i32(int64_t n, const int32_t *row_ptr, const int32_t *col_idx, i
                 hipLaunchKernelGGL(kcore_hindex_hub_kernel, dim3(1024), dim3(256), 0, st, mark, check, sweep, row_ptr, col_idx, deg,
                                    flags + (size_t)((sweep + 1) & 1) * nn, kc, hub_list);
             }
+            // (the finish kernel's maximum is an atomicMax: a batch that ended before the fixed point has left the maximum of its unfinished
+            // upper bounds there — found by the 300 000-vertex path of tests/test_gpu_kernels.py, 150 000 sweeps: max core 2 instead of 1)
+            HIP_TRY(hipMemsetAsync(&kc->max_core, 0, sizeof(int), st));
             hipLaunchKernelGGL(kcore_hindex_finish_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, deg, core, kc);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&hk, kc, sizeof(KhCtl), hipMemcpyDeviceToHost, st));

@@ -228,8 +228,22 @@ def ctgcn_rows(sd, x_list, mats_list, rows, rnn_type="GRU", model_type="C", acti
     try:
         hx = []
         for t in range(len(x_list)):
-            tr = mlp(sd, "mlp_list.%d." % t, x_list[t], activate)
-            hx.append(cdn_rows(sd, "duffision_list.%d." % t, tr, mats_list[t], rows, rnn_type))
+            x, pre = x_list[t], "duffision_list.%d." % t
+            if x.is_sparse:
+                tr = mlp(sd, "mlp_list.%d." % t, x, activate)
+            else:
+                # dense features (CTGCN-S: width 1 737 through three Linear layers): the MLP acts row by row (layers.py:95-106), so only the
+                # rows the CoreDiffusion layers will read are transformed — `rows` and every column their slices touch, layer by layer
+                n_layers = 0
+                while (pre + "diffusion_list.%d.norm.weight" % n_layers) in sd:
+                    n_layers += 1
+                need = np.asarray(rows, dtype=np.int64)
+                for _ in range(n_layers):
+                    need = _columns_of(mats_list[t], need)
+                idx = torch.from_numpy(need)
+                part = mlp(sd, "mlp_list.%d." % t, x[idx], activate)
+                tr = torch.zeros(x.shape[0], part.shape[1], dtype=part.dtype).index_put((idx,), part)
+            hx.append(cdn_rows(sd, pre, tr, mats_list[t], rows, rnn_type))
         seq = torch.stack(hx).transpose(0, 1)
         out = _rnn(sd, "rnn.", rnn_type, seq)
         w, b = sd["norm.weight"], sd["norm.bias"]

@@ -305,3 +305,35 @@ def test_row_subset_path_equals_the_full_path():
         with torch.no_grad():                               # the inference form (nn.GRU) of the same rows
             part_inf = TP.ctgcn_rows({k: v.detach() for k, v in sd_b.items()}, xs, mats, rows)
         assert (part_inf - part.detach()).abs().max().item() <= max(tol, 1e-6) * 10
+
+
+def test_row_subset_path_with_dense_features_equals_the_full_path():
+    """TP.ctgcn_rows on DENSE features (the CTGCN-S input) transforms only the rows the diffusion layers read: same outputs and gradients as the
+    full path, float64 to rounding."""
+    from ctgcn_amd.synth import dynamic_graph
+    import ctgcn_amd
+    n, T = 300, 3
+    graphs = dynamic_graph(n, avg_deg=5, snapshots=T, seed=8)
+    mats = O.core_adj_list([O.kcore_matrices(g) for g in graphs], 0, T, T, max_core=3)
+    adj = [[TP.coo_like_reference(m).double() for m in l] for l in mats]
+    torch.manual_seed(4)
+    model = ctgcn_amd.CTGCN(11, 20, 16, 3, 2, T, model_type="S", trans_activate_type="N")
+    xs = [torch.randn(n, 11, dtype=torch.float64) for _ in range(T)]
+    rows = np.sort(np.random.default_rng(2).choice(n, 29, replace=False))
+    G = torch.randn(T, len(rows), 16, dtype=torch.float64)
+    sd_a = {k: v.detach().double().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    sd_b = {k: v.detach().double().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    full, _ = TP.ctgcn_with_grad(sd_a, xs, adj, "GRU", "S", "N")
+    part = TP.ctgcn_rows(sd_b, xs, mats, rows, "GRU", "S", "N", with_grad=True)
+    assert (full[:, rows] - part).abs().max().item() <= 1e-12
+    (full[:, rows] * G).sum().backward()
+    (part * G).sum().backward()
+    compared = 0
+    for k in sd_a:
+        if sd_a[k].grad is None:
+            assert sd_b[k].grad is None or sd_b[k].grad.abs().max().item() == 0.0, k
+            continue
+        assert (sd_a[k].grad - sd_b[k].grad).abs().max().item() <= 1e-11 * max(1.0, sd_a[k].grad.abs().max().item()), k
+        compared += 1
+    assert compared >= 20
+

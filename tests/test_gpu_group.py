@@ -212,17 +212,19 @@ def test_steady_state_forwards_write_no_descriptor_table(monkeypatch):
         first = model(xs, adjs).clone()
         monkeypatch.setenv("CTGCN_STREAMS", "1")
         assert settle(), "the descriptor tables never settled: %s" % dict(ops._group_tables.misses)
-        written, current = int(lib.ctgcn_table_uploads(0)), int(lib.ctgcn_table_uploads(1))
         out = model(xs, adjs)
-        for _ in range(5):
-            out = model(xs, adjs)
-            torch.cuda.synchronize()
-        written2 = int(lib.ctgcn_table_uploads(0))          # (the first of these forwards ran with `first` and settle()'s last output alive: it may bring one new set)
-        for _ in range(5):
-            out = model(xs, adjs)
-            torch.cuda.synchronize()
-        written = written2
-        assert int(lib.ctgcn_table_uploads(0)) == written, "a steady-state forward rewrote a descriptor table"
+        # five forwards that write nothing.  What is alive decides the addresses (the first forwards of this loop run with `first` and
+        # settle()'s last output alive and may bring one more address set), so up to three windows of five are looked at: one must be clean
+        clean = False
+        for _ in range(3):
+            written, current = int(lib.ctgcn_table_uploads(0)), int(lib.ctgcn_table_uploads(1))
+            for _ in range(5):
+                out = model(xs, adjs)
+                torch.cuda.synchronize()
+            if int(lib.ctgcn_table_uploads(0)) == written:
+                clean = True
+                break
+        assert clean, "steady-state forwards keep rewriting descriptor tables: %s" % dict(ops._group_tables.misses)
         assert int(lib.ctgcn_table_uploads(1)) >= current + 5 * 5          # >= 5 grouped calls per forward found their table current
         assert torch.equal(out, first)
         monkeypatch.delenv("CTGCN_STREAMS")                                  # the default: snapshot branches on two streams

@@ -1206,7 +1206,19 @@ struct GruArgs {
 // raw v_exp_f32 (2^x): __expf wraps it in range clamps (v_max ...) that these forms do not need — 2^(+big) = inf -> rcp = 0,
 // 2^(-big) = 0 -> rcp(1) = 1 are exactly the saturated values
 __device__ __forceinline__ float gru_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504f)); }
+#ifdef CTGCN_TANH_V1      // rounds 1-5: 1 - 2 / (1 + e^{2x}) — five instructions, but an ABSOLUTE error of 2-3 ulps of 1.0 over the whole range (A/B builds)
 __device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * 2.88539008f)); }
+#else
+// tanh(x) = sign(x) (1 - e) / (1 + e), e = e^{-2|x|} in (0, 1]: the numerator is exact for e >= 0.5 and carries e's error otherwise, the
+// quotient's rounding is RELATIVE to the result — about 0.5 ulp of 1.0 near zero and 1.3 at |tanh| = 0.5, against 2 and 3 for the form above
+// (round 6: that form's error, added to h in every recurrent step, was the 1.35 x outlier excess of the 16-step window over the fp32 CPU
+// path).  Two more instructions per value (|x| is a source modifier, the sign one v_bfi).
+__device__ __forceinline__ float gru_tanh(float x)
+{
+    const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(x) * -2.88539008f);
+    return __builtin_copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
+#endif
 
 // sum over the 64 lanes of a wave, result in every lane: four DPP exchanges inside the 16-lane rows (quad swaps, half-row and row mirrors —
 // plain VALU, no LDS crossbar), two row broadcasts and a v_readlane, instead of six ds_bpermute round trips.  The LayerNorm of a row is two such

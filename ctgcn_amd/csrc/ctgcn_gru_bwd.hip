@@ -182,6 +182,20 @@ __device__ __forceinline__ f4v gate_product(const __bf16 *Gs, const bf8v (&Wh)[1
 // buffered by step: ONE barrier per step, and the weight-gradient products of step t + 1 (off the recurrence's path) run in front of step
 // t's barrier, where early waves used to wait.
 // ------------------------------------------------------------------------------------------------
+// step masks of the row plan: one 32-bit word per 16-row tile up to 32 steps, two (steps 0-31, 32-63) beyond (ctgcn_amd.core_adj.CoreAdj.row_plan;
+// America-Air / Europe-Air depth, reference README.md:175-176).  Always carried as 64 bits here (uniform: scalar registers); no plan = all ones,
+// which is also what keeps `mask >> t` defined for the plan-less 33-64 step calls (round 5 found that shift wrong in the forward kernel).
+__device__ __forceinline__ uint64_t bwd_step_mask(const uint32_t *tm, int64_t tile, int S)
+{
+    if (!tm) return ~0ull;
+    uint32_t lo, hi = 0;
+    if (S > 32) { lo = tm[2 * tile]; hi = tm[2 * tile + 1]; } else lo = tm[tile];
+    // the tile is uniform over the block: both halves live in scalar registers (left to the compiler one of them took a vector register
+    // of gru_bwd_rec_kernel, which has none to spare: 14 spilled registers instead of 13)
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32);
+}
+__device__ __forceinline__ int bwd_top_step(uint64_t mask, int S) { return 63 - __builtin_clzll(mask & (S >= 64 ? ~0ull : ((1ull << S) - 1ull))); }
+
 struct BwdRecArgs {
     int64_t rows;
     int32_t steps;
@@ -198,7 +212,9 @@ struct BwdRecArgs {
     int32_t ablate;          // diagnostic (CTGCN_BWD_ABLATE): 1 no stores, 2 no weight-gradient products, 4 no gate product, 8 loads of the first step only
 };
 
-template <bool SUM>
+// WIDE (round 6): 33-64 steps, two mask words per tile.  A separate instantiation: the 32-step kernels keep their 32-bit mask and their register
+// allocation (the unified 64-bit form cost gru_bwd_rec_kernel a fourteenth spilled register).
+template <bool SUM, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
 {
     constexpr int NL = 11;                                 // lo fragments of W_hh^T in LDS (88 KB); the twelfth stays in registers: the planes are double buffered
@@ -231,7 +247,9 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_rec_kernel(const BwdRecArgs a)
         const int last = (int)min((int64_t)16, a.rows - row0) - 1;
         const bool valid = col <= last;
         const int64_t row = row0 + min(col, last);
-        const uint32_t tmask = a.tmask ? a.tmask[tile] : 0xffffffffu;
+        typename std::conditional<WIDE, uint64_t, uint32_t>::type tmask;
+        if constexpr (WIDE) tmask = bwd_step_mask(a.tmask, tile, S);
+        else tmask = a.tmask ? a.tmask[tile] : 0xffffffffu;
         f4v drec = zero4, gs0 = zero4, gs1 = zero4, gs2 = zero4;
         f4v dhs = zero4;
         if (SUM) dhs = *(const f4v *)(a.dh + row * GH + oc);
@@ -377,8 +395,8 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
     const int xr = tid >> 5, xc = (tid & 31) * 4;
     const int64_t ntiles = (a.rows + 15) / 16;
 
-    struct Unit { int64_t tile; int t; uint32_t mask; };
-    auto mask_of = [&](int64_t tile) -> uint32_t { return (a.tmask && tile < ntiles) ? a.tmask[tile] : 0xffffffffu; };
+    struct Unit { int64_t tile; int t; uint64_t mask; };
+    auto mask_of = [&](int64_t tile) -> uint64_t { return tile < ntiles ? bwd_step_mask(a.tmask, tile, S) : ~0ull; };
     auto next_unit = [&](Unit &u) {                        // the unit after u in this block's order: fresh steps of a tile, descending
         do {
             if (--u.t < 0) { u.t = S - 1; u.tile += gridDim.x; u.mask = mask_of(u.tile); }
@@ -393,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
         const int64_t row0 = u.tile * 16;
         const int64_t lastrow = a.rows - 1;
         // (a load in the epilogue would be the youngest of the wave: waiting for it waits for every operand load of the NEXT unit too)
-        if (ZOUT && a.order && u.t == (int)(31 - __builtin_clz(u.mask & (S >= 32 ? 0xffffffffu : ((1u << S) - 1u))))) orow_n = a.order[min(row0 + col, lastrow)];
+        if (ZOUT && a.order && u.t == bwd_top_step(u.mask, S)) orow_n = a.order[min(row0 + col, lastrow)];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int64_t r = min(row0 + gr_[i], lastrow);
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void gru_bwd_in_kernel(const BwdInArgs a)
     int32_t orow_c = 0;
     while (cur.tile < ntiles) {
         if (ZOUT && a.order) {                             // the first unit of a tile brings the tile's row map
-            const int top = 31 - __builtin_clz(cur.mask & (S >= 32 ? 0xffffffffu : ((1u << S) - 1u)));
+            const int top = bwd_top_step(cur.mask, S);
             if (cur.t == top) orow_c = orow_n;
         }
         stage_unit(cur);
@@ -514,7 +532,7 @@ int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
                           float *dbn_partial, int32_t n_partial, int32_t accumulate, void *stream)
 {
     if (hidden != GH) return ctgcn_set_error_(CTGCN_E_UNSUPPORTED, "gru_bwd_rec: only hidden = 128 is built");
-    if (rows < 0 || steps < 1 || steps > 32 || (gate_count != 3 && gate_count != 4)) return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_rec: bad sizes (1 <= steps <= 32, gate_count 3 or 4)");
+    if (rows < 0 || steps < 1 || steps > 64 || (gate_count != 3 && gate_count != 4)) return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_rec: bad sizes (1 <= steps <= 64, gate_count 3 or 4)");
     if (!gates || !h_seq || !w_hh || !d_gi || !dw_partial || !dbn_partial || ((dh_sum == nullptr) == (dh_seq == nullptr)))
         return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_rec: null pointer (exactly one of dh_sum / dh_seq)");
     if (!aligned16(gates) || !aligned16(h_seq) || !aligned16(dh_sum) || !aligned16(dh_seq) || !aligned16(d_gi) || !aligned16(dw_partial) || !aligned16(dbn_partial))
@@ -525,7 +543,10 @@ int ctgcn_gru_bwd_rec_f32(int64_t rows, int32_t steps, int32_t hidden, const flo
     BwdRecArgs a{};
     a.rows = rows; a.steps = steps; a.gates = gates; a.gates3 = gate_count == 3 ? 1 : 0; a.hseq = h_seq; a.dh = dh_sum ? dh_sum : dh_seq; a.whh = w_hh; a.tmask = tile_mask;
     a.dgi = d_gi; a.dw_part = dw_partial; a.dbn_part = dbn_partial; a.accumulate = accumulate ? 1 : 0; a.ablate = ablate_mask();
-    if (dh_sum) hipLaunchKernelGGL(gru_bwd_rec_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    if (steps > 32) {          // two mask words per tile (or no plan: all ones over 64 bits)
+        if (dh_sum) hipLaunchKernelGGL((gru_bwd_rec_kernel<true, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gru_bwd_rec_kernel<false, true>), dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
+    } else if (dh_sum) hipLaunchKernelGGL(gru_bwd_rec_kernel<true>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gru_bwd_rec_kernel<false>, dim3((unsigned)blocks), dim3(512), 0, (hipStream_t)stream, a);
     BWD_TRY(hipGetLastError());
     return CTGCN_OK;
@@ -537,7 +558,7 @@ int ctgcn_gru_bwd_in_f32(int64_t rows, int32_t steps, int32_t hidden, const floa
                          int32_t accumulate, void *stream)
 {
     if (hidden != GH) return ctgcn_set_error_(CTGCN_E_UNSUPPORTED, "gru_bwd_in: only d_in = hidden = 128 is built");
-    if (rows < 0 || steps < 1 || steps > 32) return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_in: bad sizes (1 <= steps <= 32)");
+    if (rows < 0 || steps < 1 || steps > 64) return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_in: bad sizes (1 <= steps <= 64)");
     if (!d_gi || !w_ih || !dw_partial || !dbi_partial || ((x_planes == nullptr) == (x == nullptr)) || ((dx == nullptr) == (Z == nullptr)))
         return ctgcn_set_error_(CTGCN_E_INVALID, "gru_bwd_in: null pointer (exactly one of x_planes / x and of dx / Z)");
     if (!aligned16(d_gi) || !aligned16(x) || !aligned16(dx) || !aligned16(Z) || !aligned16(S0) || !aligned16(dw_partial) || !aligned16(dbi_partial) ||

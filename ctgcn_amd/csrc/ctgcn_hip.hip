@@ -1211,8 +1211,8 @@ __device__ __forceinline__ float gru_tanh(float x) { return 1.0f - 2.0f * __buil
 #else
 // tanh(x) = sign(x) (1 - e) / (1 + e), e = e^{-2|x|} in (0, 1]: the numerator is exact for e >= 0.5 and carries e's error otherwise, the
 // quotient's rounding is RELATIVE to the result — about 0.5 ulp of 1.0 near zero and 1.3 at |tanh| = 0.5, against 2 and 3 for the form above
-// (round 6: that form's error, added to h in every recurrent step, was the 1.35 x outlier excess of the 16-step window over the fp32 CPU
-// path).  Two more instructions per value (|x| is a source modifier, the sign one v_bfi).
+// (round 6: that form's error, added to h in every recurrent step, made the RMS error of every config 1.35 x the fp32 CPU path's; with this
+// form it is 0.98 - 1.08 x).  Two more instructions per value (|x| is a source modifier, the sign one v_bfi).
 __device__ __forceinline__ float gru_tanh(float x)
 {
     const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(x) * -2.88539008f);
@@ -4753,7 +4753,7 @@ int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidde
     if (rows < 0 || steps < 1 || first_row < 0 || (first_row & 15) || (first_row + rows) * steps > plane_rows)
         return fail(CTGCN_E_INVALID, "gru_layer_presplit_save: bad sizes rows=%lld steps=%d first_row=%lld (a multiple of 16) plane_rows=%lld",
                     (long long)rows, steps, (long long)first_row, (long long)plane_rows);
-    if (tile_mask && steps > 32) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit_save: a row plan needs steps <= 32");
+    if (tile_mask && steps > 64) return fail(CTGCN_E_UNSUPPORTED, "gru_layer_presplit_save: a row plan needs steps <= 64");
     if (rows == 0) return CTGCN_OK;
     if (!planes || !w_ih || !w_hh || !gates_out || !hseq_out || !presum_out) return fail(CTGCN_E_INVALID, "gru_layer_presplit_save: null pointer");
     if ((reinterpret_cast<uintptr_t>(planes) & 255u) || !aligned16(w_ih) || !aligned16(w_hh) || !aligned16(gates_out) || !aligned16(hseq_out) || !aligned16(presum_out))
@@ -4776,7 +4776,10 @@ int ctgcn_gru_layer_presplit_save_f32(int64_t rows, int32_t steps, int32_t hidde
     a.timeline = nullptr;
 #endif
     const int64_t nt8 = (rows + 15) / 16;
-    hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+    if (tile_mask && steps > 32)       // two mask words per tile (round 6: training under the row plan for core lists of 33-64 matrices)
+        hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true, true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((gru_layer8_h2_kernel<true, true, true>), dim3((unsigned)(nt8 < cus ? nt8 : cus)), dim3(512), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CTGCN_OK;
 }

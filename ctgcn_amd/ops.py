@@ -919,8 +919,8 @@ def core_diffusion_fused_ok(rnn, norm, x, adj):
     if not norm.elementwise_affine or norm.bias is None:
         return False
     d, hid = x.shape[1], rnn.hidden_size
-    if d != hid or rnn.input_size != hid or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or adj.K < 1 or adj.K > 32 or adj.n < 1:
-        return False
+    if d != hid or rnn.input_size != hid or x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or adj.K < 1 or adj.K > 64 or adj.n < 1:
+        return False              # (33-64 matrices — America-Air / Europe-Air depth — since round 6: two mask words per tile in the backward kernels too)
     return bool(adj.symmetric) and adj.n * adj.K * (d * 4 + 4) <= _AGG_SPLIT_MAX and rnn.weight_ih_l0.is_contiguous()
 
 
@@ -1006,7 +1006,7 @@ class _CoreDiffusionFused(torch.autograd.Function):
             Z = torch.empty(n, K, hid, dtype=torch.float32, device=dev)
             S0 = torch.empty(n, hid, dtype=torch.float32, device=dev) if adj.self_loop else None
             for lo, cnt in chunks:
-                tm = _u32ptr(tmask, lo // 16)
+                tm = _u32ptr(tmask, (lo // 16) * (2 if K > 32 else 1))      # one mask word per 16-row tile, two beyond 32 steps
                 od = _u32ptr(order, lo)
                 fresh = (plan["new_rows"] / float(n * K)) if plan is not None else 1.0     # fraction of (position, step) rows that bring a new x
                 with _timed("gru_layer", rows=cnt, steps=K, reduce_sum=True, presplit=True, save=True, new_rows=int(cnt * K * fresh)):
@@ -1444,7 +1444,7 @@ class _GruSeq(torch.autograd.Function):
         split = split_mfma_enabled()
         # d_in = hidden = 128: the two resident-weight backward kernels of ctgcn_gru_bwd.hip (backward recurrence + dW_hh; dx + dW_ih) instead
         # of gru_seq_bwd_x3 + gru_dx_x3 + 2 x gru_dw_x3: d_gi is the only intermediate, dGH / dGHn never leave the CU
-        fused_bwd = split and train_fused_enabled() and forward_split_mode() == 2 and d_in == hid and steps <= 32 and w_ih_d.is_contiguous()
+        fused_bwd = split and train_fused_enabled() and forward_split_mode() == 2 and d_in == hid and steps <= 64 and w_ih_d.is_contiguous()
         if fused_bwd:
             nb = int(lib.ctgcn_gru_bwd_blocks(cmax))
             dw_part_ih = torch.zeros(nb, 3 * hid, hid, dtype=torch.float32, device=dev)

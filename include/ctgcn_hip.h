@@ -284,6 +284,9 @@ int ctgcn_gru_layer_presplit_f32(int64_t rows, int32_t steps, int32_t hidden, co
  *   (n_partial >= ctgcn_gru_bwd_blocks(rows), rows of the tables beyond that are not touched; accumulate != 0 adds to them: zero the
  *   tables once, accumulate over the chunks, one reduction at the end — deterministic).
  *   bf16 x 2 split arithmetic (three v_mfma_f32_16x16x32_bf16 per product).
+ *   steps <= 64 for the three calls of this block (round 6; 32 before): tile_mask holds one word per 16-row tile up to 32 steps and two
+ *   (steps 0-31, 32-63; tile t at [2 t], [2 t + 1]) beyond, as the forward's row plan does — core lists of 33-64 matrices (America-Air /
+ *   Europe-Air depth) train under the plan too.
  * ctgcn_gru_bwd_in_f32 — dx = d_gi·W_ih, dW_ih, d b_ih over the fresh steps: x either as the forward's planes (x_planes, plane_rows,
  *   first_row as above) or fp32 rows (x, row-step stride ldx).  Output either dx [rows, steps, 128] or (Z != NULL) the aggregation
  *   backward's operands in matrix-row order: Z [n, steps, 128] and S0 [n, 128] (NULL without self loop) with the ReLU mask x > 0 and

@@ -22,10 +22,9 @@ round 5's samples showed HIP / CPU ratios of 1.05 .. 1.71 and needed a counting-
 questioned ("systematic, not noise?").  tools/parity_full.py settles it outside the suite, once per round, on EVERY row of every config in
 float64 (profiles/r06_parity_full.json): ratio 1.03 (config 5; 95 % interval 0.88 - 1.22 from a bootstrap over nodes), 1.09 (math-like),
 1.10 (Enron-like), 1.14 (Facebook-like, 1.08 - 1.20), 0 / 0 (AS-like) — the plain 1.25 x rule holds on the full arrays with no allowance,
-and the build WITHOUT any 16-bit operand (CTGCN_FP32_MFMA_ONLY=1) sits at 1.06: the small excess is accumulation order and the
-1-ulp exp / rcp of the gate math, not the fp16 x 2 split.  The tool fails when a full array breaks 1.25 x / 1.5 x.  In the suite (a) stays a
+and the build WITHOUT any 16-bit operand (CTGCN_FP32_MFMA_ONLY=1) sits at 1.07: the small excess is not the fp16 x 2 split.  The tool fails when a full array breaks 1.25 x / 1.5 x.  In the suite (a) stays a
 consistency check of the sample against that pin: the allowance below is three standard deviations of the sample's own outlier count.
-Depth matters: the 16-step window (test_full_depth_window...) sits at 1.35 on its full array (interval 1.21 - 1.53) and carries its own slack.
+Depth matters: the 16-step window (test_full_depth_window...) sits at 1.33 on its full array (interval 1.18 - 1.50) and carries its own slack.
 
 Config 5 (1 M nodes) is held to the same rule at FULL size (test_config5_full_size_matches_cpu_oracle): snapshots 3 and 15 of the
 16-snapshot window, max_core 8, through the inference path (aggregation -> fp16 planes -> register-resident GRU layer kernel), the
@@ -42,7 +41,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 FRAC_SLACK = 1.25       # observed <= 1.16 (profiles/r03_parity_errors.json)
 WORST_SLACK = 1.5       # observed <= 1.40: the single worst of up to 2e8 entries is an extreme-value statistic; round 2 allowed 2.0
-RMS_SLACK = 1.6         # observed on the full arrays (profiles/r06_parity_full.json): 1.07 (Facebook-like) .. 1.48 (Enron-like); both sides ~4e-7
+RMS_SLACK = 1.25        # observed on the full arrays (profiles/r06_parity_full.json): 0.98 (AS-like) .. 1.08 (T = 16); 1.07 - 1.48 before tanh became (1 - e)/(1 + e)
 
 
 def _record(case, **numbers):
@@ -457,13 +456,13 @@ def test_full_depth_window_matches_cpu_oracle_on_sampled_rows():
     CoreDiffusion layers per snapshot) through the inference path — 16 grouped-or-single snapshot branches and the per-step temporal GRU
     kernel at depth 16 — against the CPU oracle on 1 024 random rows + the 8 highest-degree nodes, in float32 (the reference's arithmetic)
     and float64, under the module's rule with the slack this depth needs, SET FROM THE FULL ARRAY: tools/parity_full.py, case
-    window_T16_n200k (profiles/r06_parity_full.json: all 200 000 rows x 16 steps in float64) counts 1 937 entries outside rtol 1e-4 /
-    atol 1e-5 for the HIP path against 1 433 for the fp32 CPU path of 4.1e8 — ratio 1.35, 95 % interval 1.21 - 1.53 (bootstrap over
-    nodes); worst error 1.58e-4 against 1.18e-4, RMS 4.9e-7 against 3.6e-7.  So at depth 16 the excess IS systematic (the 2-step windows above
-    sit at 1.03 - 1.14), and it is not the fp16 x 2 operand split (round 5's guess): the build without any 16-bit operand shows the same
-    excess on config 5.  It is the gate math — v_exp_f32 / v_rcp_f32 (1 ulp each) and tanh as 1 - 2 / (1 + e^2x), whose absolute error near
-    zero is an ulp of 1.0 where the CPU's tanhf keeps a relative ulp — carried through 8 + 8 + 16 recurrent steps.  Both paths stay
-    4e-6 of the entries away from the tolerance; the slack here is 1.6 x = the interval's upper end, plus the sample's counting allowance."""
+    window_T16_n200k (profiles/r06_parity_full.json: all 200 000 rows x 16 steps in float64) counts 1 909 entries outside rtol 1e-4 /
+    atol 1e-5 for the HIP path against 1 433 for the fp32 CPU path of 4.1e8 — ratio 1.33, 95 % interval 1.18 - 1.50 (bootstrap over
+    nodes); worst error 1.63e-4 against 1.18e-4; RMS 3.9e-7 against 3.6e-7.  So at depth 16 the tail excess IS systematic (the 2-step windows
+    sit at 1.03 - 1.14), and it is not the fp16 x 2 operand split (round 5's guess: the build without any 16-bit operand shows the same) nor the
+    gate math's typical error (the RMS errors are equal since tanh became (1 - e)/(1 + e); the tail counts did not move with it): its
+    source is not identified.  Both paths stay 4e-6 of the entries away from the tolerance; the slack here is 1.6 x = the interval's upper end,
+    plus the sample's counting allowance."""
     import ctgcn_amd
     from ctgcn_amd.helper import core_adj_from_scipy
     from ctgcn_amd.synth import window_graph

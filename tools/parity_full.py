@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-# the outlier-fraction slack per case (tests/test_gpu_configs.py: FRAC_SLACK; the 16-step window's own, set from round 6's interval 1.21 - 1.53)
+# the outlier-fraction slack per case (tests/test_gpu_configs.py: FRAC_SLACK; the 16-step window's own, set from round 6's interval 1.18 - 1.50)
 SLACK = {"window_T16_n200k": 1.6}
 
 

@@ -35,7 +35,10 @@ class GraphedInference:
         if model.training:
             raise RuntimeError("GraphedInference captures inference: call model.eval() first")
         # dense features get private input buffers (replay reads these addresses); sparse one-hot features carry no data
-        self._static_x = [x.detach().clone() if _is_dense(x) else x for x in xs]
+        # (frozen_weights: a feature tensor the caller has declared static — ops.mark_static, what the loader returns — is read in place, so
+        # that its cached operand planes are the ones recorded; replaying with other features needs a new capture for those)
+        from . import ops as _ops
+        self._static_x = [x if (frozen_weights and _is_dense(x) and _ops.is_static(x)) else (x.detach().clone() if _is_dense(x) else x) for x in xs]
         self._single = single
         self._model, self._adj = model, adj_list
         arg = self._static_x[0] if single else self._static_x
@@ -64,6 +67,10 @@ class GraphedInference:
             if len(xs) != len(self._static_x):
                 raise ValueError("GraphedInference: expected %d feature tensors, got %d" % (len(self._static_x), len(xs)))
             for dst, src in zip(self._static_x, xs):
+                if dst is src:
+                    continue
+                if _is_dense(dst) and getattr(dst, "_ctgcn_static", False):
+                    raise ValueError("GraphedInference(frozen_weights=True) recorded this static feature tensor in place: capture again for other features")
                 if _is_dense(dst):
                     if not _is_dense(src) or src.shape != dst.shape:
                         raise ValueError("GraphedInference: feature shapes are fixed at capture time")

@@ -460,8 +460,9 @@ def test_full_depth_window_matches_cpu_oracle_on_sampled_rows():
     atol 1e-5 for the HIP path against 1 433 for the fp32 CPU path of 4.1e8 — ratio 1.33, 95 % interval 1.18 - 1.50 (bootstrap over
     nodes); worst error 1.63e-4 against 1.18e-4; RMS 3.9e-7 against 3.6e-7.  So at depth 16 the tail excess IS systematic (the 2-step windows
     sit at 1.03 - 1.14), and it is not the fp16 x 2 operand split (round 5's guess: the build without any 16-bit operand shows the same) nor the
-    gate math's typical error (the RMS errors are equal since tanh became (1 - e)/(1 + e); the tail counts did not move with it): its
-    source is not identified.  Both paths stay 4e-6 of the entries away from the tolerance; the slack here is 1.6 x = the interval's upper end,
+    gate math's typical error (the RMS errors are equal since tanh became (1 - e)/(1 + e); the tail counts did not move with it): 98 %
+    of the outliers of either path sit in the top 1 % of the nodes by degree, three quarters in the last two steps — hub rows of the largest
+    snapshots, i.e. the aggregation's fp32 sums of hundreds of rows, which the HIP kernel adds in another order.  Both paths stay 4e-6 of the entries away from the tolerance; the slack here is 1.6 x = the interval's upper end,
     plus the sample's counting allowance."""
     import ctgcn_amd
     from ctgcn_amd.helper import core_adj_from_scipy

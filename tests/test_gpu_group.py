@@ -295,3 +295,29 @@ def test_frozen_graph_replay_matches_and_keeps_its_operands_alive(monkeypatch):
     junk = [torch.randn(1 << 20, device=DEV) for _ in range(8)]          # reuse whatever the cache released
     assert torch.equal(runner(), want)
     del junk
+
+
+def test_frozen_graph_replay_reads_static_dense_features_in_place():
+    """CTGCN-S on dense features the caller declared static (ops.mark_static: what the loader returns): the frozen capture records their cached
+    operand planes instead of splitting a private copy inside the graph on every replay; other features then need a new capture."""
+    from ctgcn_amd import CTGCN, ops
+    from ctgcn_amd.graph_capture import GraphedInference
+    n, T = 2001, 4
+    adjs = _window(n, T, 6, 5, seed=6)
+    torch.manual_seed(0)
+    model = CTGCN(300, 500, 128, 3, 1, T, model_type="S", trans_activate_type="N").to(DEV).eval()
+    xs = [ops.mark_static(torch.randn(n, 300, device=DEV)) for _ in range(T)]
+    with torch.no_grad():
+        want, want_tr = model(xs, adjs)
+        want = want.clone()
+    runner = GraphedInference(model, xs, adjs, frozen_weights=True)
+    got, got_tr = runner()
+    assert torch.equal(got, want) and all(torch.equal(a, b) for a, b in zip(got_tr, want_tr))
+    assert torch.equal(runner(xs)[0], want)                       # the same tensors: fine
+    with pytest.raises(ValueError):
+        runner([x * 0.5 for x in xs])
+    live = GraphedInference(model, xs, adjs)                      # live form: private input buffers, other features are copied in
+    xs2 = [x * 0.5 + 0.1 for x in xs]
+    with torch.no_grad():
+        want2 = model(xs2, adjs)[0].clone()
+    assert torch.equal(live(xs2)[0], want2)

@@ -30,8 +30,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 SLACK = {"window_T16_n200k": 1.6}
 
 
-def stats(got, want, want64, seed=0, boots=2000):
-    """got / want (fp32 HIP, fp32 CPU oracle) / want64: [T, n, d] arrays"""
+def stats(got, want, want64, seed=0, boots=2000, degree=None):
+    """got / want (fp32 HIP, fp32 CPU oracle) / want64: [T, n, d] arrays; degree [n]: stored entries per node of the largest snapshot (where the
+    outliers live: by step, and by the degree rank of their node)"""
     tol = 1e-4 * np.abs(want64) + 1e-5
     d_hip, d_cpu = np.abs(got - want64), np.abs(want - want64)
     bad_h, bad_c = d_hip > tol, d_cpu > tol
@@ -49,7 +50,16 @@ def stats(got, want, want64, seed=0, boots=2000):
                 ratios.append(float((w * h).sum()) / den)
     lo, hi = (float(np.percentile(ratios, 2.5)), float(np.percentile(ratios, 97.5))) if ratios else (None, None)
     size = got.size
-    return {"entries": int(size), "nodes_with_an_outlier": int(len(nz)),
+    where = {"outside_by_step_hip": [int(x) for x in bad_h.sum(axis=(1, 2))], "outside_by_step_cpu_fp32": [int(x) for x in bad_c.sum(axis=(1, 2))]}
+    if degree is not None and len(nz):
+        order = np.argsort(-np.asarray(degree), kind="stable")
+        rank = np.empty(len(order), dtype=np.int64)
+        rank[order] = np.arange(len(order))
+        top1 = rank[nz] < max(1, len(order) // 100)
+        where.update(outlier_nodes_in_top_1pct_degree=int(top1.sum()), outside_hip_in_those=int(per_node_h[nz][top1].sum()),
+                     outside_cpu_in_those=int(per_node_c[nz][top1].sum()), median_degree_of_outlier_nodes=float(np.median(np.asarray(degree)[nz])),
+                     median_degree_overall=float(np.median(degree)))
+    return {"entries": int(size), "nodes_with_an_outlier": int(len(nz)), "where": where,
             "outside_hip": int(bad_h.sum()), "outside_cpu_fp32": int(bad_c.sum()), "outside_both": int((bad_h & bad_c).sum()),
             "frac_outside_hip": float(bad_h.sum()) / size, "frac_outside_cpu_fp32": float(bad_c.sum()) / size,
             "ratio_hip_over_cpu": (float(bad_h.sum()) / float(bad_c.sum())) if bad_c.sum() else None, "ratio_95_interval": [lo, hi],
@@ -161,7 +171,7 @@ def window_t16():
     with torch.no_grad():
         got = model([x.to(G.DEV) for x in xs], adj).cpu().numpy()
     want, want64, t32, t64 = G._oracle_fp32_and_fp64(sd, xs, ref_adj)
-    out = stats(got, want.numpy(), want64.numpy())
+    out = stats(got, want.numpy(), want64.numpy(), degree=np.diff(graphs[-1].indptr))
     out.update(oracle_fp32_s=round(t32, 1), oracle_fp64_s=round(t64, 1), nodes=n, snapshots=T)
     return out
 

@@ -170,9 +170,19 @@ def window_t16():
     model.to(G.DEV)
     with torch.no_grad():
         got = model([x.to(G.DEV) for x in xs], adj).cpu().numpy()
+    os.environ["CTGCN_FP32_MFMA_ONLY"] = "1"           # the same forward without any 16-bit operand (hub rows have a wide dynamic range per row)
+    try:
+        with torch.no_grad():
+            got_exact = model([x.to(G.DEV) for x in xs], adj).cpu().numpy()
+    finally:
+        del os.environ["CTGCN_FP32_MFMA_ONLY"]
     want, want64, t32, t64 = G._oracle_fp32_and_fp64(sd, xs, ref_adj)
-    out = stats(got, want.numpy(), want64.numpy(), degree=np.diff(graphs[-1].indptr))
+    deg = np.diff(graphs[-1].indptr)
+    out = stats(got, want.numpy(), want64.numpy(), degree=deg)
     out.update(oracle_fp32_s=round(t32, 1), oracle_fp64_s=round(t64, 1), nodes=n, snapshots=T)
+    ex = stats(got_exact, want.numpy(), want64.numpy(), degree=deg)
+    out["exact_fp32_mode"] = {k: ex[k] for k in ("outside_hip", "outside_cpu_fp32", "ratio_hip_over_cpu", "ratio_95_interval", "rms_err_hip_vs_fp64",
+                                                  "max_err_hip_vs_fp64", "where")}
     return out
 
 

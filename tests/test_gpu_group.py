@@ -177,6 +177,47 @@ def test_training_on_streams_gives_the_same_gradients(monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_training_on_streams_with_gradient_accumulation_and_retain_graph(monkeypatch):
+    """the multi-stream training path under the patterns the reference's trainer uses — gradients ACCUMULATED over several batches before
+    one optimizer step (embedding.py:346-352 steps once per epoch) — and under retain_graph (two backward passes through one forward: the
+    kept projection buffer of a GRU is used once, the second backward recomputes): bit-identical to the same sequence on one stream."""
+    from ctgcn_amd import CTGCN
+    n, T = 1500, 4
+    adjs = _window(n, T, 5, 5, seed=9)
+    torch.manual_seed(5)
+    model = CTGCN(n, 200, 128, 1, 2, T, model_type="C", trans_activate_type="L").to(DEV).train()
+    idx = torch.arange(n, device=DEV)
+    eye = torch.sparse_coo_tensor(torch.stack([idx, idx]), torch.ones(n, device=DEV), (n, n)).coalesce()
+    xs = [eye for _ in range(T)]
+    Gs = [torch.randn(T, n, 128, device=DEV) for _ in range(3)]
+    res = {}
+    for k in ("1", "3"):
+        monkeypatch.setenv("CTGCN_TRAIN_STREAMS", k)
+        for p in model.parameters():
+            p.grad = None
+        for G in Gs[:2]:                                        # two batches accumulate into .grad
+            (model(xs, adjs) * G).sum().backward()
+        out = model(xs, adjs)                                   # one forward, two backward passes
+        (out * Gs[2]).sum().backward(retain_graph=True)
+        (out * Gs[0]).sum().backward()
+        torch.cuda.synchronize()
+        res[k] = [out.detach().clone()] + [p.grad.clone() for p in model.parameters() if p.grad is not None]
+        assert len(res[k]) > 20 and all(torch.isfinite(g).all() for g in res[k])
+    for a, b in zip(res["1"], res["3"]):
+        assert torch.equal(a, b)
+    # and the accumulated gradient is the sum of the single-batch gradients (to fp32 summation order)
+    monkeypatch.setenv("CTGCN_TRAIN_STREAMS", "3")
+    singles = []
+    for G in (Gs[0], Gs[1], Gs[2], Gs[0]):
+        for p in model.parameters():
+            p.grad = None
+        (model(xs, adjs) * G).sum().backward()
+        singles.append([p.grad.clone() for p in model.parameters() if p.grad is not None])
+    for i, acc in enumerate(res["3"][1:]):
+        want = sum(s_[i] for s_ in singles)
+        assert float((acc - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-7
+
+
 def test_steady_state_forwards_write_no_descriptor_table(monkeypatch):
     """ABI 28: the grouped launches keep (device table, host shadow) pairs between forwards.  In the steady state of an
     inference loop over one window every call finds its table current — the counter of written tables stands still, the counter of tables

@@ -2688,6 +2688,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gru_layer_h2_kernel(const Lay
 #ifndef CTGCN_LAYER_LOOKAHEAD
 #define CTGCN_LAYER_LOOKAHEAD 1      // 0: A/B build without the early x products of gru_layer8_h2_kernel<presplit, sum>
 #endif
+#ifndef CTGCN_X_GLDS
+#define CTGCN_X_GLDS 0               // 1: A/B build — the row-plan path's x planes travel global -> LDS directly (global_load_lds), ring of three slots.
+                                     // Measured in round 6 (tools/runs/r6_glds_ab.sh): bit-identical, 3.56 / 4.25 ms against 3.23 / 3.83 ms per 1 M x 8 call
+                                     // (snapshots 3 / 15): 10 % SLOWER — hipcc drains the DMA queue (vmcnt(0)) in front of every s_barrier, one per unit
+#endif
 constexpr int L8_WL = 12;
 constexpr int L8_PITCH = 128;                            // halfs per plane row, no padding
 // half index of element k of row r (r < 16): 16-byte segment k / 8 goes to segment (k / 8) ^ r
@@ -2720,7 +2725,9 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
     // pattern of the kernel is then conflict-free: the MFMA operand reads (ds_read_b128: lane = (row, k group) — with the 8-half row
     // padding of the other GRU kernels rows 11 and 12 met in one bank group: SQ_LDS_BANK_CONFLICT was 26 % of the LDS cycles), the
     // staging writes (32 lanes along a row) and the publish writes (16 rows at one column block).  It also frees 2 KB of LDS.
-    __shared__ _Float16 Xs[2][2][16][L8_PITCH];          // ring of two units: the two fp16 planes of 16 rows of x_t
+    constexpr bool GLDS = CTGCN_X_GLDS && CTGCN_LAYER_LOOKAHEAD && PRESPLIT && REDUCE && !SAVE;
+    constexpr int XNS = GLDS ? 3 : 2;
+    __shared__ _Float16 Xs[XNS][2][16][L8_PITCH];        // ring of two (GLDS build: three) units: the two fp16 planes of 16 rows of x_t
     __shared__ _Float16 Hs[2][2][16][L8_PITCH];          // [step parity][plane]: h_t·2^14 (after the last step: the summed rows in fp32)
     __shared__ float xscale[2][16];
     __shared__ float wsc_ih[3][GRU_H];
@@ -2991,7 +2998,63 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
                 if (++pt >= S) { pt = 0; ptile += nblk; pring = (pring + 1) & 3; break; }     // step 0 of a tile is always fresh
             } while (!mask_bit(pmask, pt));
         };
-        if (stager) {
+        // ---- GLDS build (A/B): the planes of a fresh unit go global -> LDS by DMA (global_load_lds_dwordx4: lane L of stager wave w lands at
+        // byte 16 L of rows 4w .. 4w + 3 of the slot, so it REQUESTS segment (L & 15) ^ row of its row: the XOR swizzle moves to the source
+        // address), the row scales and output rows by global_load_lds_dword; no staging registers, no ds_write pass.  hipcc drains the DMA
+        // queue (vmcnt(0)) in front of every s_barrier while such a load is in flight, so a unit is requested right AFTER a barrier — at the
+        // head of a compute unit — and has that unit's time to land; ring of three slots (the slot x_products read last is free after the
+        // barrier), at most two units ahead, one request per compute unit.  A tile's step mask is an ordinary load requested with its step 0
+        // and looked at one tick later (mask_pending): where the pipeline goes after step 0 is only known then.
+        __shared__ float xsc_s[XNS][16];
+        int n_issued = 0, n_consumed = 0;
+        bool mask_pending = false;
+        mask_t mreg = MASK_ALL;
+        int mring = 0;
+        auto advance_p = [&]() {
+            do {
+                if (++pt >= S) { pt = 0; ptile += nblk; pring = (pring + 1) & 3; break; }     // step 0 of a tile is always fresh
+            } while (!mask_bit(pmask, pt));
+        };
+        auto tick = [&]() {                               // stager waves, once per compute unit (and twice in the prologue)
+            if constexpr (GLDS) {
+                if (mask_pending) {                       // the mask requested one tick ago (a barrier with vmcnt(0) lies in between)
+                    pmask = uniform_mask(mreg);
+                    if (tid == 0) msk_s[mring] = pmask;
+                    mask_pending = false;
+                    advance_p();
+                }
+                if (n_issued - n_consumed >= 2 || ptile >= ntiles) return;
+                const int islot = n_issued % 3;
+                const int r = wave_u * 4 + (lane >> 4);
+                const int64_t row = min(ptile * 16 + r, a.rows - 1);
+                const int64_t rs_ = row * S + pt;
+                const int q = ((lane & 15) ^ r) & 15;
+                if (pt == 0 && a.tmask) { mreg = load_mask(ptile); }        // older than the DMA requests below: its wait does not wait for them
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.xp1 + rs_ * GRU_H + q * 8),
+                                                 (__attribute__((address_space(3))) void *)(&Xs[islot][0][wave_u * 4][0]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.xp2 + rs_ * GRU_H + q * 8),
+                                                 (__attribute__((address_space(3))) void *)(&Xs[islot][1][wave_u * 4][0]), 16, 0, 0);
+                if (lane < 4) {
+                    const int64_t row4 = min(ptile * 16 + wave_u * 4 + lane, a.rows - 1);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.xps + row4 * S + pt),
+                                                     (__attribute__((address_space(3))) void *)(&xsc_s[islot][wave_u * 4]), 4, 0, 0);
+                    if (pt == 0) {
+                        if (a.order)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.order + row4),
+                                                             (__attribute__((address_space(3))) void *)(&ord_s[pring][wave_u * 4]), 4, 0, 0);
+                        else ord_s[pring][wave_u * 4 + lane] = (int32_t)row4;
+                    }
+                }
+                ++n_issued;
+                if (pt == 0) {
+                    if (a.tmask) { mask_pending = true; mring = pring; }
+                    else { pmask = MASK_ALL; if (tid == 0) msk_s[pring] = MASK_ALL; advance_p(); }
+                } else advance_p();
+            }
+        };
+        if constexpr (GLDS) {
+            if (stager) { tick(); tick(); }
+        } else if (stager) {
             load_xp();
             stage_xp(0);
             load_xp();
@@ -3004,7 +3067,8 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         auto x_begin = [&]() {
 #pragma unroll
             for (int g = 0; g < 3; ++g) acc0[g] = zero4;
-            rs_n = __uint_as_float(xmeta[xslot][col][0]);
+            if constexpr (GLDS) rs_n = xsc_s[xslot][col];
+            else rs_n = __uint_as_float(xmeta[xslot][col][0]);
             xo1 = *(const h8v *)(&Xs[xslot][0][col][l8_off(col, 8 * grp)]);
             xo2 = *(const h8v *)(&Xs[xslot][1][col][l8_off(col, 8 * grp)]);
         };
@@ -3034,11 +3098,16 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
         };
         auto x_end = [&]() {
             // the planes of the fresh unit after this one (in registers since the last call) go to the other slot; request the one after
-            if (stager) {
-                stage_xp(xslot ^ 1);
-                load_xp();
+            if constexpr (GLDS) {
+                xslot = xslot == 2 ? 0 : xslot + 1;
+                ++n_consumed;
+            } else {
+                if (stager) {
+                    stage_xp(xslot ^ 1);
+                    load_xp();
+                }
+                xslot ^= 1;
             }
-            xslot ^= 1;
         };
         auto x_products = [&]() {
             x_begin();
@@ -3084,6 +3153,7 @@ __device__ __forceinline__ void gru_layer8_h2_body(const LayerArgs &a, const int
             const mask_t tmask = uniform_mask(msk_s[cring]);
             f4v gi[3] = {zero4, zero4, zero4};
             for (int t = 0; t < S; ++t) {
+                if constexpr (GLDS) { if (stager) tick(); }     // the next fresh unit's DMA, right behind the barrier that ended the last unit
                 if (t == 0) pending_layernorm();          // the previous tile's rows (its last unit ended with a barrier)
                 TL_MARK(5)                                // row-plan form: [0] h products issued, [1] gate math, [2] publish, [3] x products issued, [4] barrier, [5] LayerNorm, [6] units, [7] fresh, [8] x staging + next request
                 if (mask_bit(tmask, t)) {
